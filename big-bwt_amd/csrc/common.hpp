@@ -1,0 +1,178 @@
+// common.hpp -- shared host-side plumbing for libpfpgpu (context, errors, device buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <chrono>
+#include "../../include/pfpgpu.h"
+
+namespace pfp {
+
+// special bytes of the parse (utils.h:6-8)
+constexpr uint8_t kDollar = 2, kEndOfWord = 1, kEndOfDict = 0;
+// Karp-Rabin window modulus (newscan.cpp:172)
+constexpr uint32_t kPrime = 1999999973u;
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define PFP_HIP(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      throw ::pfp::Error(PFP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__) +   \
+                                       " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+
+#define PFP_REQUIRE(cond, code, msg)                       \
+  do {                                                     \
+    if (!(cond)) throw ::pfp::Error((code), (msg));        \
+  } while (0)
+
+inline int cdiv(uint64_t a, uint64_t b) { return (int)((a + b - 1) / b); }
+inline uint64_t cdiv64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+inline int bits_for(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b)) b++; return b; }
+
+}  // namespace pfp
+
+// Device memory pool of one context.  All work of a context is issued on ONE stream, so a block
+// released by the host can be handed out again at once: every later use is ordered behind every
+// earlier use by the stream itself.  Blocks are cached until pfp_ctx_destroy (steady-state calls
+// do not touch hipMalloc); best-fit reuse within 25 % slack.
+struct pfp_pool {
+  struct Block { void *p; size_t bytes; };
+  std::vector<Block> free_list;
+  std::vector<Block> all;
+  size_t total_bytes = 0;
+  void *get(size_t bytes, hipError_t *err) {
+    *err = hipSuccess;
+    size_t best = (size_t)-1, bi = (size_t)-1;
+    for (size_t i = 0; i < free_list.size(); i++) {
+      size_t b = free_list[i].bytes;
+      if (b >= bytes && b <= bytes + bytes / 4 + 4096 && b < best) { best = b; bi = i; }
+    }
+    if (bi != (size_t)-1) {
+      void *p = free_list[bi].p;
+      free_list[bi] = free_list.back(); free_list.pop_back();
+      return p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {   // give cached blocks back to the driver and retry once
+      (void)hipGetLastError();
+      trim();
+      e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) { *err = e; (void)hipGetLastError(); return nullptr; }
+    all.push_back({p, bytes}); total_bytes += bytes;
+    return p;
+  }
+  void put(void *p) {
+    for (auto &b : all) if (b.p == p) { free_list.push_back(b); return; }
+  }
+  void trim() {   // caller guarantees the stream is idle
+    (void)hipDeviceSynchronize();
+    for (auto &f : free_list) {
+      (void)hipFree(f.p);
+      for (size_t i = 0; i < all.size(); i++) if (all[i].p == f.p) { total_bytes -= all[i].bytes; all[i] = all.back(); all.pop_back(); break; }
+    }
+    free_list.clear();
+  }
+  void destroy() {
+    for (auto &b : all) (void)hipFree(b.p);
+    all.clear(); free_list.clear(); total_bytes = 0;
+  }
+};
+
+struct pfp_ctx {
+  int device = 0;
+  pfp_pool pool;
+  bool debug = false;             // PFP_DEBUG=1: validate every intermediate on the host
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool profiling = false;
+  pfp_stats stats{};
+  int n_cu = 256;
+  // pinned staging scalars for D2H counters
+  uint64_t *h_scalars = nullptr;  // 16 x u64, pinned
+  void *staged = nullptr;         // pfp::StagedText kept by pfp_stage_text_dev
+  void *k1scratch = nullptr;      // scratch of pfp_scan_k1_enqueue
+};
+
+namespace pfp {
+
+// Device buffer drawn from the context's pool (see pfp_pool).
+template <class T>
+struct DBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  pfp_ctx *ctx = nullptr;
+  DBuf() = default;
+  DBuf(pfp_ctx *c, size_t count) { alloc(c, count); }
+  DBuf(const DBuf &) = delete;
+  DBuf &operator=(const DBuf &) = delete;
+  DBuf(DBuf &&o) noexcept { *this = std::move(o); }
+  DBuf &operator=(DBuf &&o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; ctx = o.ctx; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DBuf() { release(); }
+  void alloc(pfp_ctx *c, size_t count) {
+    release();
+    ctx = c; n = count;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    bytes = (bytes + 511) & ~size_t(511);
+    hipError_t e;
+    p = (T *)c->pool.get(bytes, &e);
+    if (!p)
+      throw Error(e == hipErrorOutOfMemory ? PFP_ENOMEM : PFP_EHIP,
+                  std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+  }
+  void release() {
+    if (p) { ctx->pool.put(p); p = nullptr; n = 0; }
+  }
+  void zero() { PFP_HIP(hipMemsetAsync(p, 0, n * sizeof(T), ctx->stream)); }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+template <class T>
+inline void d2h(pfp_ctx *c, T *dst, const T *src, size_t count) {
+  PFP_HIP(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+}
+template <class T>
+inline void h2d(pfp_ctx *c, T *dst, const T *src, size_t count) {
+  PFP_HIP(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+}
+inline void sync(pfp_ctx *c) { PFP_HIP(hipStreamSynchronize(c->stream)); }
+
+// read one device scalar (syncs the stream)
+template <class T>
+inline T read_scalar(pfp_ctx *c, const T *dptr) {
+  static_assert(sizeof(T) <= 8, "scalar");
+  PFP_HIP(hipMemcpyAsync(c->h_scalars, dptr, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  T v;
+  memcpy(&v, c->h_scalars, sizeof(T));
+  return v;
+}
+
+struct PhaseTimer {
+  pfp_ctx *c; double *slot; std::chrono::steady_clock::time_point t0;
+  PhaseTimer(pfp_ctx *ctx, double *s) : c(ctx), slot(s) {
+    if (c->profiling) { (void)hipStreamSynchronize(c->stream); t0 = std::chrono::steady_clock::now(); }
+  }
+  ~PhaseTimer() {
+    if (c->profiling) {
+      (void)hipStreamSynchronize(c->stream);
+      *slot += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
+};
+
+}  // namespace pfp

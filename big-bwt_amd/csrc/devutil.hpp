@@ -1,0 +1,48 @@
+// devutil.hpp -- small device-side helpers (unaligned vector access, sub-wave reductions).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace pfp {
+
+// gfx950 runs with unaligned-access mode on: a dwordx4 global load/store may start at any byte.
+struct __attribute__((packed, aligned(1))) U128u { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U64u { uint64_t v; };
+
+__device__ __forceinline__ uint4 ld16u(const uint8_t *p) {
+  U128u v = *reinterpret_cast<const U128u *>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st16u(uint8_t *p, uint4 v) {
+  U128u u{v.x, v.y, v.z, v.w};
+  *reinterpret_cast<U128u *>(p) = u;
+}
+__device__ __forceinline__ uint64_t ld8u(const uint8_t *p) { return reinterpret_cast<const U64u *>(p)->v; }
+
+// zero the bytes at index >= keep (0..16) of a little-endian 16-byte register block
+__device__ __forceinline__ uint4 keep_bytes16(uint4 v, int keep) {
+  uint32_t r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int k = keep - 4 * i;
+    r[i] = k >= 4 ? r[i] : (k <= 0 ? 0u : (r[i] & ((1u << (8 * k)) - 1u)));
+  }
+  return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return k;
+}
+
+// sum over the 8 lanes of an aligned 8-lane group
+__device__ __forceinline__ uint64_t group8_sum(uint64_t v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t group8_or(uint32_t v) {
+  v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64); v |= __shfl_xor(v, 4, 64);
+  return v;
+}
+
+}  // namespace pfp

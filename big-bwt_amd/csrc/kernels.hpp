@@ -1,0 +1,112 @@
+// kernels.hpp -- declarations shared by the pipeline translation units.
+#pragma once
+#include "common.hpp"
+
+namespace pfp {
+
+// ---------------------------------------------------------------- text staging
+// T' = Dollar . T . Dollar^w lives in HBM with a zeroed 64-byte front pad so that T[0] is
+// 16-byte aligned, T'[x] = tprime()[x], and short unaligned over-reads stay inside the buffer.
+struct StagedText {
+  static constexpr size_t kFront = 64, kBack = 128;
+  DBuf<uint8_t> buf;
+  uint64_t n = 0;
+  int w = 0;
+  const uint8_t *tbase() const { return buf.p + kFront; }        // T[i]
+  const uint8_t *tprime() const { return buf.p + kFront - 1; }   // T'[x]
+  void stage(pfp_ctx *c, const void *src, bool src_on_device, uint64_t n_, int w_);
+  void restage_tail(pfp_ctx *c, uint64_t new_n, int w_) const;    // Dollars at [new_n,new_n+w), zeros after
+};
+
+// ---------------------------------------------------------------- stage 1a (scan.hip)
+struct KRParams { uint32_t negpw, pinv, pshift, plimit; };
+KRParams make_kr_params(int w, uint64_t p);
+void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p, uint16_t *flags16,
+                uint32_t *block_counts, unsigned long long *first_bad);
+uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, DBuf<uint64_t> &d_ends,
+                   uint64_t *n_used);
+
+// ---------------------------------------------------------------- stage 1b (phrase.hip)
+// Distinct phrases (the dictionary) in first-occurrence order plus the parse as word ids.
+struct Dictionary {
+  uint64_t P = 0;          // # phrases
+  uint64_t d = 0;          // # distinct words
+  uint64_t dsize = 0;      // bytes of dict incl. one 0x01 per word and the final 0x00
+  DBuf<uint8_t> bytes;     // D (padded with zeros: +64 front is not needed, +64 back)
+  DBuf<uint64_t> woff;     // [d+1] start of word j in bytes; woff[d] = dsize-1
+  DBuf<uint32_t> wlen;     // [d]
+  DBuf<uint32_t> wocc;     // [d]
+  DBuf<uint32_t> pid;      // [P] word id of phrase k (empty when built from a .dict file)
+  DBuf<uint8_t> last;      // [P] .last
+  DBuf<uint64_t> sai;      // [P] .sai values
+  uint64_t reseeds = 0;
+};
+void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const DBuf<uint64_t> &ends, uint64_t n_ends,
+                      bool want_sai, Dictionary &D);
+// dictionary from a reference-format .dict/.occ pair already in device memory
+void dictionary_from_bytes(pfp_ctx *c, Dictionary &D);
+
+// ---------------------------------------------------------------- suffix sorting (sufsort.hip)
+struct SuffixOrder {
+  uint64_t N = 0;
+  DBuf<uint32_t> sa;     // [N] suffix start positions in sorted order (ties: position order)
+  DBuf<uint32_t> rank;   // [N] rank[i] = first sa slot of i's group (equal strings share it)
+  uint64_t rounds = 0;
+};
+// Suffixes of the dictionary as 0x01-terminated strings (gsacak semantics):
+// pos_word[i] = word containing position i (d for the final 0x00), wend[j] = position of
+// word j's terminator.
+void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *pos_word,
+                        const uint32_t *wend, uint64_t d, SuffixOrder &out);
+// plain suffix array of an integer string with unique smallest last symbol (sacak_int)
+void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out);
+// plain suffix array of a byte string with s[N-1]==0 unique smallest (sacak)
+void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrder &out);
+
+// ---------------------------------------------------------------- stage 2+3 (merge.hip)
+struct DictIndex {        // per-position / per-word helper arrays over the dictionary
+  DBuf<uint32_t> pos_word;   // [dsize]
+  DBuf<uint32_t> wend;       // [d+1] terminator position of word j (wend[d] = dsize-1)
+  DBuf<uint32_t> lexrank;    // [d] 0-based lexicographic rank of word j
+};
+void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix);
+void compute_lexrank(pfp_ctx *c, const Dictionary &D, const SuffixOrder &so, DictIndex &ix);
+
+struct ParseBWT {         // outputs of bwtparse.c in HBM
+  uint64_t P = 0;
+  DBuf<uint32_t> ilist;    // [P+1]
+  DBuf<uint8_t> bwlast;    // [P+1]
+  DBuf<uint64_t> bwsai;    // [P+1] (only with SA flags)
+  uint64_t rounds = 0;
+};
+// parse symbols are 1-based lexicographic ranks; occ_lex[r] = occurrences of rank r
+void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t *last, const uint64_t *sai,
+               const uint32_t *occ_lex, uint64_t d, ParseBWT &out);
+
+struct BwtOutputs {
+  uint64_t n_out = 0;      // n+1
+  uint8_t *d_bwt = nullptr;    // [n+1] device, caller-provided
+  uint64_t *d_sa = nullptr;    // [n+1] device, caller-provided when flags != 0
+  uint64_t hard_groups = 0, hard_chars = 0;
+};
+void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, const ParseBWT &pb,
+               const uint32_t *occ_lex, int w, int flags, uint64_t expect_n_out, BwtOutputs &out);
+
+// 5-byte packing and run sampling of finished device outputs
+void pack5_dev(pfp_ctx *c, const uint64_t *vals, uint64_t cnt, uint8_t *out5);
+void unpack5_dev(pfp_ctx *c, const uint8_t *in5, uint64_t cnt, uint64_t *vals);
+// pairs (pos,sa) packed as 10 bytes each; returns pair count; out buffer allocated inside
+uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const uint64_t *sa, uint64_t n_out, bool run_end,
+                         DBuf<uint8_t> &out10);
+
+
+// ---------------------------------------------------------------- PFP_DEBUG=1 (validate.hip)
+void validate_scan(pfp_ctx *c, const DBuf<uint64_t> &ends, uint64_t n_ends, uint64_t n, int w);
+void validate_dictionary(pfp_ctx *c, const Dictionary &D, int w);
+void validate_index(pfp_ctx *c, const Dictionary &D, const DictIndex &ix);
+void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, const SuffixOrder &so, bool dict_mode, const char *what);
+void validate_int_sa(pfp_ctx *c, const uint32_t *sym, const SuffixOrder &so);
+void validate_lexrank(pfp_ctx *c, const Dictionary &D, const DictIndex &ix);
+void validate_parse_bwt(pfp_ctx *c, const ParseBWT &pb);
+
+}  // namespace pfp

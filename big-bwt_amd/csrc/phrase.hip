@@ -1,0 +1,307 @@
+// phrase.hip -- stage 1b: phrase identity, deduplication, dictionary build.
+//
+// Replaces save_update_word + the std::map<hash,word_stats> of the reference parser
+// (newscan.cpp:229-304; sharded twin pscan.cpp:137-205) and the dictionary/occ writer
+// (newscan.cpp:394-441).  Design, MI355X-first:
+//   * phrase k is T'[start_k .. end_k] with end_k from the scan's ends[]; nothing is copied.
+//   * identity hash: order-sensitive *commutative* sum  sum_j mix(chunk_j, j)  over 8-byte
+//     chunks, so an 8-lane group hashes a typical phrase with one 16-byte unaligned load per
+//     lane and a giant phrase (an 18 Mb run of N) is split over the whole chip and combined
+//     with 64-bit atomic adds - no sequential Horner chain as in kr_hash (newscan.cpp:229-239).
+//   * dedup = radix sort of (hash, phrase#) + adjacent compare.  Every occurrence is verified
+//     byte-for-byte against its predecessor (the reference compares strings on every hit,
+//     newscan.cpp:282); a mismatch reseeds the hash and retries, so the result is exact.
+//   * words are numbered in first-occurrence order; the lexicographic ranks the reference
+//     assigns with std::sort (newscan.cpp:622-636) fall out of the dictionary suffix sort.
+#include "kernels.hpp"
+#include "prims.hpp"
+#include "devutil.hpp"
+
+namespace pfp {
+
+constexpr uint32_t kLongPhrase = 8192;  // phrases longer than this are split across blocks
+
+struct PhraseGeom {
+  const uint64_t *ends; uint64_t ne; uint64_t n; int w;
+};
+__device__ __forceinline__ uint64_t ph_end(const PhraseGeom &g, uint64_t k) {   // T' index of last byte
+  return k < g.ne ? g.ends[k] + 1 : g.n + (uint64_t)g.w;
+}
+__device__ __forceinline__ uint64_t ph_start(const PhraseGeom &g, uint64_t k) { // T' index of first byte
+  return k == 0 ? 0 : g.ends[k - 1] + 2 - (uint64_t)g.w;
+}
+
+__device__ __forceinline__ uint64_t chunk_term(uint64_t x, uint64_t idx, uint64_t seed) {
+  uint64_t t = x ^ (seed + idx * 0x9E3779B97F4A7C15ULL);
+  t *= 0xD6E8FEB86659FD93ULL;
+  t ^= t >> 32;
+  return t;
+}
+// contribution of the 16-byte piece at byte offset off of a phrase of length len
+__device__ __forceinline__ uint64_t piece_terms(const uint8_t *src, uint64_t off, uint64_t len, uint64_t seed) {
+  uint4 v = ld16u(src + off);
+  int keep = (len - off) >= 16 ? 16 : (int)(len - off);
+  v = keep_bytes16(v, keep);
+  uint64_t x0 = (uint64_t)v.x | ((uint64_t)v.y << 32), x1 = (uint64_t)v.z | ((uint64_t)v.w << 32);
+  uint64_t s = chunk_term(x0, off >> 3, seed);
+  if (keep > 8) s += chunk_term(x1, (off >> 3) + 1, seed);
+  return s;
+}
+__device__ __forceinline__ uint64_t finish_hash(uint64_t sum, uint64_t len) {
+  return fmix64(sum ^ (len * 0xA24BAED4963EE407ULL));
+}
+
+__global__ __launch_bounds__(256) void phrase_hash_kernel(const uint8_t *__restrict__ tp, PhraseGeom g, uint64_t P,
+                                                          uint64_t seed, uint64_t *__restrict__ hash,
+                                                          uint32_t *__restrict__ long_list,
+                                                          uint32_t *__restrict__ long_count) {
+  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t k = t >> 3;
+  int l8 = (int)(t & 7);
+  if (k >= P) return;
+  uint64_t s = ph_start(g, k), len = ph_end(g, k) - s + 1;
+  if (len > kLongPhrase) {
+    if (l8 == 0) { uint32_t i = atomicAdd(long_count, 1u); long_list[i] = (uint32_t)k; }
+    return;
+  }
+  uint64_t sum = 0;
+  for (uint64_t off = (uint64_t)l8 * 16; off < len; off += 128) sum += piece_terms(tp + s, off, len, seed);
+  sum = group8_sum(sum);
+  if (l8 == 0) hash[k] = finish_hash(sum, len);
+}
+
+__global__ __launch_bounds__(256) void phrase_hash_long_kernel(const uint8_t *__restrict__ tp, PhraseGeom g,
+                                                               uint64_t seed, const uint32_t *__restrict__ long_list,
+                                                               uint32_t nlong, unsigned long long *__restrict__ hsum) {
+  __shared__ uint64_t wsum[4];
+  for (uint32_t li = 0; li < nlong; li++) {
+    uint64_t k = long_list[li];
+    uint64_t s = ph_start(g, k), len = ph_end(g, k) - s + 1;
+    uint64_t npieces = (len + 15) >> 4;
+    uint64_t sum = 0;
+    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < npieces; c += (uint64_t)gridDim.x * 256)
+      sum += piece_terms(tp + s, c * 16, len, seed);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint64_t b = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      if (b) atomicAdd(&hsum[li], (unsigned long long)b);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void phrase_hash_long_finish_kernel(PhraseGeom g, const uint32_t *__restrict__ long_list, uint32_t nlong,
+                                               const unsigned long long *__restrict__ hsum,
+                                               uint64_t *__restrict__ hash) {
+  uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= nlong) return;
+  uint64_t k = long_list[li];
+  uint64_t len = ph_end(g, k) - ph_start(g, k) + 1;
+  hash[k] = finish_hash(hsum[li], len);
+}
+
+__global__ void iota_u32_kernel(uint32_t *p, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+
+// sorted by hash: head flags + byte verification against the predecessor
+__global__ __launch_bounds__(256) void dedup_verify_kernel(const uint8_t *__restrict__ tp, PhraseGeom g, uint64_t P,
+                                                           const uint64_t *__restrict__ ks,
+                                                           const uint32_t *__restrict__ vs,
+                                                           uint32_t *__restrict__ head, uint32_t *__restrict__ collision) {
+  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t i = t >> 3;
+  int l8 = (int)(t & 7);
+  if (i >= P) return;
+  bool hd = (i == 0) || ks[i] != ks[i - 1];
+  if (l8 == 0) head[i] = hd ? 1u : 0u;
+  if (hd) return;
+  uint64_t a = vs[i], b = vs[i - 1];
+  uint64_t sa = ph_start(g, a), la = ph_end(g, a) - sa + 1;
+  uint64_t sb = ph_start(g, b), lb = ph_end(g, b) - sb + 1;
+  uint32_t diff = (la != lb) ? 1u : 0u;
+  if (!diff && sa != sb) {
+    for (uint64_t off = (uint64_t)l8 * 16; off < la; off += 128) {
+      int keep = (la - off) >= 16 ? 16 : (int)(la - off);
+      uint4 va = keep_bytes16(ld16u(tp + sa + off), keep), vb = keep_bytes16(ld16u(tp + sb + off), keep);
+      diff |= (va.x ^ vb.x) | (va.y ^ vb.y) | (va.z ^ vb.z) | (va.w ^ vb.w);
+    }
+  }
+  diff = group8_or(diff);
+  if (diff && l8 == 0) atomicOr(collision, 1u);
+}
+
+__global__ void collect_words_kernel(uint64_t P, const uint32_t *__restrict__ head, const uint32_t *__restrict__ hscan,
+                                     const uint32_t *__restrict__ vs, uint32_t *__restrict__ hrep,
+                                     uint32_t *__restrict__ hpos, uint32_t d) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) hpos[d] = (uint32_t)P;
+  if (i >= P || !head[i]) return;
+  uint32_t hw = hscan[i] - 1;
+  hrep[hw] = vs[i];   // stable sort => smallest phrase index of the run
+  hpos[hw] = (uint32_t)i;
+}
+
+__global__ void finish_words_kernel(PhraseGeom g, uint32_t d, const uint32_t *__restrict__ rep_sorted,
+                                    const uint32_t *__restrict__ hw_sorted, const uint32_t *__restrict__ hpos,
+                                    uint32_t *__restrict__ fo_of_hw, uint32_t *__restrict__ wlen,
+                                    uint32_t *__restrict__ wlen1, uint64_t *__restrict__ wsrc,
+                                    uint32_t *__restrict__ wocc, uint32_t *__restrict__ toolong) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) wlen1[d] = 0;
+  if (j >= d) return;
+  uint32_t hw = hw_sorted[j];
+  fo_of_hw[hw] = j;
+  uint64_t k = rep_sorted[j];
+  uint64_t s = ph_start(g, k), len = ph_end(g, k) - s + 1;
+  if (len >= 0xFFFFFFF0ull) { atomicOr(toolong, 1u); len = 0xFFFFFFF0ull; }
+  wlen[j] = (uint32_t)len;
+  wlen1[j] = (uint32_t)len + 1;
+  wsrc[j] = s;
+  wocc[j] = hpos[hw + 1] - hpos[hw];
+}
+
+__global__ void assign_pid_kernel(uint64_t P, const uint32_t *__restrict__ hscan, const uint32_t *__restrict__ vs,
+                                  const uint32_t *__restrict__ fo_of_hw, uint32_t *__restrict__ pid) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P) pid[vs[i]] = fo_of_hw[hscan[i] - 1];
+}
+
+// copy one 16-byte piece (or its partial tail) of a word
+__device__ __forceinline__ void copy_piece(const uint8_t *src, uint8_t *dst, uint64_t off, uint64_t len) {
+  if (off + 16 <= len) {
+    st16u(dst + off, ld16u(src + off));
+  } else {
+    for (uint64_t b = off; b < len; b++) dst[b] = src[b];
+  }
+}
+
+__global__ __launch_bounds__(256) void dict_copy_kernel(const uint8_t *__restrict__ tp, uint32_t d,
+                                                        const uint64_t *__restrict__ wsrc,
+                                                        const uint32_t *__restrict__ wlen,
+                                                        const uint64_t *__restrict__ woff, uint8_t *__restrict__ D,
+                                                        uint32_t *__restrict__ long_list,
+                                                        uint32_t *__restrict__ long_count) {
+  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t j = t >> 3;
+  int l8 = (int)(t & 7);
+  if (j >= d) return;
+  uint64_t len = wlen[j];
+  uint8_t *dst = D + woff[j];
+  if (l8 == 0) dst[len] = kEndOfWord;
+  if (len > kLongPhrase) {
+    if (l8 == 0) { uint32_t i = atomicAdd(long_count, 1u); long_list[i] = (uint32_t)j; }
+    return;
+  }
+  const uint8_t *src = tp + wsrc[j];
+  for (uint64_t off = (uint64_t)l8 * 16; off < len; off += 128) copy_piece(src, dst, off, len);
+}
+
+__global__ __launch_bounds__(256) void dict_copy_long_kernel(const uint8_t *__restrict__ tp,
+                                                             const uint64_t *__restrict__ wsrc,
+                                                             const uint32_t *__restrict__ wlen,
+                                                             const uint64_t *__restrict__ woff, uint8_t *__restrict__ D,
+                                                             const uint32_t *__restrict__ long_list, uint32_t nlong) {
+  for (uint32_t li = 0; li < nlong; li++) {
+    uint32_t j = long_list[li];
+    uint64_t len = wlen[j];
+    const uint8_t *src = tp + wsrc[j];
+    uint8_t *dst = D + woff[j];
+    uint64_t npieces = (len + 15) >> 4;
+    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < npieces; c += (uint64_t)gridDim.x * 256)
+      copy_piece(src, dst, c * 16, len);
+  }
+}
+
+// .last (newscan.cpp:296) and .sai (newscan.cpp:298-301)
+__global__ void last_sai_kernel(const uint8_t *__restrict__ tp, PhraseGeom g, uint64_t P, uint8_t *__restrict__ last,
+                                uint64_t *__restrict__ sai) {
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  uint64_t e = ph_end(g, k);
+  last[k] = tp[e - (uint64_t)g.w];
+  if (sai) sai[k] = e;
+}
+
+void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const DBuf<uint64_t> &ends, uint64_t n_ends,
+                      bool want_sai, Dictionary &D) {
+  const uint64_t P = n_ends + 1;
+  PFP_REQUIRE(P <= 0xFFFFFFFEull, PFP_ELIMIT, "parse has more than 2^32-2 phrases (bwtparse.c:93); use a larger -p");
+  PhraseGeom g{ends.p, n_ends, n, w};
+  const uint8_t *tp = tx.tprime();
+  D.P = P;
+  const int TB = 256;
+  DBuf<uint64_t> hash(c, P), ks(c, P);
+  DBuf<uint32_t> iota(c, P), vs(c, P), head(c, P), hscan(c, P);
+  DBuf<uint32_t> long_list(c, P), counters(c, 4);  // [0] long count, [1] collision, [2] too long, [3] long count (copy)
+  hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, iota.p, P);
+  uint64_t seed = 0x243F6A8885A308D3ULL;
+  uint32_t d = 0;
+  for (int attempt = 0;; attempt++) {
+    counters.zero();
+    hipLaunchKernelGGL(phrase_hash_kernel, dim3(cdiv(P * 8, TB)), dim3(TB), 0, c->stream, tp, g, P, seed, hash.p,
+                       long_list.p, counters.p);
+    uint32_t nlong = read_scalar(c, counters.p);
+    if (nlong) {
+      DBuf<unsigned long long> hsum(c, nlong);
+      hsum.zero();
+      hipLaunchKernelGGL(phrase_hash_long_kernel, dim3(c->n_cu * 4), dim3(TB), 0, c->stream, tp, g, seed, long_list.p,
+                         nlong, hsum.p);
+      hipLaunchKernelGGL(phrase_hash_long_finish_kernel, dim3(cdiv(nlong, 64)), dim3(64), 0, c->stream, g, long_list.p,
+                         nlong, hsum.p, hash.p);
+    }
+    sort_pairs_u64_u32(c, hash.p, ks.p, iota.p, vs.p, P, 0, 64);
+    hipLaunchKernelGGL(dedup_verify_kernel, dim3(cdiv(P * 8, TB)), dim3(TB), 0, c->stream, tp, g, P, ks.p, vs.p, head.p,
+                       counters.p + 1);
+    inclusive_sum_u32(c, head.p, hscan.p, P);
+    PFP_HIP(hipGetLastError());
+    PFP_HIP(hipMemcpyAsync(c->h_scalars, counters.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, hscan.p + (P - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    uint32_t coll; memcpy(&coll, c->h_scalars, 4);
+    memcpy(&d, c->h_scalars + 1, 4);
+    if (!coll) break;
+    PFP_REQUIRE(attempt < 3, PFP_ECOLLISION, "phrase hash collision survived 4 seeds (newscan.cpp:282-286)");
+    seed = seed * 0x9E3779B97F4A7C15ULL + 0x7F4A7C15ULL;
+    D.reseeds++;
+  }
+  D.d = d;
+  // words in first-occurrence order
+  DBuf<uint32_t> hrep(c, d), hpos(c, (size_t)d + 1), hwi(c, d), rep_sorted(c, d), hw_sorted(c, d), fo_of_hw(c, d);
+  hipLaunchKernelGGL(collect_words_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, P, head.p, hscan.p, vs.p, hrep.p,
+                     hpos.p, d);
+  hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, hwi.p, (uint64_t)d);
+  sort_pairs_u32_u32(c, hrep.p, rep_sorted.p, hwi.p, hw_sorted.p, d, 0, bits_for(P));
+  D.wlen.alloc(c, d); D.wocc.alloc(c, d); D.woff.alloc(c, (size_t)d + 1); D.pid.alloc(c, P);
+  DBuf<uint32_t> wlen1(c, (size_t)d + 1);
+  DBuf<uint64_t> wsrc(c, d);
+  hipLaunchKernelGGL(finish_words_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, g, d, rep_sorted.p, hw_sorted.p,
+                     hpos.p, fo_of_hw.p, D.wlen.p, wlen1.p, wsrc.p, D.wocc.p, counters.p + 2);
+  hipLaunchKernelGGL(assign_pid_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, P, hscan.p, vs.p, fo_of_hw.p, D.pid.p);
+  exclusive_sum_u32_u64(c, wlen1.p, D.woff.p, (size_t)d + 1);
+  PFP_HIP(hipMemcpyAsync(c->h_scalars, D.woff.p + d, 8, hipMemcpyDeviceToHost, c->stream));
+  PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, counters.p + 2, 4, hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  uint32_t toolong; memcpy(&toolong, c->h_scalars + 1, 4);
+  D.dsize = c->h_scalars[0] + 1;
+  PFP_REQUIRE(!toolong && D.dsize < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary of 4 GiB or more needs the 64-bit index build");
+  D.bytes.alloc(c, D.dsize + 64);
+  PFP_HIP(hipMemsetAsync(D.bytes.p + (D.dsize - 1), 0, 65, c->stream));
+  PFP_HIP(hipMemsetAsync(counters.p + 3, 0, 4, c->stream));
+  hipLaunchKernelGGL(dict_copy_kernel, dim3(cdiv((uint64_t)d * 8, TB)), dim3(TB), 0, c->stream, tp, d, wsrc.p, D.wlen.p,
+                     D.woff.p, D.bytes.p, long_list.p, counters.p + 3);
+  uint32_t nlongw = read_scalar(c, counters.p + 3);
+  if (nlongw)
+    hipLaunchKernelGGL(dict_copy_long_kernel, dim3(c->n_cu * 4), dim3(TB), 0, c->stream, tp, wsrc.p, D.wlen.p, D.woff.p,
+                       D.bytes.p, long_list.p, nlongw);
+  D.last.alloc(c, P);
+  if (want_sai) D.sai.alloc(c, P);
+  hipLaunchKernelGGL(last_sai_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, tp, g, P, D.last.p,
+                     want_sai ? D.sai.p : (uint64_t *)nullptr);
+  PFP_HIP(hipGetLastError());
+}
+
+}  // namespace pfp

@@ -1,0 +1,610 @@
+// pipeline.hip -- orchestration of the parse -> SA -> BWT chain and the extern "C" boundary
+// (include/pfpgpu.h).  The chain mirrors bigbwt:69-156 (newscan -> bwtparse -> pfbwt) but every
+// intermediate stays in HBM; the staged entry points ingest/emit the reference's file formats.
+#include "kernels.hpp"
+#include "prims.hpp"
+#include "devutil.hpp"
+#include <cstdlib>
+#include <new>
+
+using namespace pfp;
+
+namespace pfp {
+
+static constexpr int TB = 256;
+
+void StagedText::stage(pfp_ctx *c, const void *src, bool src_on_device, uint64_t n_, int w_) {
+  n = n_; w = w_;
+  size_t total = kFront + n + (size_t)w + kBack;
+  buf.alloc(c, total);
+  PFP_HIP(hipMemsetAsync(buf.p, 0, kFront - 1, c->stream));
+  PFP_HIP(hipMemsetAsync(buf.p + kFront - 1, kDollar, 1, c->stream));
+  if (n)
+    PFP_HIP(hipMemcpyAsync(buf.p + kFront, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           c->stream));
+  restage_tail(c, n, w);
+}
+void StagedText::restage_tail(pfp_ctx *c, uint64_t new_n, int w_) const {
+  PFP_HIP(hipMemsetAsync(buf.p + kFront + new_n, kDollar, (size_t)w_, c->stream));
+  PFP_HIP(hipMemsetAsync(buf.p + kFront + new_n + w_, 0, kBack, c->stream));
+}
+
+// occ in lexicographic order and the parse as 1-based lexicographic ranks (newscan.cpp:436,456)
+__global__ void occ_lex_kernel(uint32_t d, const uint32_t *__restrict__ lexrank, const uint32_t *__restrict__ wocc,
+                               uint32_t *__restrict__ occ_lex, uint32_t *__restrict__ word_at_rank) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= d) return;
+  uint32_t r = lexrank[j];
+  occ_lex[r] = wocc[j];
+  if (word_at_rank) word_at_rank[r] = j;
+}
+__global__ void parse_sym_kernel(uint64_t P, const uint32_t *__restrict__ pid, const uint32_t *__restrict__ lexrank,
+                                 uint32_t *__restrict__ sym) {
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < P) sym[k] = lexrank[pid[k]] + 1;
+}
+__global__ void sorted_len1_kernel(uint32_t d, const uint32_t *__restrict__ word_at_rank,
+                                   const uint32_t *__restrict__ wlen, uint32_t *__restrict__ len1) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r == 0) len1[d] = 0;
+  if (r < d) len1[r] = wlen[word_at_rank[r]] + 1;
+}
+// .dict in lexicographic order (newscan.cpp:406-438): 8 lanes per word, 16-byte pieces
+__global__ __launch_bounds__(256) void dict_permute_kernel(uint32_t d, const uint32_t *__restrict__ word_at_rank,
+                                                           const uint64_t *__restrict__ woff,
+                                                           const uint32_t *__restrict__ wlen,
+                                                           const uint8_t *__restrict__ src,
+                                                           const uint64_t *__restrict__ doff, uint8_t *__restrict__ dst) {
+  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t r = t >> 3;
+  int l8 = (int)(t & 7);
+  if (r >= d) return;
+  uint32_t j = word_at_rank[r];
+  uint64_t len = (uint64_t)wlen[j] + 1;   // with terminator
+  const uint8_t *s = src + woff[j];
+  uint8_t *o = dst + doff[r];
+  for (uint64_t off = (uint64_t)l8 * 16; off < len; off += 128) {
+    if (off + 16 <= len) st16u(o + off, ld16u(s + off));
+    else for (uint64_t b = off; b < len; b++) o[b] = s[b];
+  }
+}
+
+// word table of a dictionary given as bytes (reference .dict): starts and lengths
+__global__ void words_from_wend_kernel(uint32_t d, const uint32_t *__restrict__ wend, uint64_t *__restrict__ woff,
+                                       uint32_t *__restrict__ wlen) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) woff[d] = wend[d];
+  if (j >= d) return;
+  uint64_t s = j ? (uint64_t)wend[j - 1] + 1 : 0;
+  woff[j] = s;
+  wlen[j] = (uint32_t)(wend[j] - s);
+}
+
+struct Chain {
+  StagedText tx;
+  DBuf<uint64_t> ends;
+  uint64_t n_ends = 0, n_used = 0;
+  Dictionary D;
+  DictIndex ix;
+  SuffixOrder so;
+  DBuf<uint32_t> occ_lex, word_at_rank, sym;
+  ParseBWT pb;
+};
+
+static void check_args(int w, uint64_t p, int flags) {
+  PFP_REQUIRE(w >= 4, PFP_EINVAL, "Windows size must be at least 4 (newscan.cpp:537)");
+  PFP_REQUIRE(w <= 4096, PFP_EINVAL, "window size above 4096 is not supported");
+  PFP_REQUIRE(p >= 10, PFP_EINVAL, "Modulus must be at leas 10 (newscan.cpp:541)");
+  PFP_REQUIRE(!((flags & PFP_FLAG_SA) && (flags & (PFP_FLAG_SSA | PFP_FLAG_ESA))), PFP_EINVAL,
+              "You can either compute the full SA or a sample of it, not both (bigbwt:59-61)");
+  PFP_REQUIRE((flags & ~7) == 0, PFP_EINVAL, "unknown flag bits");
+}
+
+// stage 1 on a staged text: scan, dictionary, dictionary suffix order, lexicographic ranks
+static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool want_sai) {
+  pfp_stats &st = c->stats;
+  {
+    PhaseTimer t(c, &st.ms_scan);
+    ch.n_ends = scan_text(c, ch.tx, n, w, p, ch.ends, &ch.n_used);
+    if (c->debug) validate_scan(c, ch.ends, ch.n_ends, ch.n_used, w);
+  }
+  {
+    PhaseTimer t(c, &st.ms_phrases);
+    build_dictionary(c, ch.tx, ch.n_used, w, ch.ends, ch.n_ends, want_sai, ch.D);
+    if (c->debug) validate_dictionary(c, ch.D, w);
+    build_dict_index(c, ch.D, ch.ix);
+    if (c->debug) validate_index(c, ch.D, ch.ix);
+  }
+  {
+    PhaseTimer t(c, &st.ms_sa_dict);
+    sort_dict_suffixes(c, ch.D.bytes.p, ch.D.dsize, ch.ix.pos_word.p, ch.ix.wend.p, ch.D.d, ch.so);
+    if (c->debug) validate_suffix_order(c, ch.D.bytes.p, ch.so, true, "dict SA");
+    compute_lexrank(c, ch.D, ch.so, ch.ix);
+    if (c->debug) validate_lexrank(c, ch.D, ch.ix);
+    const uint32_t d = (uint32_t)ch.D.d;
+    ch.occ_lex.alloc(c, d); ch.word_at_rank.alloc(c, d);
+    hipLaunchKernelGGL(occ_lex_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ch.ix.lexrank.p, ch.D.wocc.p,
+                       ch.occ_lex.p, ch.word_at_rank.p);
+    ch.sym.alloc(c, ch.D.P);
+    hipLaunchKernelGGL(parse_sym_kernel, dim3(cdiv(ch.D.P, TB)), dim3(TB), 0, c->stream, ch.D.P, ch.D.pid.p,
+                       ch.ix.lexrank.p, ch.sym.p);
+    PFP_HIP(hipGetLastError());
+  }
+  st.n = ch.n_used; st.n_phrases = ch.D.P; st.n_words = ch.D.d; st.dict_size = ch.D.dsize;
+  st.sa_rounds_dict = ch.so.rounds; st.hash_reseeds = ch.D.reseeds;
+}
+
+static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, int flags, uint8_t *d_bwt,
+                          uint64_t *d_sa, uint64_t *n_used) {
+  pfp_stats &st = c->stats;
+  st = pfp_stats{};
+  auto t0 = std::chrono::steady_clock::now();
+  run_parse(c, ch, n, w, p, flags != 0);
+  {
+    PhaseTimer t(c, &st.ms_sa_parse);
+    parse_bwt(c, ch.sym.p, ch.D.P, ch.D.last.p, flags ? ch.D.sai.p : nullptr, ch.occ_lex.p, ch.D.d, ch.pb);
+    st.sa_rounds_parse = ch.pb.rounds;
+    if (c->debug) validate_parse_bwt(c, ch.pb);
+  }
+  {
+    PhaseTimer t(c, &st.ms_merge);
+    BwtOutputs bo;
+    bo.d_bwt = d_bwt; bo.d_sa = d_sa;
+    merge_bwt(c, ch.D, ch.ix, ch.so, ch.pb, ch.occ_lex.p, w, flags, ch.n_used + 1, bo);
+    st.hard_groups = bo.hard_groups; st.hard_chars = bo.hard_chars;
+  }
+  sync(c);
+  st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  *n_used = ch.n_used;
+}
+
+template <class T>
+static T *host_alloc(size_t count) {
+  T *p = (T *)malloc((count ? count : 1) * sizeof(T));
+  if (!p) throw Error(PFP_ENOMEM, "host malloc failed");
+  return p;
+}
+
+// fetch device results of a finished chain into a pfp_bwt_result (reference file formats)
+static void fetch_outputs(pfp_ctx *c, const uint8_t *d_bwt, const uint64_t *d_sa, uint64_t n_out, int flags,
+                          pfp_bwt_result *out) {
+  out->bwt = host_alloc<uint8_t>(n_out);
+  out->bwt_size = n_out;
+  d2h(c, out->bwt, d_bwt, n_out);
+  if (flags & PFP_FLAG_SA) {                       // .sa: n entries, SA[0]=n omitted (pfbwt.cpp:158-162)
+    uint64_t cnt = n_out - 1;
+    DBuf<uint8_t> packed(c, cnt * 5 + 1);
+    pack5_dev(c, d_sa + 1, cnt, packed.p);
+    out->sa = host_alloc<uint8_t>(cnt * 5);
+    out->sa_bytes = cnt * 5;
+    d2h(c, out->sa, packed.p, cnt * 5);
+    sync(c);
+  }
+  if (flags & PFP_FLAG_SSA) {
+    DBuf<uint8_t> pairs;
+    uint64_t k = sample_runs_dev(c, d_bwt, d_sa, n_out, false, pairs);
+    out->ssa = host_alloc<uint8_t>(k * 10); out->ssa_bytes = k * 10;
+    d2h(c, out->ssa, pairs.p, k * 10);
+    sync(c);
+  }
+  if (flags & PFP_FLAG_ESA) {
+    DBuf<uint8_t> pairs;
+    uint64_t k = sample_runs_dev(c, d_bwt, d_sa, n_out, true, pairs);
+    out->esa = host_alloc<uint8_t>(k * 10); out->esa_bytes = k * 10;
+    d2h(c, out->esa, pairs.p, k * 10);
+    sync(c);
+  }
+  sync(c);
+}
+
+}  // namespace pfp
+
+// ======================================================================== extern "C"
+
+#define PFP_TRY(ctx) try {
+#define PFP_CATCH(ctx)                                                                    \
+  }                                                                                       \
+  catch (const pfp::Error &e) { if (ctx) (ctx)->err = e.what(); (void)hipGetLastError(); return e.code; } \
+  catch (const std::bad_alloc &) { if (ctx) (ctx)->err = "host out of memory"; return PFP_ENOMEM; }   \
+  catch (const std::exception &e) { if (ctx) (ctx)->err = e.what(); return PFP_EHIP; }
+
+extern "C" {
+
+const char *pfp_version(void) { return "pfpgpu 0.1 (gfx950, wave64; prefix-free parsing BWT)"; }
+
+const char *pfp_strerror(int code) {
+  switch (code) {
+    case PFP_OK: return "ok";
+    case PFP_EINVAL: return "invalid argument";
+    case PFP_ENODEV: return "no usable HIP device";
+    case PFP_EHIP: return "HIP runtime error";
+    case PFP_ECOLLISION: return "phrase hash collision";
+    case PFP_ELIMIT: return "size limit exceeded";
+    case PFP_EFORMAT: return "inconsistent input";
+    case PFP_ENOMEM: return "out of memory";
+    case PFP_ESHORT: return "input too short";
+    default: return "unknown error";
+  }
+}
+
+int pfp_ctx_create(pfp_ctx **out, int device) {
+  if (!out) return PFP_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    (void)hipGetLastError();
+    return PFP_ENODEV;
+  }
+  pfp_ctx *c = new (std::nothrow) pfp_ctx();
+  if (!c) return PFP_ENOMEM;
+  try {
+    c->device = device;
+    PFP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PFP_HIP(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    PFP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    PFP_HIP(hipHostMalloc((void **)&c->h_scalars, 16 * sizeof(uint64_t), hipHostMallocDefault));
+    const char *dbg = getenv("PFP_DEBUG");
+    c->debug = dbg && dbg[0] && dbg[0] != '0';
+    (void)hipGetLastError();
+  } catch (const pfp::Error &e) {
+    (void)hipGetLastError();
+    delete c;
+    return e.code == PFP_EHIP ? PFP_ENODEV : e.code;
+  }
+  *out = c;
+  return PFP_OK;
+}
+
+struct K1Scratch { pfp::DBuf<uint16_t> flags; pfp::DBuf<uint32_t> bcnt; pfp::DBuf<unsigned long long> fbad; uint64_t n = 0; };
+static pfp::StagedText *&staged_of(pfp_ctx *c) { return *reinterpret_cast<pfp::StagedText **>(&c->staged); }
+
+void pfp_ctx_destroy(pfp_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  delete staged_of(c);
+  delete reinterpret_cast<K1Scratch *>(c->k1scratch);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->pool.destroy();
+  if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *pfp_last_error(const pfp_ctx *c) { return c ? c->err.c_str() : "null context"; }
+void *pfp_ctx_stream(pfp_ctx *c) { return c ? (void *)c->stream : nullptr; }
+void pfp_free(void *p) { free(p); }
+void pfp_set_profiling(pfp_ctx *c, int on) { if (c) c->profiling = on != 0; }
+int pfp_get_stats(const pfp_ctx *c, pfp_stats *st) {
+  if (!c || !st) return PFP_EINVAL;
+  *st = c->stats;
+  return PFP_OK;
+}
+
+void pfp_parse_result_free(pfp_parse_result *r) {
+  if (!r) return;
+  free(r->dict); free(r->occ); free(r->parse); free(r->last); free(r->sai);
+  memset(r, 0, sizeof *r);
+}
+void pfp_bwt_result_free(pfp_bwt_result *r) {
+  if (!r) return;
+  free(r->bwt); free(r->sa); free(r->ssa); free(r->esa);
+  memset(r, 0, sizeof *r);
+}
+
+// ---------------------------------------------------------------- stage 1a
+int pfp_scan(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, uint64_t **ends, uint64_t *n_ends,
+             uint64_t *n_used) {
+  if (!c || (!text && n) || !ends || !n_ends) return PFP_EINVAL;
+  *ends = nullptr; *n_ends = 0;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  PFP_REQUIRE(w >= 1 && w <= 4096 && p >= 1, PFP_EINVAL, "bad window or modulus");
+  StagedText tx;
+  tx.stage(c, text, false, n, w);
+  DBuf<uint64_t> d_ends;
+  uint64_t used = n;
+  uint64_t k = scan_text(c, tx, n, w, p, d_ends, &used);
+  uint64_t *h = host_alloc<uint64_t>(k);
+  if (k) d2h(c, h, d_ends.p, k);
+  sync(c);
+  *ends = h; *n_ends = k;
+  if (n_used) *n_used = used;
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// ---------------------------------------------------------------- stage 1
+int pfp_parse(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, int want_sai, pfp_parse_result *out) {
+  if (!c || (!text && n) || !out) return PFP_EINVAL;
+  memset(out, 0, sizeof *out);
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  check_args(w, p, 0);
+  c->stats = pfp_stats{};
+  Chain ch;
+  ch.tx.stage(c, text, false, n, w);
+  run_parse(c, ch, n, w, p, want_sai != 0);
+  const uint32_t d = (uint32_t)ch.D.d;
+  const uint64_t P = ch.D.P;
+  // .dict in lexicographic order
+  DBuf<uint32_t> len1(c, (size_t)d + 1);
+  DBuf<uint64_t> doff(c, (size_t)d + 1);
+  hipLaunchKernelGGL(sorted_len1_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ch.word_at_rank.p, ch.D.wlen.p,
+                     len1.p);
+  exclusive_sum_u32_u64(c, len1.p, doff.p, (size_t)d + 1);
+  DBuf<uint8_t> sdict(c, ch.D.dsize + 64);
+  PFP_HIP(hipMemsetAsync(sdict.p + ch.D.dsize - 1, 0, 1, c->stream));
+  hipLaunchKernelGGL(dict_permute_kernel, dim3(cdiv((uint64_t)d * 8, TB)), dim3(TB), 0, c->stream, d, ch.word_at_rank.p,
+                     ch.D.woff.p, ch.D.wlen.p, ch.D.bytes.p, doff.p, sdict.p);
+  PFP_HIP(hipGetLastError());
+  out->n_used = ch.n_used;
+  out->dict_size = ch.D.dsize; out->n_words = d; out->n_phrases = P;
+  out->dict = host_alloc<uint8_t>(ch.D.dsize);
+  out->occ = host_alloc<uint32_t>(d);
+  out->parse = host_alloc<uint32_t>(P);
+  out->last = host_alloc<uint8_t>(P);
+  d2h(c, out->dict, sdict.p, ch.D.dsize);
+  d2h(c, out->occ, ch.occ_lex.p, d);
+  d2h(c, out->parse, ch.sym.p, P);
+  d2h(c, out->last, ch.D.last.p, P);
+  if (want_sai) {
+    DBuf<uint8_t> packed(c, P * 5);
+    pack5_dev(c, ch.D.sai.p, P, packed.p);
+    out->sai = host_alloc<uint8_t>(P * 5);
+    d2h(c, out->sai, packed.p, P * 5);
+    sync(c);
+  }
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// ---------------------------------------------------------------- suffix sorting
+int pfp_sacak_int(pfp_ctx *c, const uint32_t *s, uint32_t *SA, uint64_t n, uint64_t k) {
+  (void)k;
+  if (!c || !s || !SA) return PFP_EINVAL;   // gsacak.c:2498 returns -1 on NULL
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  PFP_REQUIRE(n >= 1, PFP_EINVAL, "empty string");
+  PFP_REQUIRE(s[n - 1] == 0, PFP_EFORMAT, "sacak_int: last symbol must be 0");
+  DBuf<uint32_t> ds(c, n);
+  h2d(c, ds.p, s, n);
+  SuffixOrder so;
+  sort_int_suffixes(c, ds.p, n, so);
+  d2h(c, SA, so.sa.p, n);
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_sacak(pfp_ctx *c, const uint8_t *s, uint32_t *SA, uint64_t n) {
+  if (!c || !s || !SA) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  PFP_REQUIRE(n >= 1, PFP_EINVAL, "empty string");
+  PFP_REQUIRE(s[n - 1] == 0, PFP_EFORMAT, "sacak: last symbol must be 0");
+  DBuf<uint8_t> ds(c, n + 64);
+  h2d(c, ds.p, s, n);
+  PFP_HIP(hipMemsetAsync(ds.p + n, 0, 64, c->stream));
+  SuffixOrder so;
+  sort_byte_suffixes(c, ds.p, n, so);
+  d2h(c, SA, so.sa.p, n);
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// dictionary given as bytes: fill D.{bytes,dsize,d,woff,wlen} and the index
+static void dictionary_from_host(pfp_ctx *c, const uint8_t *s, uint64_t n, Dictionary &D, DictIndex &ix) {
+  PFP_REQUIRE(n >= 2 && s[n - 1] == kEndOfDict && s[n - 2] == kEndOfWord, PFP_EFORMAT,
+              "dictionary must end with 0x01 0x00 (pfbwt.cpp:498-503)");
+  D.dsize = n;
+  D.bytes.alloc(c, n + 64);
+  h2d(c, D.bytes.p, s, n);
+  PFP_HIP(hipMemsetAsync(D.bytes.p + n, 0, 64, c->stream));
+  DBuf<uint32_t> inc(c, n);
+  inclusive_count_eq_u8(c, D.bytes.p, kEndOfWord, inc.p, n);
+  D.d = read_scalar(c, inc.p + (n - 1));
+  build_dict_index(c, D, ix);
+  D.woff.alloc(c, D.d + 1); D.wlen.alloc(c, D.d);
+  hipLaunchKernelGGL(words_from_wend_kernel, dim3(cdiv(D.d, TB)), dim3(TB), 0, c->stream, (uint32_t)D.d, ix.wend.p,
+                     D.woff.p, D.wlen.p);
+  PFP_HIP(hipGetLastError());
+}
+
+int pfp_gsacak(pfp_ctx *c, const uint8_t *s, uint32_t *SA, uint64_t n) {
+  if (!c || !s || !SA) return PFP_EINVAL;   // gsacak.c:2503
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  Dictionary D; DictIndex ix; SuffixOrder so;
+  dictionary_from_host(c, s, n, D, ix);
+  sort_dict_suffixes(c, D.bytes.p, n, ix.pos_word.p, ix.wend.p, D.d, so);
+  d2h(c, SA, so.sa.p, n);
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// ---------------------------------------------------------------- stage 2
+int pfp_bwtparse(pfp_ctx *c, const uint32_t *parse, uint64_t P, const uint8_t *last, const uint8_t *sai,
+                 const uint32_t *occ, uint64_t n_words, uint32_t *ilist, uint8_t *bwlast, uint8_t *bwsai) {
+  if (!c || !parse || !last || !occ || !ilist || !bwlast || (sai && !bwsai)) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  PFP_REQUIRE(P >= 2, PFP_ESHORT, "parse has fewer than 2 phrases (bwtparse.c:244)");
+  PFP_REQUIRE(P <= 0xFFFFFFFEull, PFP_ELIMIT, "Input containing more than 2^32-2 phrases (bwtparse.c:93)");
+  DBuf<uint32_t> dparse(c, P), docc(c, n_words);
+  DBuf<uint8_t> dlast(c, P);
+  DBuf<uint64_t> dsai;
+  h2d(c, dparse.p, parse, P); h2d(c, dlast.p, last, P); h2d(c, docc.p, occ, n_words);
+  if (sai) {
+    DBuf<uint8_t> packed(c, P * 5);
+    h2d(c, packed.p, sai, P * 5);
+    dsai.alloc(c, P);
+    unpack5_dev(c, packed.p, P, dsai.p);
+    sync(c);
+  }
+  ParseBWT pb;
+  parse_bwt(c, dparse.p, P, dlast.p, sai ? dsai.p : nullptr, docc.p, n_words, pb);
+  d2h(c, ilist, pb.ilist.p, P + 1);
+  d2h(c, bwlast, pb.bwlast.p, P + 1);
+  if (sai) {
+    DBuf<uint8_t> packed(c, (P + 1) * 5);
+    pack5_dev(c, pb.bwsai.p, P + 1, packed.p);
+    d2h(c, bwsai, packed.p, (P + 1) * 5);
+    sync(c);
+  }
+  sync(c);
+  PFP_REQUIRE(ilist[0] == 1, PFP_EFORMAT, "ilist[0] != 1 (bwtparse.c:305): parse does not start with the smallest word");
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// ---------------------------------------------------------------- stage 3
+int pfp_merge(pfp_ctx *c, const uint8_t *dict, uint64_t dict_size, const uint32_t *occ, uint64_t n_words,
+              const uint32_t *ilist, const uint8_t *bwlast, const uint8_t *bwsai, uint64_t n_plus_1, int w, int flags,
+              pfp_bwt_result *out) {
+  if (!c || !dict || !occ || !ilist || !bwlast || !out) return PFP_EINVAL;
+  memset(out, 0, sizeof *out);
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  check_args(w, 10, flags);
+  PFP_REQUIRE(!flags || bwsai, PFP_EINVAL, "SA output requested but no bwsai given");
+  PFP_REQUIRE(dict_size > 1 + (uint64_t)w, PFP_EFORMAT, "invalid dictionary file (pfbwt.cpp:332)");
+  PFP_REQUIRE(ilist[0] == 1, PFP_EFORMAT, "ilist[0] != 1 (pfbwt.cpp:377)");
+  PFP_REQUIRE(dict[0] == kDollar, PFP_EFORMAT, "dictionary must start with Dollar (pfbwt.cpp:125)");
+  Dictionary D; DictIndex ix; SuffixOrder so;
+  dictionary_from_host(c, dict, dict_size, D, ix);
+  PFP_REQUIRE(D.d == n_words, PFP_EFORMAT, "occ entries != dictionary words (pfbwt.cpp:357)");
+  // expected output size: every suffix longer than w of every word, once per occurrence
+  uint64_t expect = 0, tot_occ = 0;
+  {
+    uint64_t s = 0, j = 0;
+    for (uint64_t i = 0; i < dict_size; i++)
+      if (dict[i] == kEndOfWord) {
+        uint64_t len = i - s;
+        if (len > (uint64_t)w) expect += (len - (uint64_t)w) * occ[j];
+        tot_occ += occ[j];
+        j++; s = i + 1;
+      }
+  }
+  PFP_REQUIRE(tot_occ + 1 == n_plus_1, PFP_EFORMAT, "sum(occ)+1 != parse size (pfbwt.cpp:397)");
+  D.wocc.alloc(c, D.d);
+  h2d(c, D.wocc.p, occ, D.d);
+  if (c->debug) validate_index(c, D, ix);
+  sort_dict_suffixes(c, D.bytes.p, D.dsize, ix.pos_word.p, ix.wend.p, D.d, so);
+  if (c->debug) validate_suffix_order(c, D.bytes.p, so, true, "dict SA");
+  compute_lexrank(c, D, so, ix);
+  if (c->debug) validate_lexrank(c, D, ix);
+  DBuf<uint32_t> occ_lex(c, D.d);
+  hipLaunchKernelGGL(occ_lex_kernel, dim3(cdiv(D.d, TB)), dim3(TB), 0, c->stream, (uint32_t)D.d, ix.lexrank.p, D.wocc.p,
+                     occ_lex.p, (uint32_t *)nullptr);
+  ParseBWT pb;
+  pb.P = n_plus_1 - 1;
+  pb.ilist.alloc(c, n_plus_1); pb.bwlast.alloc(c, n_plus_1);
+  h2d(c, pb.ilist.p, ilist, n_plus_1); h2d(c, pb.bwlast.p, bwlast, n_plus_1);
+  if (flags) {
+    DBuf<uint8_t> packed(c, n_plus_1 * 5);
+    h2d(c, packed.p, bwsai, n_plus_1 * 5);
+    pb.bwsai.alloc(c, n_plus_1);
+    unpack5_dev(c, packed.p, n_plus_1, pb.bwsai.p);
+    sync(c);
+  }
+  DBuf<uint8_t> d_bwt(c, expect + 16);
+  DBuf<uint64_t> d_sa;
+  if (flags) d_sa.alloc(c, expect + 1);
+  BwtOutputs bo;
+  bo.d_bwt = d_bwt.p; bo.d_sa = flags ? d_sa.p : nullptr;
+  merge_bwt(c, D, ix, so, pb, occ_lex.p, w, flags, expect, bo);
+  c->stats.hard_groups = bo.hard_groups; c->stats.hard_chars = bo.hard_chars;
+  fetch_outputs(c, d_bwt.p, d_sa.p, expect, flags, out);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// ---------------------------------------------------------------- whole chain
+int pfp_bigbwt_dev(pfp_ctx *c, const void *d_text, uint64_t n, int w, uint64_t p, int flags, void *d_bwt, void *d_sa,
+                   uint64_t *n_used) {
+  if (!c || (!d_text && n) || !d_bwt || (flags && !d_sa)) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  check_args(w, p, flags);
+  PFP_REQUIRE(((uintptr_t)d_bwt & 15) == 0, PFP_EINVAL, "d_bwt must be 16-byte aligned");
+  Chain ch;
+  ch.tx.stage(c, d_text, true, n, w);
+  uint64_t used = 0;
+  run_chain_dev(c, ch, n, w, p, flags, (uint8_t *)d_bwt, (uint64_t *)d_sa, &used);
+  if (n_used) *n_used = used;
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_bigbwt(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags, pfp_bwt_result *out) {
+  if (!c || (!text && n) || !out) return PFP_EINVAL;
+  memset(out, 0, sizeof *out);
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  check_args(w, p, flags);
+  Chain ch;
+  ch.tx.stage(c, text, false, n, w);
+  DBuf<uint8_t> d_bwt(c, n + 1 + 16);
+  DBuf<uint64_t> d_sa;
+  if (flags) d_sa.alloc(c, n + 1);
+  uint64_t used = 0;
+  run_chain_dev(c, ch, n, w, p, flags, d_bwt.p, flags ? d_sa.p : nullptr, &used);
+  fetch_outputs(c, d_bwt.p, d_sa.p, used + 1, flags, out);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// ---------------------------------------------------------------- micro entry points
+int pfp_stage_text_dev(pfp_ctx *c, const void *d_text, uint64_t n, int w) {
+  if (!c || (!d_text && n)) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  PFP_REQUIRE(w >= 1 && w <= 4096, PFP_EINVAL, "bad window");
+  StagedText *&s = staged_of(c);
+  if (!s) s = new StagedText();
+  s->stage(c, d_text, true, n, w);
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_scan_staged(pfp_ctx *c, uint64_t p, uint64_t *n_ends) {
+  if (!c) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  StagedText *s = staged_of(c);
+  PFP_REQUIRE(s && s->buf.p, PFP_EINVAL, "no staged text");
+  DBuf<uint64_t> d_ends;
+  uint64_t used = 0;
+  uint64_t k = scan_text(c, *s, s->n, s->w, p, d_ends, &used);
+  sync(c);
+  if (n_ends) *n_ends = k;
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_scan_k1_enqueue(pfp_ctx *c, uint64_t p) {
+  if (!c) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  StagedText *s = staged_of(c);
+  PFP_REQUIRE(s && s->buf.p, PFP_EINVAL, "no staged text");
+  // scratch kept across calls so that the enqueue itself does no allocation
+  if (!c->k1scratch) c->k1scratch = new K1Scratch();
+  K1Scratch &sc = *reinterpret_cast<K1Scratch *>(c->k1scratch);
+  uint64_t nchunks = cdiv64(s->n, 16);
+  if (sc.n != s->n || !sc.flags.p) {
+    sc.flags.alloc(c, nchunks + 1); sc.bcnt.alloc(c, cdiv64(nchunks, 256) + 1); sc.fbad.alloc(c, 1); sc.n = s->n;
+  }
+  scan_flags(c, s->tbase(), s->n, s->w, p, sc.flags.p, sc.bcnt.p, sc.fbad.p);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+// scan.hip -- stage 1a: rolling Karp-Rabin window scan + phrase-boundary compaction.
+//
+// Replaces KR_window::addchar and the `hash % p == 0` test of process_file
+// (reference newscan.cpp:168-202, 363-377; threaded twin pscan.hpp:44-108).
+//
+// The reference hash after >= w characters is  H_i = sum_j c[i-w+1+j] * 256^(w-1-j) mod q,
+// q = 1999999973: a pure function of the last w bytes, so every position is independent.
+// Layout: one thread owns 16 consecutive text positions (one aligned 16-byte load plus the
+// 16 bytes before it as halo, all in registers), evaluates the first window with a 3-bytes-
+// per-step Horner, then rolls 15 times.  All modular reductions are exact 32-bit Barrett
+// steps (one v_mul_hi_u32 + one v_mul_lo_u32), no 64-bit division:
+//     T < 2^(32+S):  qhat = mulhi(T >> S, floor(2^62/q)) >> (30-S) in {Q-1,Q};  r = T - qhat*q
+// The `% p` test is the exact divisibility test  rotr(h * inv(p_odd), s) <= (2^32-1)/p.
+// Kernel A writes a 16-bit trigger mask per thread (n/8 bytes) and a per-block count;
+// kernel B turns the masks into the dense, ordered ends[] array (wave-shuffle prefix sums).
+#include "kernels.hpp"
+#include "prims.hpp"
+
+namespace pfp {
+
+constexpr uint32_t kBarrettM = 2305843040u;  // floor(2^62 / 1999999973)
+static_assert((uint64_t)kBarrettM * kPrime <= (1ull << 62), "barrett");
+static_assert((uint64_t)(kBarrettM + 1ull) * kPrime > (1ull << 62), "barrett");
+
+// exact r = T mod q for T < 2^(32+S), S <= 28
+template <int S>
+__device__ __forceinline__ uint32_t kr_reduce(uint64_t T) {
+  uint32_t xs = (uint32_t)(T >> S);
+  uint32_t qhat = __umulhi(xs, kBarrettM) >> (30 - S);
+  uint32_t r = (uint32_t)T - qhat * kPrime;  // true value in [0,2q) < 2^32
+  uint32_t r2 = r - kPrime;
+  return r < r2 ? r : r2;
+}
+
+__device__ __forceinline__ bool kr_divides(uint32_t h, const KRParams &kp) {
+  uint32_t x = h * kp.pinv;
+  x = (x >> kp.pshift) | (kp.pshift ? (x << (32 - kp.pshift)) : 0u);
+  return x <= kp.plimit;
+}
+
+__device__ __forceinline__ uint32_t byte_of(const uint32_t (&r)[8], int k) {
+  return (r[k >> 2] >> (8 * (k & 3))) & 0xffu;
+}
+
+// any byte < 3 in x?  (exact "hasless" test)
+__device__ __forceinline__ uint32_t bad_bytes(uint32_t x) {
+  return (x - 0x03030303u) & ~x & 0x80808080u;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void kr_flag_kernel(const uint8_t *__restrict__ tbase, uint64_t n, KRParams kp,
+                                                      uint16_t *__restrict__ flags16,
+                                                      uint32_t *__restrict__ block_counts,
+                                                      unsigned long long *__restrict__ first_bad) {
+  static_assert(W >= 2 && W <= 17, "register path needs w-1 <= 16");
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // 16-byte chunk index
+  const uint64_t pos0 = c * 16;
+  uint32_t mask = 0;
+  if (pos0 < n) {
+    const uint4 pv = *reinterpret_cast<const uint4 *>(tbase + pos0 - 16);
+    const uint4 cv = *reinterpret_cast<const uint4 *>(tbase + pos0);
+    const uint32_t r[8] = {pv.x, pv.y, pv.z, pv.w, cv.x, cv.y, cv.z, cv.w};
+    // bytes <= 2 stop the parse (newscan.cpp:364): report the first one
+    uint32_t bad = bad_bytes(cv.x) | bad_bytes(cv.y) | bad_bytes(cv.z) | bad_bytes(cv.w);
+    if (bad) {
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (byte_of(r, 16 + k) <= 2 && pos0 + k < n) { atomicMin(first_bad, (unsigned long long)(pos0 + k)); break; }
+    }
+    // first window: bytes [16-(W-1) .. 16], Horner 3 bytes per step
+    uint32_t h = 0;
+    constexpr int first = 16 - (W - 1);
+    int k = first;
+#pragma unroll
+    for (int s = 0; s < W / 3; s++) {
+      uint64_t T = ((uint64_t)h << 24) | (byte_of(r, k) << 16) | (byte_of(r, k + 1) << 8) | byte_of(r, k + 2);
+      h = kr_reduce<23>(T);
+      k += 3;
+    }
+    if (W % 3 == 1) { h = kr_reduce<8>(((uint64_t)h << 8) | byte_of(r, k)); }
+    if (W % 3 == 2) { h = kr_reduce<15>(((uint64_t)h << 16) | (byte_of(r, k) << 8) | byte_of(r, k + 1)); }
+    const uint64_t lo_valid = (uint64_t)(W - 1);  // words shorter than w+1 are never saved (newscan.cpp:248)
+    if (kr_divides(h, kp) && pos0 >= lo_valid) mask |= 1u;
+#pragma unroll
+    for (int j = 1; j < 16; j++) {
+      uint32_t cin = byte_of(r, 16 + j), cout = byte_of(r, 16 + j - W);
+      uint64_t T = (uint64_t)cout * kp.negpw + (((uint64_t)h << 8) | cin);  // < 2^40
+      h = kr_reduce<8>(T);
+      if (kr_divides(h, kp) && pos0 + j >= lo_valid && pos0 + j < n) mask |= 1u << j;
+    }
+    flags16[c] = (uint16_t)mask;
+  }
+  // block count of triggers
+  uint32_t cnt = __popc(mask);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  __shared__ uint32_t wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// generic window size (w > 17): same arithmetic, bytes fetched from memory
+__global__ __launch_bounds__(256) void kr_flag_generic_kernel(const uint8_t *__restrict__ tbase, uint64_t n, int W,
+                                                              KRParams kp, uint16_t *__restrict__ flags16,
+                                                              uint32_t *__restrict__ block_counts,
+                                                              unsigned long long *__restrict__ first_bad) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t pos0 = c * 16;
+  uint32_t mask = 0;
+  if (pos0 < n) {
+    for (int k = 0; k < 16; k++)
+      if (pos0 + k < n && tbase[pos0 + k] <= 2) { atomicMin(first_bad, (unsigned long long)(pos0 + k)); break; }
+    uint32_t h = 0;
+    if (pos0 + 1 >= (uint64_t)W) {
+      for (int k = 0; k < W; k++) h = kr_reduce<8>(((uint64_t)h << 8) | tbase[pos0 - (W - 1) + k]);
+      if (kr_divides(h, kp)) mask |= 1u;
+    }
+    for (int j = 1; j < 16; j++) {
+      uint64_t pos = pos0 + j;
+      if (pos + 1 < (uint64_t)W) continue;
+      if (pos + 1 == (uint64_t)W) {
+        h = 0;
+        for (int k = 0; k < W; k++) h = kr_reduce<8>(((uint64_t)h << 8) | tbase[k]);
+      } else {
+        uint32_t cin = tbase[pos], cout = tbase[pos - W];
+        h = kr_reduce<8>((uint64_t)cout * kp.negpw + (((uint64_t)h << 8) | cin));
+      }
+      if (kr_divides(h, kp) && pos < n) mask |= 1u << j;
+    }
+    flags16[c] = (uint16_t)mask;
+  }
+  uint32_t cnt = __popc(mask);
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  __shared__ uint32_t wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// K2: masks -> dense ordered phrase ends (text positions)
+__global__ __launch_bounds__(256) void kr_compact_kernel(const uint16_t *__restrict__ flags16, uint64_t nchunks,
+                                                         const uint32_t *__restrict__ block_offsets,
+                                                         uint64_t *__restrict__ ends) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t mask = (c < nchunks) ? flags16[c] : 0u;
+  uint32_t cnt = __popc(mask);
+  // inclusive wave scan
+  uint32_t incl = cnt;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  __shared__ uint32_t wsum[4];
+  if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int i = 0; i < (int)(threadIdx.x >> 6); i++) wbase += wsum[i];
+  uint64_t o = (uint64_t)block_offsets[blockIdx.x] + wbase + (incl - cnt);
+  while (mask) {
+    int b = __ffs(mask) - 1;
+    mask &= mask - 1;
+    ends[o++] = c * 16 + (uint64_t)b;
+  }
+}
+
+// ------------------------------------------------------------------ host side
+
+static uint32_t inv_mod_2_32(uint32_t odd) {
+  uint32_t x = odd;  // Newton: correct to 3 bits initially
+  for (int i = 0; i < 5; i++) x *= 2u - odd * x;
+  return x;
+}
+
+KRParams make_kr_params(int w, uint64_t p) {
+  KRParams kp{};
+  uint64_t pw = 1;
+  for (int i = 0; i < w; i++) pw = (pw * 256) % kPrime;  // 256^w mod q
+  kp.negpw = (uint32_t)(kPrime - pw);
+  if (p >= (1ull << 31)) {
+    // h < 2^31 <= p: only h == 0 is divisible
+    kp.pinv = 1; kp.pshift = 0; kp.plimit = 0;
+  } else {
+    uint32_t pp = (uint32_t)p; int s = 0;
+    while ((pp & 1u) == 0) { pp >>= 1; s++; }
+    kp.pinv = inv_mod_2_32(pp); kp.pshift = (uint32_t)s; kp.plimit = (uint32_t)(0xFFFFFFFFull / p);
+  }
+  return kp;
+}
+
+template <int W>
+static void launch_flag(pfp_ctx *c, int nblocks, const uint8_t *tbase, uint64_t n, const KRParams &kp,
+                        uint16_t *flags16, uint32_t *bc, unsigned long long *fb) {
+  hipLaunchKernelGGL(kr_flag_kernel<W>, dim3(nblocks), dim3(256), 0, c->stream, tbase, n, kp, flags16, bc, fb);
+}
+
+void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p, uint16_t *flags16,
+                uint32_t *block_counts, unsigned long long *first_bad) {
+  KRParams kp = make_kr_params(w, p);
+  uint64_t nchunks = cdiv64(n, 16);
+  int nblocks = (int)cdiv64(nchunks, 256);
+  if (nblocks == 0) return;
+  switch (w) {
+#define CASE(W) case W: launch_flag<W>(c, nblocks, tbase, n, kp, flags16, block_counts, first_bad); break;
+    CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17)
+#undef CASE
+    default:
+      hipLaunchKernelGGL(kr_flag_generic_kernel, dim3(nblocks), dim3(256), 0, c->stream, tbase, n, w, kp, flags16,
+                         block_counts, first_bad);
+  }
+  PFP_HIP(hipGetLastError());
+}
+
+// Full stage 1a on a staged text.  Returns the number of trigger ends; d_ends receives them.
+// If a byte <= 2 is found before n, *n_used is set to its position and the scan is redone on
+// the prefix (the reference stops reading there: newscan.cpp:364).
+uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, DBuf<uint64_t> &d_ends,
+                   uint64_t *n_used) {
+  PFP_REQUIRE(w >= 1 && w <= 255, PFP_EINVAL, "window size out of range");
+  uint64_t cur_n = n;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    uint64_t nchunks = cdiv64(cur_n, 16);
+    int nblocks = (int)cdiv64(nchunks, 256);
+    *n_used = cur_n;
+    if (nblocks == 0) { d_ends.alloc(c, 1); return 0; }
+    DBuf<uint16_t> flags16(c, nchunks);
+    DBuf<uint32_t> bcnt(c, (size_t)nblocks + 1), boff(c, (size_t)nblocks + 1);
+    DBuf<unsigned long long> fbad(c, 1);
+    PFP_HIP(hipMemsetAsync(fbad.p, 0xff, 8, c->stream));
+    PFP_HIP(hipMemsetAsync(bcnt.p + nblocks, 0, 4, c->stream));
+    scan_flags(c, tx.tbase(), cur_n, w, p, flags16.p, bcnt.p, fbad.p);
+    exclusive_sum_u32(c, bcnt.p, boff.p, (size_t)nblocks + 1);
+    // total + first_bad in one sync
+    PFP_HIP(hipMemcpyAsync(c->h_scalars, boff.p + nblocks, 4, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, fbad.p, 8, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    uint32_t total; memcpy(&total, c->h_scalars, 4);
+    uint64_t fb = c->h_scalars[1];
+    if (fb < cur_n) {
+      // truncate at the first special byte and rescan the prefix with Dollar padding re-staged
+      PFP_REQUIRE(attempt == 0, PFP_EHIP, "scan: special byte after truncation");
+      cur_n = fb;
+      tx.restage_tail(c, cur_n, w);
+      continue;
+    }
+    d_ends.alloc(c, (size_t)total + 1);
+    if (total)
+      hipLaunchKernelGGL(kr_compact_kernel, dim3(nblocks), dim3(256), 0, c->stream, flags16.p, nchunks, boff.p, d_ends.p);
+    PFP_HIP(hipGetLastError());
+    return total;
+  }
+  return 0;
+}
+
+}  // namespace pfp

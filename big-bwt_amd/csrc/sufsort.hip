@@ -1,0 +1,168 @@
+// sufsort.hip -- GPU suffix sorting by prefix doubling on group-head ranks.
+//
+// Replaces the reference's serial induced sorting (gsa/gsacak.c: sacak_int :2497-2500 used by
+// bwtparse.c:167; gsacak :2502-2522 used by pfbwt.cpp:495; sacak :2492-2495 used by
+// simplebwt.c:77).  Induced sorting is one long left-to-right/right-to-left dependency chain
+// (gsacak.c:262-289); by SURVEY.md 2.2-Q11 any correct sorter yields the same arrays, so the
+// MI355X build sorts by prefix doubling: every round is a device-wide radix sort of the still
+// unresolved suffixes keyed by (group head, rank of the suffix h positions on), O(log maxlen)
+// rounds, all state resident in HBM.
+//
+// Dictionary mode compares 0x01-terminated strings: the key of a suffix never looks past its
+// own word's terminator, a group whose whole string is already inside the sorted prefix is
+// final, and equal strings keep one shared rank.  That rank equality *is* the "same suffix"
+// test the reference derives from the LCP array (pfbwt.cpp:204-209), so no LCP array is built.
+// Ties stay in position order (stable sorts), which reproduces gsacak's separator order
+// (gsacak.c:1559-1561).
+#include "kernels.hpp"
+#include "prims.hpp"
+#include "devutil.hpp"
+
+namespace pfp {
+
+enum : int { MODE_DICT = 0, MODE_PLAIN = 1 };
+
+struct SufGeom {
+  int mode; uint64_t N; const uint32_t *pos_word; const uint32_t *wend;
+};
+// length of the suffix string starting at i, terminator included
+__device__ __forceinline__ uint64_t suf_len(const SufGeom &g, uint32_t i) {
+  if (g.mode == MODE_DICT) return (uint64_t)g.wend[g.pos_word[i]] - i + 1;
+  return g.N - i;
+}
+
+// first 8 bytes of every dictionary suffix, big-endian, zero after the word terminator
+__global__ void init_keys_dict_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
+                                      uint32_t *__restrict__ val) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  uint64_t k = __builtin_bswap64(ld8u(s + i));
+  uint64_t v = k ^ 0x0101010101010101ULL;
+  uint64_t z = ~(((v & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | v | 0x7F7F7F7F7F7F7F7FULL);
+  if (z) {
+    int idx = __clzll((long long)z) >> 3;          // first terminator byte
+    k &= ~0ULL << (56 - 8 * idx);
+  }
+  key[i] = k; val[i] = (uint32_t)i;
+}
+__global__ void init_keys_bytes_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
+                                       uint32_t *__restrict__ val) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  key[i] = __builtin_bswap64(ld8u(s + i));         // buffer is zero padded past N
+  val[i] = (uint32_t)i;
+}
+__global__ void init_keys_int_kernel(const uint32_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
+                                     uint32_t *__restrict__ val) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  uint64_t a = s[i], b = (i + 1 < N) ? s[i + 1] : 0;
+  key[i] = (a << 32) | b; val[i] = (uint32_t)i;
+}
+__global__ void iota32_kernel(uint32_t *p, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+
+// key of an unresolved suffix: (its group's head slot, 1 + rank of the suffix h further on)
+__global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ aslot,
+                                  const uint32_t *__restrict__ sa, const uint32_t *__restrict__ rank,
+                                  uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  uint32_t i = sa[aslot[a]];
+  uint64_t grp = rank[i];
+  uint64_t nxt = (h < suf_len(g, i)) ? (uint64_t)rank[i + h] + 1 : 0;
+  key[a] = (grp << 32) | nxt;
+  val[a] = i;
+}
+
+__global__ void heads_kernel(uint64_t m, const uint64_t *__restrict__ key, const uint32_t *__restrict__ aslot,
+                             uint8_t *__restrict__ hd, uint32_t *__restrict__ hv) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  bool h = (a == 0) || key[a] != key[a - 1];
+  hd[a] = h ? 1 : 0;
+  hv[a] = h ? aslot[a] : 0u;
+}
+
+// write the refined order back and decide which suffixes stay unresolved.
+// sorted_len = prefix length that is sorted after this round.
+__global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, const uint32_t *__restrict__ aslot,
+                                  const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead,
+                                  const uint8_t *__restrict__ hd, uint32_t *__restrict__ sa,
+                                  uint32_t *__restrict__ rank, uint8_t *__restrict__ keep) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  uint32_t i = val[a];
+  sa[aslot[a]] = i;
+  rank[i] = newhead[a];
+  bool single = hd[a] && (a + 1 == m || hd[a + 1]);
+  bool fin = (g.mode == MODE_DICT) && suf_len(g, i) <= sorted_len;
+  keep[a] = (!single && !fin) ? 1 : 0;
+}
+
+static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> &val, uint64_t h0, SuffixOrder &out) {
+  // precondition: key/val hold the initial (prefix key, position) pairs for all N positions
+  const uint64_t N = g.N;
+  const int TB = 256;
+  out.N = N;
+  out.sa.alloc(c, N); out.rank.alloc(c, N);
+  DBuf<uint64_t> keyo(c, N);
+  DBuf<uint32_t> valo(c, N), aslot(c, N), aslot2(c, N), hv(c, N), newhead(c, N), cnt(c, 1);
+  DBuf<uint8_t> hd(c, N + 1), keep(c, N);
+  sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, N, 0, 64);
+  hipLaunchKernelGGL(iota32_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, aslot.p, N);
+  uint64_t m = N, h = h0;
+  out.rounds = 0;
+  const int keybits = 32 + bits_for(N);
+  for (;;) {
+    hipLaunchKernelGGL(heads_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p);
+    inclusive_max_u32(c, hv.p, newhead.p, m);
+    hipLaunchKernelGGL(write_back_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p,
+                       newhead.p, hd.p, out.sa.p, out.rank.p, keep.p);
+    select_flagged_u32(c, aslot.p, keep.p, aslot2.p, cnt.p, m);
+    PFP_HIP(hipGetLastError());
+    uint32_t m2 = read_scalar(c, cnt.p);
+    std::swap(aslot.p, aslot2.p);
+    m = m2;
+    if (m == 0) break;
+    PFP_REQUIRE(h < 2 * N, PFP_EHIP, "suffix sort failed to converge");
+    hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, out.sa.p,
+                       out.rank.p, key.p, val.p);
+    sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, keybits);
+    h *= 2;
+    out.rounds++;
+  }
+}
+
+void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *pos_word, const uint32_t *wend,
+                        uint64_t d, SuffixOrder &out) {
+  (void)d;
+  PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
+  SufGeom g{MODE_DICT, N, pos_word, wend};
+  DBuf<uint64_t> key(c, N);
+  DBuf<uint32_t> val(c, N);
+  hipLaunchKernelGGL(init_keys_dict_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, key.p, val.p);
+  doubling(c, g, key, val, 8, out);
+}
+
+void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrder &out) {
+  PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "text too large for 32-bit suffix indices");
+  SufGeom g{MODE_PLAIN, N, nullptr, nullptr};
+  DBuf<uint64_t> key(c, N);
+  DBuf<uint32_t> val(c, N);
+  hipLaunchKernelGGL(init_keys_bytes_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, key.p, val.p);
+  doubling(c, g, key, val, 8, out);
+}
+
+void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out) {
+  PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "parse too large for 32-bit suffix indices");
+  SufGeom g{MODE_PLAIN, N, nullptr, nullptr};
+  DBuf<uint64_t> key(c, N);
+  DBuf<uint32_t> val(c, N);
+  hipLaunchKernelGGL(init_keys_int_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, sym, N, key.p, val.p);
+  doubling(c, g, key, val, 2, out);
+}
+
+}  // namespace pfp

@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's stage interface over the C ABI of libpfpgpu.so.
+
+The reference (alshai/Big-BWT) is three executables glued by files; this module exposes the
+same three stages plus the whole chain as functions over numpy arrays that hold the reference's
+file formats byte for byte:
+
+    parse()     == newscanNT.x / pscan.x      (newscan.cpp:569-650)
+    bwtparse()  == bwtparse                   (bwtparse.c:212-322)
+    merge()     == pfbwtNT.x / pfbwt.x        (pfbwt.cpp:320-418)
+    bigbwt()    == bigbwt -w W -p M [-S|-s|-e] (bigbwt:69-156)
+    sacak_int() / sacak() / gsacak()  == gsa/gsacak.h:78-105
+
+Everything computes in hand-written HIP kernels on the MI355X; there is no CPU fallback: the
+import succeeds without a GPU (so that symbol checks can run), but creating a Context does not.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpfpgpu.so")
+
+FLAG_SA, FLAG_SSA, FLAG_ESA = 1, 2, 4
+
+ERRORS = {0: "PFP_OK", -1: "PFP_EINVAL", -2: "PFP_ENODEV", -3: "PFP_EHIP", -4: "PFP_ECOLLISION",
+          -5: "PFP_ELIMIT", -6: "PFP_EFORMAT", -7: "PFP_ENOMEM", -8: "PFP_ESHORT"}
+
+# every symbol include/pfpgpu.h declares
+SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror", "pfp_version", "pfp_ctx_stream",
+           "pfp_free", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak",
+           "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_dev", "pfp_get_stats",
+           "pfp_set_profiling", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue"]
+
+
+class PfpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class _ParseResult(C.Structure):
+    _fields_ = [("n_used", C.c_uint64), ("dict", C.POINTER(C.c_uint8)), ("dict_size", C.c_uint64),
+                ("occ", C.POINTER(C.c_uint32)), ("n_words", C.c_uint64),
+                ("parse", C.POINTER(C.c_uint32)), ("n_phrases", C.c_uint64),
+                ("last", C.POINTER(C.c_uint8)), ("sai", C.POINTER(C.c_uint8))]
+
+
+class _BwtResult(C.Structure):
+    _fields_ = [("bwt", C.POINTER(C.c_uint8)), ("bwt_size", C.c_uint64),
+                ("sa", C.POINTER(C.c_uint8)), ("sa_bytes", C.c_uint64),
+                ("ssa", C.POINTER(C.c_uint8)), ("ssa_bytes", C.c_uint64),
+                ("esa", C.POINTER(C.c_uint8)), ("esa_bytes", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n_phrases", C.c_uint64), ("n_words", C.c_uint64), ("dict_size", C.c_uint64),
+                ("sa_rounds_dict", C.c_uint64), ("sa_rounds_parse", C.c_uint64),
+                ("hard_groups", C.c_uint64), ("hard_chars", C.c_uint64), ("hash_reseeds", C.c_uint64),
+                ("ms_scan", C.c_double), ("ms_phrases", C.c_double), ("ms_sa_dict", C.c_double),
+                ("ms_sa_parse", C.c_double), ("ms_merge", C.c_double), ("ms_total", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libpfpgpu.so (built in-tree by __graft_entry__.build / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: the HIP extension has not been built "
+                              f"(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        lib.pfp_last_error.restype = C.c_char_p
+        lib.pfp_strerror.restype = C.c_char_p
+        lib.pfp_version.restype = C.c_char_p
+        lib.pfp_ctx_stream.restype = C.c_void_p
+        lib.pfp_ctx_destroy.restype = None
+        lib.pfp_free.restype = None
+        lib.pfp_set_profiling.restype = None
+        lib.pfp_parse_result_free.restype = None
+        lib.pfp_bwt_result_free.restype = None
+        _lib = lib
+    return _lib
+
+
+def _arr(a, dtype):
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(a, dtype=np.uint8)
+    a = np.ascontiguousarray(a)
+    if a.dtype != dtype:
+        a = a.astype(dtype) if dtype != np.uint8 or a.dtype.itemsize == 1 else a.view(np.uint8)
+    return a
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _take(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(int(n),)).astype(dtype, copy=True)
+
+
+def unpack5(b):
+    """5-byte little-endian ints (utils.c:112-129) -> u64 array"""
+    b = np.frombuffer(bytes(b), dtype=np.uint8).reshape(-1, 5)
+    out = np.zeros((len(b), 8), dtype=np.uint8)
+    out[:, :5] = b
+    return out.view(np.uint64).reshape(-1)
+
+
+def pack5(v):
+    v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1)
+    return v.view(np.uint8).reshape(-1, 8)[:, :5].copy().reshape(-1)
+
+
+class Context:
+    """One HIP stream + memory pool on one GPU (pfp_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        rc = self.lib.pfp_ctx_create(C.byref(self._h), C.c_int(device))
+        if rc:
+            raise PfpError(rc, "pfp_ctx_create failed: " + self.lib.pfp_strerror(rc).decode() +
+                           " (the HIP path is mandatory; no CPU fallback exists)")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self.lib.pfp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise PfpError(rc, self.lib.pfp_last_error(self._h).decode(errors="replace"))
+
+    @property
+    def stream(self):
+        return self.lib.pfp_ctx_stream(self._h)
+
+    def set_profiling(self, on=True):
+        self.lib.pfp_set_profiling(self._h, C.c_int(1 if on else 0))
+
+    def stats(self):
+        st = Stats()
+        self._check(self.lib.pfp_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    # -- stage 1a: newscan.cpp:168-202, 363-377
+    def scan(self, text, w=10, p=100):
+        t = _arr(text, np.uint8)
+        ends = C.POINTER(C.c_uint64)()
+        ne, used = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.pfp_scan(self._h, _ptr(t, C.c_uint8), C.c_uint64(len(t)), C.c_int(w), C.c_uint64(p),
+                                      C.byref(ends), C.byref(ne), C.byref(used)))
+        out = _take(ends, ne.value, np.uint64)
+        self.lib.pfp_free(ends)
+        return out, used.value
+
+    # -- stage 1: newscan.cpp main
+    def parse(self, text, w=10, p=100, want_sai=False):
+        t = _arr(text, np.uint8)
+        r = _ParseResult()
+        self._check(self.lib.pfp_parse(self._h, _ptr(t, C.c_uint8), C.c_uint64(len(t)), C.c_int(w), C.c_uint64(p),
+                                       C.c_int(1 if want_sai else 0), C.byref(r)))
+        out = dict(n_used=int(r.n_used), dict=_take(r.dict, r.dict_size, np.uint8), occ=_take(r.occ, r.n_words, np.uint32),
+                   parse=_take(r.parse, r.n_phrases, np.uint32), last=_take(r.last, r.n_phrases, np.uint8),
+                   sai=_take(r.sai, 5 * r.n_phrases, np.uint8) if want_sai else None)
+        self.lib.pfp_parse_result_free(C.byref(r))
+        return out
+
+    # -- gsa/gsacak.h
+    def sacak_int(self, s, k=0):
+        s = _arr(s, np.uint32)
+        sa = np.zeros(len(s), dtype=np.uint32)
+        self._check(self.lib.pfp_sacak_int(self._h, _ptr(s, C.c_uint32), _ptr(sa, C.c_uint32), C.c_uint64(len(s)), C.c_uint64(k)))
+        return sa
+
+    def sacak(self, s):
+        s = _arr(s, np.uint8)
+        sa = np.zeros(len(s), dtype=np.uint32)
+        self._check(self.lib.pfp_sacak(self._h, _ptr(s, C.c_uint8), _ptr(sa, C.c_uint32), C.c_uint64(len(s))))
+        return sa
+
+    def gsacak(self, s):
+        s = _arr(s, np.uint8)
+        sa = np.zeros(len(s), dtype=np.uint32)
+        self._check(self.lib.pfp_gsacak(self._h, _ptr(s, C.c_uint8), _ptr(sa, C.c_uint32), C.c_uint64(len(s))))
+        return sa
+
+    # -- stage 2: bwtparse.c main
+    def bwtparse(self, parse, last, occ, sai=None):
+        parse = _arr(parse, np.uint32); last = _arr(last, np.uint8); occ = _arr(occ, np.uint32)
+        P = len(parse)
+        ilist = np.zeros(P + 1, dtype=np.uint32)
+        bwlast = np.zeros(P + 1, dtype=np.uint8)
+        bwsai = np.zeros(5 * (P + 1), dtype=np.uint8) if sai is not None else None
+        sai_a = _arr(sai, np.uint8) if sai is not None else None
+        self._check(self.lib.pfp_bwtparse(self._h, _ptr(parse, C.c_uint32), C.c_uint64(P), _ptr(last, C.c_uint8),
+                                          _ptr(sai_a, C.c_uint8) if sai is not None else None,
+                                          _ptr(occ, C.c_uint32), C.c_uint64(len(occ)), _ptr(ilist, C.c_uint32),
+                                          _ptr(bwlast, C.c_uint8),
+                                          _ptr(bwsai, C.c_uint8) if sai is not None else None))
+        return ilist, bwlast, bwsai
+
+    def _bwt_result(self, r):
+        out = dict(bwt=_take(r.bwt, r.bwt_size, np.uint8), sa=_take(r.sa, r.sa_bytes, np.uint8),
+                   ssa=_take(r.ssa, r.ssa_bytes, np.uint8), esa=_take(r.esa, r.esa_bytes, np.uint8))
+        self.lib.pfp_bwt_result_free(C.byref(r))
+        return out
+
+    # -- stage 3: pfbwt.cpp main
+    def merge(self, dict_, occ, ilist, bwlast, bwsai=None, w=10, flags=0):
+        d = _arr(dict_, np.uint8); occ = _arr(occ, np.uint32); ilist = _arr(ilist, np.uint32); bwlast = _arr(bwlast, np.uint8)
+        bs = _arr(bwsai, np.uint8) if bwsai is not None else None
+        r = _BwtResult()
+        self._check(self.lib.pfp_merge(self._h, _ptr(d, C.c_uint8), C.c_uint64(len(d)), _ptr(occ, C.c_uint32),
+                                       C.c_uint64(len(occ)), _ptr(ilist, C.c_uint32), _ptr(bwlast, C.c_uint8),
+                                       _ptr(bs, C.c_uint8) if bs is not None else None, C.c_uint64(len(ilist)),
+                                       C.c_int(w), C.c_int(flags), C.byref(r)))
+        return self._bwt_result(r)
+
+    # -- bigbwt chain, host buffers
+    def bigbwt(self, text, w=10, p=100, flags=0):
+        t = _arr(text, np.uint8)
+        r = _BwtResult()
+        self._check(self.lib.pfp_bigbwt(self._h, _ptr(t, C.c_uint8), C.c_uint64(len(t)), C.c_int(w), C.c_uint64(p),
+                                        C.c_int(flags), C.byref(r)))
+        return self._bwt_result(r)
+
+    # -- bigbwt chain, device-resident (raw device pointers, e.g. torch tensor.data_ptr())
+    def bigbwt_dev(self, d_text_ptr, n, d_bwt_ptr, d_sa_ptr=None, w=10, p=100, flags=0):
+        used = C.c_uint64()
+        self._check(self.lib.pfp_bigbwt_dev(self._h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_int(w), C.c_uint64(p),
+                                            C.c_int(flags), C.c_void_p(d_bwt_ptr),
+                                            C.c_void_p(d_sa_ptr) if d_sa_ptr else None, C.byref(used)))
+        return used.value
+
+    def stage_text_dev(self, d_text_ptr, n, w=10):
+        self._check(self.lib.pfp_stage_text_dev(self._h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_int(w)))
+
+    def scan_staged(self, p=100):
+        ne = C.c_uint64()
+        self._check(self.lib.pfp_scan_staged(self._h, C.c_uint64(p), C.byref(ne)))
+        return ne.value
+
+    def scan_k1_enqueue(self, p=100):
+        self._check(self.lib.pfp_scan_k1_enqueue(self._h, C.c_uint64(p)))

@@ -1,0 +1,161 @@
+/* pfpgpu.h -- C ABI of libpfpgpu.so: MI355X (gfx950) prefix-free-parsing BWT builder.
+ *
+ * This is the drop-in boundary for the parse -> SA -> BWT hot path of alshai/Big-BWT.
+ * The reference has no FFI; its stages are three executables glued by files, and the only
+ * in-process ABI on the path is gsa/gsacak.h.  Each entry point below names the reference
+ * interface it replaces (file:line under the reference tree).  Plain pointers and sizes only:
+ * no C++/torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns PFP_OK (0) or a negative PFP_E* code; nothing calls exit()
+ *     (the reference die()s: utils.c:12-16); pfp_last_error(ctx) gives a message.
+ *   - "host" entry points take/return caller-owned host buffers in the reference's on-disk
+ *     byte formats; "_dev" entry points take device pointers (hipMalloc'ed
+ *     or torch CUDA tensors' data_ptr) and leave results in device memory.
+ *   - one pfp_ctx per host thread / GPU; a ctx owns one HIP stream and a device memory pool.
+ *   - all compute runs in HIP kernels on the ctx's device; there is no CPU fallback: if no
+ *     GPU is usable pfp_ctx_create fails with PFP_ENODEV.
+ */
+#ifndef PFPGPU_H
+#define PFPGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFP_OK 0
+#define PFP_EINVAL (-1)     /* bad argument (w<4, p<10: newscan.cpp:537-544; -S with -s/-e: bigbwt:59-61) */
+#define PFP_ENODEV (-2)     /* no usable HIP device */
+#define PFP_EHIP (-3)       /* HIP runtime error */
+#define PFP_ECOLLISION (-4) /* phrase-hash collision survived all reseeds (newscan.cpp:282-286) */
+#define PFP_ELIMIT (-5)     /* size limit: parse > 2^32-2 words (bwtparse.c:93), dict >= 2^32-2 bytes */
+#define PFP_EFORMAT (-6)    /* inconsistent stage inputs (pfbwt.cpp:498-512 style checks) */
+#define PFP_ENOMEM (-7)
+#define PFP_ESHORT (-8)     /* text shorter than the window / empty parse (bwtparse.c:244) */
+
+/* output selection, same meaning as bigbwt -S / -s / -e (bigbwt:41-43) */
+#define PFP_FLAG_SA 1
+#define PFP_FLAG_SSA 2
+#define PFP_FLAG_ESA 4
+
+typedef struct pfp_ctx pfp_ctx;
+
+int pfp_ctx_create(pfp_ctx **ctx, int device);
+void pfp_ctx_destroy(pfp_ctx *ctx);
+const char *pfp_last_error(const pfp_ctx *ctx);
+const char *pfp_strerror(int code);
+/* library / kernel build identification ("pfpgpu <ver> gfx950 ...") */
+const char *pfp_version(void);
+/* HIP stream the ctx launches on (hipStream_t), for callers that time with events */
+void *pfp_ctx_stream(pfp_ctx *ctx);
+void pfp_free(void *host_ptr);     /* frees host buffers returned by this library */
+
+/* ------------------------------------------------------------------------------------
+ * Stage 1a: rolling Karp-Rabin window scan + phrase-boundary compaction.
+ * Replaces KR_window::addchar + the trigger test of process_file (newscan.cpp:168-202,
+ * 363-377; pscan.hpp:44-108).  ends[k] = text position of the last byte of phrase k, for
+ * every trigger position (the final phrase, which ends in the w Dollars, is not listed).
+ * *n_used = bytes actually parsed: parsing stops at the first byte <= 2 (newscan.cpp:364).
+ * ------------------------------------------------------------------------------------ */
+int pfp_scan(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p,
+             uint64_t **ends, uint64_t *n_ends, uint64_t *n_used);
+
+/* ------------------------------------------------------------------------------------
+ * Stage 1: the whole parser (newscanNT.x / pscan.x main: newscan.cpp:569-650).
+ * Outputs are the reference's files as byte-exact buffers (library-allocated, pfp_free):
+ *   dict  (.dict)  sorted phrases, each + 0x01, final 0x00      occ (.occ) u32[d]
+ *   parse (.parse) u32[P] 1-based ranks                         last (.last) u8[P]
+ *   sai   (.sai)   5-byte LE ints [P], only when want_sai
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+  uint64_t n_used;
+  uint8_t *dict;   uint64_t dict_size;
+  uint32_t *occ;   uint64_t n_words;      /* d */
+  uint32_t *parse; uint64_t n_phrases;    /* P */
+  uint8_t *last;
+  uint8_t *sai;                           /* 5*P bytes or NULL */
+} pfp_parse_result;
+int pfp_parse(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p, int want_sai,
+              pfp_parse_result *out);
+void pfp_parse_result_free(pfp_parse_result *r);
+
+/* ------------------------------------------------------------------------------------
+ * Suffix sorting, drop-in for gsa/gsacak.h:78-105 (32-bit build, uint_t = uint32_t).
+ *   pfp_sacak_int  == sacak_int(s,SA,n,k)   s[n-1]==0 unique smallest   (bwtparse.c:167)
+ *   pfp_sacak      == sacak(s,SA,n)                                      (simplebwt.c:77)
+ *   pfp_gsacak     == gsacak(s,SA,LCP,DA,n) with LCP==DA==NULL: separators (byte 1) ordered
+ *                     by position, s[n-1]==0                             (pfbwt.cpp:495)
+ * Return 0 on success (the reference returns the recursion depth, callers only test >=0).
+ * ------------------------------------------------------------------------------------ */
+int pfp_sacak_int(pfp_ctx *ctx, const uint32_t *s, uint32_t *SA, uint64_t n, uint64_t k);
+int pfp_sacak(pfp_ctx *ctx, const uint8_t *s, uint32_t *SA, uint64_t n);
+int pfp_gsacak(pfp_ctx *ctx, const uint8_t *s, uint32_t *SA, uint64_t n);
+
+/* ------------------------------------------------------------------------------------
+ * Stage 2: bwtparse main (bwtparse.c:212-322): SA of the parse, BWT(P), inverted lists and
+ * the permuted last / sai arrays.  Caller-allocated outputs: ilist u32[P+1],
+ * bwlast u8[P+1], bwsai 5*(P+1) bytes (only when sai != NULL).
+ * ------------------------------------------------------------------------------------ */
+int pfp_bwtparse(pfp_ctx *ctx, const uint32_t *parse, uint64_t P, const uint8_t *last,
+                 const uint8_t *sai /*5P bytes or NULL*/, const uint32_t *occ, uint64_t n_words,
+                 uint32_t *ilist, uint8_t *bwlast, uint8_t *bwsai);
+
+/* ------------------------------------------------------------------------------------
+ * Stage 3: pfbwt main (pfbwt.cpp:320-418 -> bwt() :109-242, pfthreads.hpp:403-518).
+ * n_plus_1 = ilist length = P+1.  Outputs library-allocated (pfp_free):
+ *   bwt (.bwt) n+1 bytes; sa (.sa) 5n bytes; ssa/esa (.ssa/.esa) 10 bytes per pair.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+  uint8_t *bwt; uint64_t bwt_size;
+  uint8_t *sa;  uint64_t sa_bytes;
+  uint8_t *ssa; uint64_t ssa_bytes;
+  uint8_t *esa; uint64_t esa_bytes;
+} pfp_bwt_result;
+int pfp_merge(pfp_ctx *ctx, const uint8_t *dict, uint64_t dict_size, const uint32_t *occ,
+              uint64_t n_words, const uint32_t *ilist, const uint8_t *bwlast,
+              const uint8_t *bwsai /*5(P+1) bytes or NULL*/, uint64_t n_plus_1, int w, int flags,
+              pfp_bwt_result *out);
+void pfp_bwt_result_free(pfp_bwt_result *r);
+
+/* ------------------------------------------------------------------------------------
+ * The whole chain in one call, as `bigbwt -w W -p M [-S|-s|-e] file` runs it (bigbwt:69-156),
+ * with every intermediate kept in HBM (no files).  Host text in, host results out.
+ * ------------------------------------------------------------------------------------ */
+int pfp_bigbwt(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags,
+               pfp_bwt_result *out);
+
+/* Device-resident variant: d_text is a device pointer to n bytes; d_bwt must hold n+1 bytes.
+ * Optional device outputs (may be NULL unless the flag is set):
+ *   d_sa   u64[n+1]  SA value per BWT position (d_sa[0] = n), flags & (SA|SSA|ESA)
+ * Run-sampled / packed outputs are derived from d_bwt/d_sa by pfp_pack_* below.
+ * *n_used returns the parsed length; bwt length is *n_used + 1. */
+int pfp_bigbwt_dev(pfp_ctx *ctx, const void *d_text, uint64_t n, int w, uint64_t p, int flags,
+                   void *d_bwt, void *d_sa, uint64_t *n_used);
+
+/* per-call statistics of the most recent pfp_bigbwt / pfp_bigbwt_dev / pfp_parse on this ctx */
+typedef struct {
+  uint64_t n, n_phrases, n_words, dict_size;
+  uint64_t sa_rounds_dict, sa_rounds_parse;
+  uint64_t hard_groups, hard_chars;
+  uint64_t hash_reseeds;
+  double ms_scan, ms_phrases, ms_sa_dict, ms_sa_parse, ms_merge, ms_total; /* host wall, synced */
+} pfp_stats;
+int pfp_get_stats(const pfp_ctx *ctx, pfp_stats *st);
+/* when set (default 0) every pipeline phase is bracketed by a stream sync so ms_* are filled */
+void pfp_set_profiling(pfp_ctx *ctx, int on);
+
+/* ---- micro entry points used by bench.py's roofline leg and by the parity tests ---- */
+/* copy a device-resident text into the ctx's padded staging buffer (T' = Dollar.T.Dollar^w) */
+int pfp_stage_text_dev(pfp_ctx *ctx, const void *d_text, uint64_t n, int w);
+/* run only stage 1a (K1 window-hash + trigger mask, block-count scan, K2 compaction) on the
+ * staged text; all work is enqueued on pfp_ctx_stream(ctx) and finished on return. */
+int pfp_scan_staged(pfp_ctx *ctx, uint64_t p, uint64_t *n_ends);
+/* enqueue only K1 (the window-hash kernel, n + n/8 bytes of traffic) - no sync, for event timing */
+int pfp_scan_k1_enqueue(pfp_ctx *ctx, uint64_t p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
