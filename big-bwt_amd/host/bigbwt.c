@@ -1,0 +1,260 @@
+/* bigbwt.c -- C command-line driver with the flag surface of the reference's `bigbwt` script
+ * (reference bigbwt:36-197), calling the HIP kernels in-process through the C ABI
+ * (include/pfpgpu.h).  Where the reference chains three executables through temp files
+ * (newscan -> bwtparse -> pfbwt, bigbwt:69-156) this driver makes one pfp_bigbwt() call and
+ * every intermediate stays in HBM; -k additionally materialises the reference's temp files
+ * through the staged entry points so that each one can be diffed against the reference.
+ *
+ *   bigbwt [-w W] [-p M] [-t T] [-s] [-e] [-S] [-k] [-v] [-c] [-f] [--sum] [--parsing]
+ *          [--compress] [-P] input
+ *
+ * Outputs next to the input, byte formats as the reference: .bwt always; .sa | .ssa | .esa;
+ * .log (appended).  -t is accepted and ignored (the GPU is the helper); -P is accepted and
+ * unnecessary (phrase deduplication is exact).  -f and --compress are not implemented yet.
+ */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <fcntl.h>
+#include <getopt.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+#include "pfpgpu.h"
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static int write_file(const char *base, const char *ext, const void *data, size_t bytes) {
+  char name[4096];
+  snprintf(name, sizeof name, "%s.%s", base, ext);
+  FILE *f = fopen(name, "wb");
+  if (!f) { perror(name); return -1; }
+  size_t w = bytes ? fwrite(data, 1, bytes, f) : 0;
+  if (fclose(f) != 0 || w != bytes) { fprintf(stderr, "Error writing %s\n", name); return -1; }
+  return 0;
+}
+
+/* bigbwt:219-228 file_digest: shells out to sha256sum exactly as the reference does */
+static void print_digest(const char *label, const char *base, const char *ext) {
+  char cmd[4200], line[256] = "Error!";
+  snprintf(cmd, sizeof cmd, "sha256sum '%s.%s' 2>/dev/null", base, ext);
+  FILE *p = popen(cmd, "r");
+  if (p) {
+    if (fgets(line, sizeof line, p)) { char *sp = strchr(line, ' '); if (sp) *sp = 0; }
+    pclose(p);
+  }
+  printf("%s sha256sum: %s\n", label, line);
+}
+
+static void usage(const char *argv0) {
+  printf("usage: %s [-h] [-w WSIZE] [-p MOD] [-t T] [-s] [-e] [-S] [-k] [-v] [-c] [-f] [--sum]\n"
+         "              [--parsing] [--compress] [--probing] input\n\n"
+         "MI355X build of the prefix-free-parsing BWT tool (drop-in for alshai/Big-BWT's bigbwt).\n\n"
+         "  input            input file name\n"
+         "  -w, --wsize W    sliding window size (def. 10)\n"
+         "  -p, --mod M      hash modulus (def. 100)\n"
+         "  -t T             number of helper threads (accepted, ignored: the GPU does the work)\n"
+         "  -s               compute the start run-length sampled Suffix Array\n"
+         "  -e               compute the end run-length sampled Suffix Array\n"
+         "  -S               compute the full Suffix Array\n"
+         "  -k               keep temporary files (.dict .occ .parse .last .sai .ilist .bwlast .bwsai)\n"
+         "  -v               verbose\n"
+         "  -c               check BWT against the whole-text suffix array (reference: SACA-K)\n"
+         "  -f               read fasta (not implemented in this build)\n"
+         "  --sum            compute output files sha256sum\n"
+         "  --parsing        stop after the parsing phase (debug only)\n"
+         "  --compress       compress output of the parsing phase (not implemented in this build)\n"
+         "  -P, --probing    accepted for compatibility (deduplication here is exact)\n",
+         argv0);
+}
+
+int main(int argc, char **argv) {
+  int w = 10, th = 0, s = 0, e = 0, S = 0, keep = 0, verbose = 0, check = 0, fasta = 0, sum = 0, parsing = 0,
+      compress = 0, device = 0;
+  unsigned long long p = 100;
+  static struct option lo[] = {{"wsize", required_argument, 0, 'w'}, {"mod", required_argument, 0, 'p'},
+                               {"sum", no_argument, 0, 1000},        {"parsing", no_argument, 0, 1001},
+                               {"compress", no_argument, 0, 1002},   {"probing", no_argument, 0, 'P'},
+                               {"device", required_argument, 0, 1003}, {"help", no_argument, 0, 'h'},
+                               {0, 0, 0, 0}};
+  int c;
+  while ((c = getopt_long(argc, argv, "w:p:t:seSkvcfPh", lo, NULL)) != -1) {
+    switch (c) {
+      case 'w': w = atoi(optarg); break;
+      case 'p': p = strtoull(optarg, NULL, 10); break;
+      case 't': th = atoi(optarg); break;
+      case 's': s = 1; break;
+      case 'e': e = 1; break;
+      case 'S': S = 1; break;
+      case 'k': keep = 1; break;
+      case 'v': verbose = 1; break;
+      case 'c': check = 1; break;
+      case 'f': fasta = 1; break;
+      case 'P': break;
+      case 1000: sum = 1; break;
+      case 1001: parsing = 1; break;
+      case 1002: compress = 1; break;
+      case 1003: device = atoi(optarg); break;
+      case 'h': usage(argv[0]); return 0;
+      default: usage(argv[0]); return 2;
+    }
+  }
+  if (optind + 1 != argc) { usage(argv[0]); return 2; }
+  const char *input = argv[optind];
+  (void)th;
+  if (S && (s || e)) {   /* bigbwt:59-61 */
+    printf("You can either compute the full SA or a sample of it, not both. Exiting...\n");
+    return 0;
+  }
+  if (fasta || compress) {
+    printf("%s is not supported by this build. Exiting...\n", fasta ? "-f (fasta mode)" : "--compress");
+    return 1;
+  }
+  char logname[4096];
+  snprintf(logname, sizeof logname, "%s.log", input);
+  printf("Sending logging messages to file: %s\n", logname);
+  FILE *logf = fopen(logname, "a");
+  if (!logf) { perror(logname); return 1; }
+
+  int fd = open(input, O_RDONLY);
+  struct stat sb;
+  if (fd < 0 || fstat(fd, &sb) != 0) { perror(input); return 1; }
+  uint64_t n = (uint64_t)sb.st_size;
+  const uint8_t *text = n ? mmap(NULL, n, PROT_READ, MAP_PRIVATE, fd, 0) : (const uint8_t *)"";
+  if (text == MAP_FAILED) { perror("mmap"); return 1; }
+
+  pfp_ctx *ctx = NULL;
+  int rc = pfp_ctx_create(&ctx, device);
+  if (rc) {
+    fprintf(stderr, "Cannot initialise the GPU (%s): this tool has no CPU path\n", pfp_strerror(rc));
+    return 1;
+  }
+  pfp_set_profiling(ctx, verbose);
+  fprintf(logf, "==== %s\n==== input %s (%llu bytes) -w %d -p %llu%s%s%s\n", pfp_version(), input,
+          (unsigned long long)n, w, p, s ? " -s" : "", e ? " -e" : "", S ? " -S" : "");
+  int flags = (S ? PFP_FLAG_SA : 0) | (s ? PFP_FLAG_SSA : 0) | (e ? PFP_FLAG_ESA : 0);
+  double start0 = now_s(), start = start0;
+  int status = 0;
+
+  if (keep || parsing) {
+    /* staged run: materialise the reference's temp files (bigbwt -k / --parsing) */
+    pfp_parse_result pr;
+    printf("==== Parsing. Command: pfp_parse(%s, -w %d -p %llu%s)\n", input, w, p, flags ? " -s" : "");
+    rc = pfp_parse(ctx, text, n, w, p, flags != 0, &pr);
+    if (rc) goto fail;
+    fprintf(logf, "Found %llu distinct words\nTotal number of words: %llu\n", (unsigned long long)pr.n_words,
+            (unsigned long long)pr.n_phrases);
+    status |= write_file(input, "dict", pr.dict, pr.dict_size);
+    status |= write_file(input, "parse", pr.parse, pr.n_phrases * 4);
+    if (!parsing) {   /* bigbwt:88-94 removes .last/.occ after --parsing */
+      status |= write_file(input, "occ", pr.occ, pr.n_words * 4);
+      status |= write_file(input, "last", pr.last, pr.n_phrases);
+      if (flags) status |= write_file(input, "sai", pr.sai, pr.n_phrases * 5);
+    }
+    printf("Elapsed time: %.4f\n", now_s() - start);
+    if (parsing) {
+      printf("==== Stopping after the parsing phase as requested\n");
+      pfp_parse_result_free(&pr);
+      goto done;
+    }
+    start = now_s();
+    uint64_t P = pr.n_phrases;
+    uint32_t *ilist = malloc((P + 1) * 4);
+    uint8_t *bwlast = malloc(P + 1), *bwsai = flags ? malloc((P + 1) * 5) : NULL;
+    printf("==== Computing BWT of parsing. Command: pfp_bwtparse(%s%s)\n", input, flags ? " -s" : "");
+    rc = pfp_bwtparse(ctx, pr.parse, P, pr.last, flags ? pr.sai : NULL, pr.occ, pr.n_words, ilist, bwlast, bwsai);
+    if (rc) goto fail;
+    status |= write_file(input, "ilist", ilist, (P + 1) * 4);
+    status |= write_file(input, "bwlast", bwlast, P + 1);
+    if (flags) status |= write_file(input, "bwsai", bwsai, (P + 1) * 5);
+    printf("Elapsed time: %.4f\n", now_s() - start);
+    start = now_s();
+    pfp_bwt_result br;
+    printf("==== Computing final BWT. Command: pfp_merge(-w %d %s%s%s%s)\n", w, input, s ? " -s" : "", e ? " -e" : "",
+           S ? " -S" : "");
+    rc = pfp_merge(ctx, pr.dict, pr.dict_size, pr.occ, pr.n_words, ilist, bwlast, bwsai, P + 1, w, flags, &br);
+    if (rc) goto fail;
+    status |= write_file(input, "bwt", br.bwt, br.bwt_size);
+    if (S) status |= write_file(input, "sa", br.sa, br.sa_bytes);
+    if (s) status |= write_file(input, "ssa", br.ssa, br.ssa_bytes);
+    if (e) status |= write_file(input, "esa", br.esa, br.esa_bytes);
+    printf("Elapsed time: %.4f\n", now_s() - start);
+    pfp_bwt_result_free(&br);
+    pfp_parse_result_free(&pr);
+    free(ilist); free(bwlast); free(bwsai);
+  } else {
+    pfp_bwt_result br;
+    printf("==== Parsing, BWT of parsing, final BWT on the GPU. Command: pfp_bigbwt(%s, -w %d -p %llu%s%s%s)\n", input, w,
+           p, s ? " -s" : "", e ? " -e" : "", S ? " -S" : "");
+    rc = pfp_bigbwt(ctx, text, n, w, p, flags, &br);
+    if (rc) goto fail;
+    pfp_stats st;
+    pfp_get_stats(ctx, &st);
+    fprintf(logf, "Found %llu distinct words\nTotal number of words: %llu\nDictionary size: %llu\n"
+                  "SA rounds dict/parse: %llu/%llu\nHard groups: %llu\nHard bwt chars: %llu\n",
+            (unsigned long long)st.n_words, (unsigned long long)st.n_phrases, (unsigned long long)st.dict_size,
+            (unsigned long long)st.sa_rounds_dict, (unsigned long long)st.sa_rounds_parse,
+            (unsigned long long)st.hard_groups, (unsigned long long)st.hard_chars);
+    if (verbose)
+      printf("  GPU ms: scan %.2f phrases %.2f dictSA %.2f parseSA %.2f merge %.2f total %.2f\n", st.ms_scan,
+             st.ms_phrases, st.ms_sa_dict, st.ms_sa_parse, st.ms_merge, st.ms_total);
+    if (st.n != n) fprintf(stderr, "Invalid char found in input file: no additional chars will be read\n");
+    status |= write_file(input, "bwt", br.bwt, br.bwt_size);
+    if (S) status |= write_file(input, "sa", br.sa, br.sa_bytes);
+    if (s) status |= write_file(input, "ssa", br.ssa, br.ssa_bytes);
+    if (e) status |= write_file(input, "esa", br.esa, br.esa_bytes);
+    pfp_bwt_result_free(&br);
+    printf("Elapsed time: %.4f\n", now_s() - start);
+  }
+  printf("Total construction time: %.4f\n", now_s() - start0);
+  if (sum) {   /* bigbwt:160-171 */
+    print_digest("BWT", input, "bwt");
+    if (S) print_digest("SA ", input, "sa");
+    if (s) print_digest("SSA", input, "ssa");
+    if (e) print_digest("ESA", input, "esa");
+  }
+  if (!keep) printf("==== Deleting temporary files.\n");   /* nothing was written: intermediates lived in HBM */
+  if (check) {   /* bigbwt:177-194: whole-text suffix array -> .Bwt, then compare */
+    start = now_s();
+    printf("==== Computing BWT using the whole-text suffix array. Command: pfp_sacak(%s)\n", input);
+    uint8_t *t0 = malloc(n + 1);
+    uint32_t *SA = malloc((n + 1) * sizeof *SA);
+    uint8_t *B = malloc(n + 1);
+    if (!t0 || !SA || !B || n + 1 >= 0xFFFFFFF0ull) { fprintf(stderr, "-c: input too large\n"); status = 1; goto done; }
+    memcpy(t0, text, n); t0[n] = 0;
+    rc = pfp_sacak(ctx, t0, SA, n + 1);
+    if (rc) goto fail;
+    for (uint64_t i = 0; i <= n; i++) B[i] = SA[i] ? t0[SA[i] - 1] : 0;   /* simplebwt.c:80-93 */
+    status |= write_file(input, "Bwt", B, n + 1);
+    printf("Elapsed time: %.4f\n", now_s() - start);
+    char nm[4096];
+    snprintf(nm, sizeof nm, "%s.bwt", input);
+    FILE *f = fopen(nm, "rb");
+    uint8_t *mine = malloc(n + 2);
+    size_t got = f ? fread(mine, 1, n + 2, f) : 0;
+    if (f) fclose(f);
+    printf("==== Comparing BWTs. Command: cmp %s.bwt %s.Bwt\n", input, input);
+    printf((got == n + 1 && memcmp(mine, B, n + 1) == 0) ? "BWTs match\n" : "BWTs differ\n");
+    free(mine); free(t0); free(SA); free(B);
+  }
+done:
+  printf("==== Done\n");
+  fclose(logf);
+  pfp_ctx_destroy(ctx);
+  return status ? 1 : 0;
+fail:
+  /* bigbwt:235-239 */
+  printf("Error executing command line:\n\t%s: %s\nCheck log file: %s\n", pfp_strerror(rc), pfp_last_error(ctx), logname);
+  fprintf(logf, "error %d: %s\n", rc, pfp_last_error(ctx));
+  fclose(logf);
+  pfp_ctx_destroy(ctx);
+  return 1;
+}

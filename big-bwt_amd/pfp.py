@@ -74,6 +74,14 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: the HIP extension has not been built "
                               f"(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        # PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, soname
+        # libamdhip64.so.7).  Two HIP runtimes in one process cannot both own the GPU, so when
+        # torch is installed it is imported FIRST: libpfpgpu.so's DT_NEEDED libamdhip64.so.7 then
+        # binds to the runtime torch already loaded and both share devices, streams and memory.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.pfp_last_error.restype = C.c_char_p
         lib.pfp_strerror.restype = C.c_char_p

@@ -1,0 +1,198 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against (a) the golden
+vectors the real reference produced and (b) the CPU oracle on the same seeded inputs; at larger
+sizes through size-independent properties of a BWT / suffix array."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from textgen import make_text
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("idx", range(15))
+def test_bigbwt_matches_reference_golden(golden, O, pkg, ctx, idx):
+    """pfp_bigbwt == bigbwt -w W -p M [-S | -s -e] (bit-exact .bwt/.sa/.ssa/.esa)."""
+    if idx >= len(golden):
+        pytest.skip("no such case")
+    c = golden[idx]
+    text = make_text(c["spec"], O)
+    for flags in (0, 1, 6):
+        r = c["runs"][str(flags)]
+        got = ctx.bigbwt(text, c["w"], c["p"], flags)
+        assert len(got["bwt"]) == r["bwt_len"]
+        assert sha(got["bwt"]) == r["bwt_sha256"], (c["name"], flags, "bwt")
+        if flags & 1:
+            assert sha(got["sa"]) == r["sa_sha256"], (c["name"], "sa")
+        if flags & 2:
+            assert sha(got["ssa"]) == r["ssa_sha256"], (c["name"], "ssa")
+        if flags & 4:
+            assert sha(got["esa"]) == r["esa_sha256"], (c["name"], "esa")
+
+
+@pytest.mark.parametrize("idx", range(15))
+def test_stage_files_match_reference_golden(golden, O, pkg, ctx, idx):
+    """pfp_parse / pfp_bwtparse / pfp_merge reproduce every temp file of the reference."""
+    if idx >= len(golden):
+        pytest.skip("no such case")
+    c = golden[idx]
+    text = make_text(c["spec"], O)
+    r = c["runs"]["6"]
+    ps = ctx.parse(text, c["w"], c["p"], want_sai=True)
+    for k in ("dict", "occ", "parse", "last", "sai"):
+        assert sha(ps[k]) == r[k + "_sha256"], (c["name"], k)
+    ilist, bwlast, bwsai = ctx.bwtparse(ps["parse"], ps["last"], ps["occ"], ps["sai"])
+    assert sha(ilist) == r["ilist_sha256"] and sha(bwlast) == r["bwlast_sha256"] and sha(bwsai) == r["bwsai_sha256"]
+    out = ctx.merge(ps["dict"], ps["occ"], ilist, bwlast, bwsai, c["w"], pkg.FLAG_SSA | pkg.FLAG_ESA)
+    assert sha(out["bwt"]) == r["bwt_sha256"] and sha(out["ssa"]) == r["ssa_sha256"] and sha(out["esa"]) == r["esa_sha256"]
+    out = ctx.merge(ps["dict"], ps["occ"], ilist, bwlast, bwsai, c["w"], pkg.FLAG_SA)
+    assert sha(out["sa"]) == c["runs"]["1"]["sa_sha256"]
+    out = ctx.merge(ps["dict"], ps["occ"], ilist, bwlast, None, c["w"], 0)
+    assert sha(out["bwt"]) == c["runs"]["0"]["bwt_sha256"]
+
+
+def test_scan_matches_oracle(O, ctx):
+    """K1/K2 against KR_window::addchar restated on the CPU, many (w,p) incl. even/odd/huge p."""
+    text = O.gen_fasta(50000, 2, 0.001, 21)
+    for w, p in [(4, 11), (5, 10), (8, 64), (10, 100), (12, 200), (16, 37), (17, 1000), (18, 50), (25, 33), (10, 1 << 33)]:
+        ends, used = ctx.scan(text, w, p)
+        want = O.scan(text, w, p)
+        assert used == len(text)
+        assert np.array_equal(ends, want), (w, p)
+
+
+def test_scan_random_bytes_all_windows(O, ctx):
+    """window hash over the full byte range 3..255 (Barrett reduction corner values)"""
+    rng = np.random.default_rng(5)
+    text = rng.integers(3, 256, size=200000, dtype=np.uint8)
+    text[1000:1100] = 255
+    text[5000:5100] = 3
+    for w in (4, 7, 10, 13, 17):
+        ends, _ = ctx.scan(text, w, 10)
+        assert np.array_equal(ends, O.scan(text, w, 10)), w
+
+
+def test_suffix_sorters_match_oracle(O, ctx):
+    rng = np.random.default_rng(7)
+    s = np.concatenate([rng.integers(1, 50, size=30000), [0]]).astype(np.uint32)
+    assert np.array_equal(ctx.sacak_int(s), O.sacak_int(s))
+    rep = np.concatenate([np.tile(rng.integers(1, 5, size=100), 200), [0]]).astype(np.uint32)   # deep LCPs
+    assert np.array_equal(ctx.sacak_int(rep), O.sacak_int(rep))
+    t = np.concatenate([O.gen_fasta(20000, 3, 0.001, 9), [0]]).astype(np.uint8)
+    assert np.array_equal(ctx.sacak(t), O.sacak(t))
+    d = O.parse(O.gen_fasta(30000, 3, 0.002, 10), 10, 100)["dict"]
+    sa, _ = O.gsacak(d, want_lcp=False)
+    assert np.array_equal(ctx.gsacak(d), sa)
+    ex = np.frombuffer(b"banana\x01anaba\x01anan\x01\x00", dtype=np.uint8)   # gsa/README.md:76-104
+    assert np.array_equal(ctx.gsacak(ex), O.gsacak(ex, want_lcp=False)[0])
+
+
+def test_error_behaviour(pkg, ctx, O):
+    text = O.gen_fasta(5000, 1, 0, 3)
+    for kw, code in [(dict(w=3), -1), (dict(p=9), -1), (dict(flags=pkg.FLAG_SA | pkg.FLAG_SSA), -1)]:
+        with pytest.raises(pkg.PfpError) as ei:
+            ctx.bigbwt(text, **kw)
+        assert ei.value.code == code
+    with pytest.raises(pkg.PfpError) as ei:      # no trigger at all -> one phrase (bwtparse.c:244 asserts n>1)
+        ctx.bigbwt(b"ACGTACGTAC", 10, 100)
+    assert ei.value.code == -8
+    with pytest.raises(pkg.PfpError) as ei:
+        ctx.bigbwt(b"", 10, 100)
+    assert ei.value.code == -8
+    # still usable afterwards
+    assert len(ctx.bigbwt(text, 10, 100)["bwt"]) == len(text) + 1
+
+
+def test_special_byte_truncates_like_reference(O, ctx):
+    """the reference stops reading at the first byte <= 2 and builds the BWT of the prefix."""
+    text = O.gen_fasta(20000, 1, 0, 4).copy()
+    text[12345] = 1
+    got = ctx.bigbwt(text, 10, 100)
+    want = O.bigbwt(text[:12345], 10, 100)
+    assert np.array_equal(got["bwt"], want["bwt"]) and len(got["bwt"]) == 12346
+
+
+def test_mid_size_against_oracle(O, pkg, ctx):
+    """~24 MB, 8 near-identical copies: every output against the oracle."""
+    text = O.gen_fasta(3000000, 8, 0.001, 31)
+    got = ctx.bigbwt(text, 10, 100, pkg.FLAG_SSA | pkg.FLAG_ESA)
+    want = O.bigbwt(text, 10, 100, O.FLAG_SSA | O.FLAG_ESA)
+    assert np.array_equal(got["bwt"], want["bwt"])
+    assert np.array_equal(pkg.unpack5(got["ssa"]).reshape(-1, 2), want["ssa"])
+    assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
+
+
+def _check_bwt_sa_properties(text, bwt, sa_vals, rng):
+    n = len(text)
+    assert len(bwt) == n + 1
+    # BWT is a permutation of text + EOS
+    hist_t = np.bincount(text, minlength=256); hist_t[0] += 1
+    assert np.array_equal(np.bincount(bwt, minlength=256), hist_t)
+    # SA[1..n] is a permutation of 0..n-1 and BWT[i] = T[SA[i]-1]
+    sa = np.concatenate([[n], sa_vals]).astype(np.int64)
+    chk = np.zeros(n + 1, dtype=bool); chk[sa] = True
+    assert chk.all()
+    prev = np.where(sa > 0, text[np.maximum(sa - 1, 0)], 0)
+    assert np.array_equal(prev.astype(np.uint8), bwt)
+    # sampled sortedness of adjacent suffixes
+    tz = np.concatenate([text, np.zeros(1, np.uint8)])
+    for i in rng.integers(0, n, size=3000):
+        a, b = int(sa[i]), int(sa[i + 1])
+        k = 0
+        while tz[a + k] == tz[b + k]:
+            k += 1
+        assert tz[a + k] < tz[b + k]
+
+
+def test_large_properties_full_sa(O, pkg, ctx):
+    """~64 MB non-repetitive + N block (the shape of BASELINE config 2), checked through
+    size-independent properties: permutation, BWT[i]=T[SA[i]-1], sampled order."""
+    text = O.gen_fasta_fast(63000000, 1, 0, 2, n_blocks=[(20000000, 4000000), (50000000, 10000)])
+    got = ctx.bigbwt(text, 10, 100, pkg.FLAG_SA)
+    _check_bwt_sa_properties(text, got["bwt"], pkg.unpack5(got["sa"]), np.random.default_rng(1))
+    plain = ctx.bigbwt(text, 10, 100, 0)
+    assert np.array_equal(plain["bwt"], got["bwt"])
+
+
+def test_device_resident_entry_point(O, pkg, ctx):
+    import torch
+    text = O.gen_fasta(400000, 6, 0.002, 17)
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(text).to(dev)
+    bwt = torch.empty(len(text) + 1 + 16, dtype=torch.uint8, device=dev)
+    sa = torch.empty(len(text) + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    used = ctx.bigbwt_dev(t.data_ptr(), len(text), bwt.data_ptr(), sa.data_ptr(), 10, 100, pkg.FLAG_SA)
+    assert used == len(text)
+    want = O.bigbwt(text, 10, 100, O.FLAG_SA)
+    assert np.array_equal(bwt[: len(text) + 1].cpu().numpy(), want["bwt"])
+    assert np.array_equal(sa[1:].cpu().numpy().astype(np.uint64), want["sa"])
+    assert int(sa[0]) == len(text)
+
+
+def test_c_driver_end_to_end(golden, O, tmp_path):
+    """the C bigbwt binary: outputs, -k temp files, --sum, -c"""
+    c = {x["name"]: x for x in golden}["gen_small"]
+    text = make_text(c["spec"], O)
+    f = tmp_path / "t.fa"
+    f.write_bytes(text.tobytes())
+    exe = os.path.join(ROOT, "big-bwt_amd", "bigbwt")
+    out = subprocess.run([exe, "-w", "10", "-p", "100", "-s", "-e", "--sum", "-c", str(f)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "BWTs match" in out.stdout and c["runs"]["6"]["bwt_sha256"] in out.stdout
+    for ext in ("bwt", "ssa", "esa"):
+        assert sha(np.fromfile(str(f) + "." + ext, dtype=np.uint8)) == c["runs"]["6"][ext + "_sha256"]
+    assert not os.path.exists(str(f) + ".dict")
+    out = subprocess.run([exe, "-S", "-k", str(f)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert sha(np.fromfile(str(f) + ".sa", dtype=np.uint8)) == c["runs"]["1"]["sa_sha256"]
+    for ext in ("dict", "occ", "parse", "last", "sai", "ilist", "bwlast", "bwsai"):
+        assert sha(np.fromfile(str(f) + "." + ext, dtype=np.uint8)) == c["runs"]["6"][ext + "_sha256"], ext
