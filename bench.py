@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: input MB/s to a bit-exact .bwt on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|small]
+
+A "step" is one complete pass of the hot path (window scan -> phrase dedup -> dictionary suffix
+sort -> BWT of the parse -> merge) over one synthetic input that is already resident in HBM when
+the timed region starts, leaving the finished .bwt (and the SA values, for workloads that ask
+for them) in HBM.  Workload (BASELINE.json configs[1]): synthetic human-chr1-shaped FASTA,
+249e6 random ACGT bases with one 18 Mb and two 10 kb blocks of N, 60-column lines, one header,
+-w 10 -p 100, BWT only (~253 MB).  One process per GPU; for N > 1 every rank builds the BWT of
+its own text of that shape (independent objects, no data-path collective: weak scaling).
+
+Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the library's own
+stream, `cpu_baseline` is the real reference (oracle/_ref, built from the reference's sources)
+timed on this host on a bounded prefix of the same text.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6.3 TB/s
+
+WORKLOADS = {
+    # name: (G bases, copies, mutation rate, N blocks (start,len), w, p, flags, description)
+    "c2": dict(G=249_000_000, C=1, r=0.0, nblocks=[(120_000_000, 18_000_000), (30_000_000, 10_000), (200_000_000, 10_000)],
+               w=10, p=100, flags=0, desc="BASELINE configs[1]: 1x human-chr1-shaped FASTA (~253 MB), -w 10 -p 100, BWT only"),
+    "c3": dict(G=12_100_020, C=64, r=1e-3, nblocks=[], w=10, p=100, flags=6,
+               desc="BASELINE configs[2]: 64x mutated yeast-shaped FASTA (~0.79 GB), -w 10 -p 100, BWT + -s -e"),
+    "small": dict(G=6_000_000, C=4, r=1e-3, nblocks=[(1_000_000, 300_000)], w=10, p=100, flags=0,
+                  desc="reduced smoke workload (not a reportable number)"),
+}
+
+
+def make_text(dev, wl, seed):
+    """GEN-shaped synthetic FASTA built directly in HBM (SURVEY.md section 4 family; torch RNG)."""
+    G, C_, r = wl["G"], wl["C"], wl["r"]
+    assert G % 60 == 0
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    base = lut[torch.randint(0, 4, (G,), generator=gen, device=dev, dtype=torch.int64)]
+    for st, ln in wl["nblocks"]:
+        base[st:st + ln] = ord("N")
+    parts = []
+    nl = torch.full((G // 60, 1), ord("\n"), dtype=torch.uint8, device=dev)
+    for c in range(C_):
+        seq = base
+        if r > 0:
+            seq = base.clone()
+            k = int(G * r)
+            pos = torch.randint(0, G, (k,), generator=gen, device=dev)
+            seq[pos] = lut[torch.randint(0, 4, (k,), generator=gen, device=dev, dtype=torch.int64)]
+        parts.append(torch.tensor(list(b">copy%d\n" % c), dtype=torch.uint8, device=dev))
+        parts.append(torch.cat([seq.view(-1, 60), nl], dim=1).reshape(-1))
+    text = torch.cat(parts).contiguous()
+    del base, parts
+    return text
+
+
+def first_window_triggers(text, w, p, O):
+    return O.kr_window(bytes(text[:w].cpu().numpy().tobytes())) % p == 0
+
+
+def time_events_ms(ext_stream, fn, reps):
+    """average device time of fn() (which only enqueues on ext_stream) over reps launches"""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record(ext_stream)
+        fn()
+        b.record(ext_stream)
+    ext_stream.synchronize()
+    ts = [a.elapsed_time(b) for a, b in evs]
+    return float(np.mean(ts)), float(np.min(ts))
+
+
+def cpu_baseline(text_host, w, p, flags, O, sample_bytes):
+    """the real reference (newscanNT.x -> bwtparse -> pfbwtNT.x, 1 thread) on a prefix of the text"""
+    sample = text_host[:sample_bytes]
+    if O.have_ref():
+        r = O.run_ref(sample.tobytes(), w, p, flags, threads=0, want_intermediates=False)
+        secs = sum(r["seconds"].values())
+        kind, bwt = "reference", np.frombuffer(r["bwt"], dtype=np.uint8)
+        detail = {k: round(v, 3) for k, v in r["seconds"].items()}
+    else:
+        t0 = time.time()
+        bwt = O.bigbwt(sample, w, p, flags)["bwt"]
+        secs = time.time() - t0
+        kind, detail = "port", {}
+    return dict(value=round(len(sample) / secs / 1e6, 3), unit="MB/s", cores=1, kind=kind,
+                sample=f"first {len(sample)} bytes of the same text, same flags; stages s: {detail}",
+                seconds=round(secs, 3)), bwt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample-mb", type=float, default=40.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = entry.load_package()          # fails loudly if libpfpgpu.so is missing
+    wl = WORKLOADS[args.workload]
+    w, p, flags = wl["w"], wl["p"], wl["flags"]
+    O = entry.load_oracle() if rank == 0 else None
+
+    seed = 2 + 1000 * rank
+    text = make_text(dev, wl, seed)
+    if rank == 0:
+        while first_window_triggers(text, w, p, O):      # reject such inputs
+            seed += 1
+            text = make_text(dev, wl, seed)
+    n = text.numel()
+    bwt = torch.empty(n + 1 + 16, dtype=torch.uint8, device=dev)
+    sa = torch.empty(n + 1, dtype=torch.int64, device=dev) if flags else None
+    torch.cuda.synchronize()
+
+    ctx = pkg.Context(local_rank)
+
+    def step():
+        return ctx.bigbwt_dev(text.data_ptr(), n, bwt.data_ptr(), sa.data_ptr() if flags else None, w, p, flags)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tot = torch.tensor([float(n)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_bytes = float(tot.item())
+    else:
+        total_bytes = float(n)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_bytes * args.steps / elapsed / 1e6
+
+    # per-phase breakdown of one extra (untimed) profiled step
+    ctx.set_profiling(True)
+    step()
+    st = ctx.stats()
+    ctx.set_profiling(False)
+
+    # ---- correctness of what was just measured (outside the timed region)
+    hist_t = torch.bincount(text.to(torch.int64), minlength=256)
+    hist_t[0] += 1
+    hist_b = torch.bincount(bwt[: n + 1].to(torch.int64), minlength=256)
+    verified = bool(torch.equal(hist_t, hist_b))
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the scan pass's kernel K1 (hand-written window-hash kernel), HIP events on the ctx stream
+        ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
+        ctx.stage_text_dev(text.data_ptr(), n, w)
+        ne = ctx.scan_staged(p)
+        ctx.scan_k1_enqueue(p); ext.synchronize()
+        k1_ms, k1_min = time_events_ms(ext, lambda: ctx.scan_k1_enqueue(p), 20)
+        P = ne + 1
+        algo_bytes = n + 8 * P                      # B_scan = n + 8P per launch
+        achieved = algo_bytes / (k1_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel="kr_flag_kernel<10> (scan pass K1)", achieved=round(achieved, 1),
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        ms_per_launch=round(k1_ms, 4), algo_bytes_per_launch=int(algo_bytes))
+        cpu = None
+        parity_sample = None
+        if not args.no_cpu_baseline and world == 1:
+            sample_bytes = int(min(n, args.cpu_sample_mb * 1e6))
+            host = text[:sample_bytes].cpu().numpy()
+            cpu, ref_bwt = cpu_baseline(host, w, p, flags, O, sample_bytes)
+            got = ctx.bigbwt(host, w, p, 0)["bwt"]        # same sample through the HIP path: bit-exact?
+            parity_sample = bool(np.array_equal(got, ref_bwt))
+        out = {
+            "metric": "input MB/s to .bwt (bit-exact vs ref)", "value": round(value, 2), "unit": "MB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "bytes_per_gpu": n, "w": w, "p": p, "flags": flags,
+                       "phrases": st["n_phrases"], "words": st["n_words"], "dict_bytes": st["dict_size"],
+                       "parallelism": f"{world} independent texts (one per GPU)" if world > 1 else "1 GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "phases_ms": {k: round(st[k], 3) for k in ("ms_scan", "ms_phrases", "ms_sa_dict", "ms_sa_parse", "ms_merge", "ms_total")},
+            "sa_rounds": {"dict": st["sa_rounds_dict"], "parse": st["sa_rounds_parse"]},
+            "verified": {"bwt_is_permutation_of_text_plus_eos": verified, "bit_exact_vs_reference_on_cpu_sample": parity_sample},
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
