@@ -54,10 +54,8 @@ struct SuffixOrder {
   uint64_t rounds = 0;
 };
 // Suffixes of the dictionary as 0x01-terminated strings (gsacak semantics):
-// pos_word[i] = word containing position i (d for the final 0x00), wend[j] = position of
-// word j's terminator.
-void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *pos_word,
-                        const uint32_t *wend, uint64_t d, SuffixOrder &out);
+// endpos[i] = position of the terminator of the word containing i (the final 0x00 is its own word).
+void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out);
 // plain suffix array of an integer string with unique smallest last symbol (sacak_int)
 void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out);
 // plain suffix array of a byte string with s[N-1]==0 unique smallest (sacak)
@@ -65,7 +63,8 @@ void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrde
 
 // ---------------------------------------------------------------- stage 2+3 (merge.hip)
 struct DictIndex {        // per-position / per-word helper arrays over the dictionary
-  DBuf<uint32_t> pos_word;   // [dsize]
+  DBuf<uint32_t> pos_word;   // [dsize] word containing position i (d for the final 0x00)
+  DBuf<uint32_t> endpos;     // [dsize] position of that word's terminator
   DBuf<uint32_t> wend;       // [d+1] terminator position of word j (wend[d] = dsize-1)
   DBuf<uint32_t> lexrank;    // [d] 0-based lexicographic rank of word j
 };

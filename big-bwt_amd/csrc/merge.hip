@@ -31,43 +31,45 @@ __global__ void pos_word_kernel(const uint8_t *__restrict__ b, uint64_t N, const
   if (term) wend[wd] = (uint32_t)i;
   if (i == N - 1) wend[d] = (uint32_t)i;
 }
+__global__ void endpos_kernel(uint64_t N, const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ wend,
+                              uint32_t *__restrict__ endpos) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) endpos[i] = wend[pos_word[i]];
+}
 
 void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix) {
   const uint64_t N = D.dsize;
   ix.pos_word.alloc(c, N);
+  ix.endpos.alloc(c, N);
   ix.wend.alloc(c, D.d + 1);
   DBuf<uint32_t> inc(c, N);
   inclusive_count_eq_u8(c, D.bytes.p, kEndOfWord, inc.p, N);
   hipLaunchKernelGGL(pos_word_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, inc.p, ix.pos_word.p,
                      ix.wend.p, (uint32_t)D.d);
+  hipLaunchKernelGGL(endpos_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, ix.pos_word.p, ix.wend.p, ix.endpos.p);
   PFP_HIP(hipGetLastError());
 }
 
-// lexicographic rank of every word = number of full-word suffixes before it in SA(D)
-__global__ void word_start_flags_kernel(const uint8_t *__restrict__ b, uint64_t N, const uint32_t *__restrict__ sa,
-                                        uint32_t *__restrict__ flag) {
-  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N) return;
-  uint32_t i = sa[t];
-  bool start = (i == 0 || b[i - 1] == kEndOfWord) && i != N - 1;
-  flag[t] = start ? 1u : 0u;
+// Lexicographic rank of every word.  A whole word is a singleton group in SA(D) (the parse is
+// prefix free), so rank[start of word] is its slot: sorting the d words by that slot gives the
+// order std::sort produces in the reference (newscan.cpp:622-636) without touching all N slots.
+__global__ void word_slot_kernel(uint32_t d, const uint64_t *__restrict__ woff, const uint32_t *__restrict__ rank,
+                                 uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < d) { key[j] = rank[woff[j]]; val[j] = j; }
 }
-__global__ void lexrank_scatter_kernel(uint64_t N, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ flag,
-                                       const uint32_t *__restrict__ scan, const uint32_t *__restrict__ pos_word,
-                                       uint32_t *__restrict__ lexrank) {
-  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N || !flag[t]) return;
-  lexrank[pos_word[sa[t]]] = scan[t];
+__global__ void lexrank_from_order_kernel(uint32_t d, const uint32_t *__restrict__ word_sorted, uint32_t *__restrict__ lexrank) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < d) lexrank[word_sorted[r]] = r;
 }
 
 void compute_lexrank(pfp_ctx *c, const Dictionary &D, const SuffixOrder &so, DictIndex &ix) {
-  const uint64_t N = D.dsize;
-  ix.lexrank.alloc(c, D.d);
-  DBuf<uint32_t> flag(c, N), scan(c, N);
-  hipLaunchKernelGGL(word_start_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, so.sa.p, flag.p);
-  exclusive_sum_u32(c, flag.p, scan.p, N);
-  hipLaunchKernelGGL(lexrank_scatter_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.sa.p, flag.p, scan.p,
-                     ix.pos_word.p, ix.lexrank.p);
+  const uint32_t d = (uint32_t)D.d;
+  ix.lexrank.alloc(c, d);
+  DBuf<uint32_t> key(c, d), val(c, d), keyo(c, d), valo(c, d);
+  hipLaunchKernelGGL(word_slot_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, D.woff.p, so.rank.p, key.p, val.p);
+  sort_pairs_u32_u32(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
+  hipLaunchKernelGGL(lexrank_from_order_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
   PFP_HIP(hipGetLastError());
 }
 
@@ -117,40 +119,61 @@ void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t 
 
 // ------------------------------------------------------------------ stage 3: merge
 
-// per SA(D) slot: output count and the char that precedes the suffix (1 = "full word")
-__global__ void slot_info_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t d, int w,
-                                 const uint32_t *__restrict__ sa, const uint32_t *__restrict__ pos_word,
-                                 const uint32_t *__restrict__ wend, const uint32_t *__restrict__ wocc,
-                                 uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc) {
-  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N) return;
-  uint32_t i = sa[t];
+// Per dictionary POSITION, written in one streaming pass after the suffix sort: everything the
+// merge needs to know about the suffix starting there, so that the per-SLOT pass is a single
+// 16-byte gather instead of four dependent ones.
+//   x = number of BWT chars the suffix emits (occ of its word; 0 when the suffix is <= w long, pfbwt.cpp:151)
+//   y = preceding char, 1 (EndOfWord) when the suffix is a whole word (pfbwt.cpp:153)
+//   z = group head slot (equal suffixes share it)      w = word id
+__global__ void posrec_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t d, int w,
+                              const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ endpos,
+                              const uint32_t *__restrict__ rank, const uint32_t *__restrict__ wocc,
+                              uint4 *__restrict__ posrec) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
   uint32_t wd = pos_word[i];
-  bool valid = wd < d && (wend[wd] - i) > (uint32_t)w;     // pfbwt.cpp:151
-  cnt[t] = valid ? wocc[wd] : 0u;
-  pc[t] = valid ? (i == 0 ? kEndOfWord : b[i - 1]) : 0;
+  bool valid = wd < d && (endpos[i] - (uint32_t)i) > (uint32_t)w;
+  uint32_t pc = (i == 0) ? kEndOfWord : b[i - 1];
+  posrec[i] = make_uint4(valid ? wocc[wd] : 0u, valid ? pc : 0u, rank[i], wd);
 }
 
-__global__ void group_flags_kernel(uint64_t N, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ rank,
-                                   const uint32_t *__restrict__ cnt, const uint8_t *__restrict__ pc,
+// per SA(D) slot: count, preceding char (0 = emits nothing) and group head, 8 slots per thread
+__global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const uint32_t *__restrict__ sa,
+                                                          const uint4 *__restrict__ posrec,
+                                                          uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc,
+                                                          uint32_t *__restrict__ grp) {
+  uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (t0 >= N) return;
+  if (t0 + 8 <= N) {
+    uint4 s0 = *reinterpret_cast<const uint4 *>(sa + t0), s1 = *reinterpret_cast<const uint4 *>(sa + t0 + 4);
+    const uint32_t idx[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    uint4 r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) r[k] = posrec[idx[k]];
+    *reinterpret_cast<uint4 *>(cnt + t0) = make_uint4(r[0].x, r[1].x, r[2].x, r[3].x);
+    *reinterpret_cast<uint4 *>(cnt + t0 + 4) = make_uint4(r[4].x, r[5].x, r[6].x, r[7].x);
+    *reinterpret_cast<uint4 *>(grp + t0) = make_uint4(r[0].z, r[1].z, r[2].z, r[3].z);
+    *reinterpret_cast<uint4 *>(grp + t0 + 4) = make_uint4(r[4].z, r[5].z, r[6].z, r[7].z);
+    uint32_t lo = r[0].y | (r[1].y << 8) | (r[2].y << 16) | (r[3].y << 24);
+    uint32_t hi = r[4].y | (r[5].y << 8) | (r[6].y << 16) | (r[7].y << 24);
+    *reinterpret_cast<uint2 *>(pc + t0) = make_uint2(lo, hi);
+  } else {
+    for (uint64_t t = t0; t < N; t++) { uint4 r = posrec[sa[t]]; cnt[t] = r.x; pc[t] = (uint8_t)r.y; grp[t] = r.z; }
+  }
+}
+
+// a group is "hard" when its members disagree on the preceding char (pfbwt.cpp:524-536), or, with
+// SA output, whenever it has more than one member (pfbwt.cpp:568, 612)
+__global__ void group_flags_kernel(uint64_t N, const uint32_t *__restrict__ grp, const uint8_t *__restrict__ pc,
                                    int any_multi_is_hard, uint8_t *__restrict__ hard) {
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N || cnt[t] == 0) return;
-  uint32_t g = rank[sa[t]];
+  if (t >= N || pc[t] == 0) return;
+  uint32_t g = grp[t];
   if (g == t) return;
   if (any_multi_is_hard || pc[t] != pc[g]) hard[g] = 1;
 }
 
 enum : uint8_t { CLS_NONE = 0, CLS_FILL = 1, CLS_FULL = 2, CLS_HARD = 3 };
-__global__ void classify_kernel(uint64_t N, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ rank,
-                                const uint32_t *__restrict__ cnt, const uint8_t *__restrict__ pc,
-                                const uint8_t *__restrict__ hard, uint8_t *__restrict__ cls) {
-  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N) return;
-  uint8_t k = CLS_NONE;
-  if (cnt[t]) k = (pc[t] == kEndOfWord) ? CLS_FULL : (hard[rank[sa[t]]] ? CLS_HARD : CLS_FILL);
-  cls[t] = k;
-}
 
 __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank, const uint32_t *__restrict__ istart_lex,
                                uint32_t *__restrict__ wistart) {
@@ -160,57 +183,75 @@ __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank,
 
 struct MergeArgs {
   uint64_t N, n_out; uint32_t d; int w; int want_sa;
-  const uint8_t *b; const uint32_t *sa, *rank, *pos_word, *wend, *wocc, *wistart;
-  const uint32_t *cnt; const uint8_t *pc, *cls; const uint64_t *off;
+  const uint32_t *sa, *endpos, *wocc, *wistart, *grp;
+  const uint4 *posrec;
+  const uint8_t *pc, *hard; const uint64_t *off;
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
   uint8_t *bwt; uint64_t *out_sa;
 };
 
 __device__ __forceinline__ uint8_t fix_char(uint8_t ch) { return ch == kDollar ? 0 : ch; }  // pfbwt.cpp:126
 
-// largest t in [0,N) with off[t] <= x  (off has N+1 entries, off[N] = total > x)
-__device__ __forceinline__ uint64_t find_slot(const uint64_t *__restrict__ off, uint64_t N, uint64_t x) {
-  uint64_t lo = 0, hi = N;          // invariant: off[lo] <= x < off[hi]
-  while (hi - lo > 1) {
-    uint64_t mid = (lo + hi) >> 1;
-    if (off[mid] <= x) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
-// output-centric expansion of fill and full-word entries: 16 BWT bytes per thread
+// Expansion of fill and full-word entries.  One workgroup owns kSlots consecutive SA(D) slots,
+// i.e. one contiguous range of the output; slot offsets, classes and chars are staged in LDS and
+// every thread then produces 16 consecutive BWT bytes per iteration (binary search in LDS for the
+// first one, forward walk for the rest) and stores them with one 16-byte store.
+constexpr int kSlots = 2048;
 __global__ __launch_bounds__(256) void expand_kernel(MergeArgs a) {
-  uint64_t x0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
-  if (x0 >= a.n_out) return;
-  uint64_t t = find_slot(a.off, a.N, x0);
-  uint32_t r[4] = {0, 0, 0, 0};
-  uint64_t next_off = a.off[t + 1];
-  uint64_t base = a.off[t];
-  int nb = (a.n_out - x0) >= 16 ? 16 : (int)(a.n_out - x0);
-  for (int k = 0; k < nb; k++) {
-    uint64_t x = x0 + k;
-    while (x >= next_off) { t++; base = next_off; next_off = a.off[t + 1]; }
-    uint8_t cl = a.cls[t];
-    uint8_t ch = 0;
-    if (cl == CLS_FILL) {
-      ch = fix_char(a.pc[t]);
-      if (a.want_sa) {
-        uint32_t i = a.sa[t];
-        uint32_t wd = a.pos_word[i];
-        uint64_t pos = a.ilist[a.wistart[wd] + (uint32_t)(x - base)];
-        a.out_sa[x] = a.bwsai[pos] - (uint64_t)(a.wend[wd] - i);
-      }
-    } else if (cl == CLS_FULL) {
-      uint32_t i = a.sa[t];
-      uint32_t wd = a.pos_word[i];
-      uint64_t pos = a.ilist[a.wistart[wd] + (uint32_t)(x - base)];
-      ch = a.bwlast[pos];
-      if (a.want_sa) a.out_sa[x] = (x == 0) ? a.n_out - 1 : a.bwsai[pos] - (uint64_t)(a.wend[wd] - i);
-    }
-    r[k >> 2] |= (uint32_t)ch << (8 * (k & 3));
+  __shared__ uint64_t loff[kSlots + 1];
+  __shared__ uint8_t lpc[kSlots], lcls[kSlots];
+  const uint64_t t0 = (uint64_t)blockIdx.x * kSlots;
+  const int ns = (a.N - t0) >= (uint64_t)kSlots ? kSlots : (int)(a.N - t0);
+  const uint64_t base = a.off[t0];
+  for (int s = threadIdx.x; s <= ns; s += 256) loff[s] = a.off[t0 + s] - base;
+  for (int s = threadIdx.x; s < ns; s += 256) {
+    uint8_t ch = a.pc[t0 + s];
+    lpc[s] = ch;
+    lcls[s] = ch == 0 ? CLS_NONE : (ch == kEndOfWord ? CLS_FULL : (a.hard[a.grp[t0 + s]] ? CLS_HARD : CLS_FILL));
   }
-  if (nb == 16) *reinterpret_cast<uint4 *>(a.bwt + x0) = make_uint4(r[0], r[1], r[2], r[3]);
-  else for (int k = 0; k < nb; k++) a.bwt[x0 + k] = (uint8_t)(r[k >> 2] >> (8 * (k & 3)));
+  __syncthreads();
+  const uint64_t L = loff[ns];
+  for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < L; x0 += 256 * 16) {
+    int lo = 0, hi = ns;                    // loff[lo] <= x0 < loff[hi]
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (loff[mid] <= x0) lo = mid; else hi = mid; }
+    int s = lo;
+    uint64_t nxt = loff[s + 1];
+    const int nb = (L - x0) >= 16 ? 16 : (int)(L - x0);
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k < nb) {
+        const uint64_t x = x0 + k;
+        while (x >= nxt) { s++; nxt = loff[s + 1]; }
+        const uint8_t cl = lcls[s];
+        uint32_t ch = 0;
+        if (cl == CLS_FILL) {
+          ch = fix_char(lpc[s]);
+          if (a.want_sa) {
+            const uint32_t i = a.sa[t0 + s];
+            const uint32_t wd = a.posrec[i].w;
+            const uint64_t pos = a.ilist[a.wistart[wd] + (uint32_t)(x - loff[s])];
+            a.out_sa[base + x] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
+          }
+        } else if (cl == CLS_FULL) {
+          const uint32_t i = a.sa[t0 + s];
+          const uint32_t wd = a.posrec[i].w;
+          const uint64_t pos = a.ilist[a.wistart[wd] + (uint32_t)(x - loff[s])];
+          ch = a.bwlast[pos];
+          if (a.want_sa) a.out_sa[base + x] = (base + x == 0) ? a.n_out - 1 : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
+        }
+        const uint32_t sh = (uint32_t)ch << (8 * (k & 3));
+        if (k < 4) r0 |= sh; else if (k < 8) r1 |= sh; else if (k < 12) r2 |= sh; else r3 |= sh;
+      }
+    }
+    uint8_t *dst = a.bwt + base + x0;
+    if (nb == 16) st16u(dst, make_uint4(r0, r1, r2, r3));
+    else {
+      const uint32_t rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+      for (int k = 0; k < 16; k++) if (k < nb) dst[k] = (uint8_t)(rr[k >> 2] >> (8 * (k & 3)));
+    }
+  }
 }
 
 // one wave per hard group: rank every (member, occurrence) by its BWT(P) position
@@ -220,11 +261,11 @@ __global__ __launch_bounds__(64) void hard_groups_kernel(MergeArgs a, const uint
   if (gi >= nh) return;
   const uint64_t g = hlist[gi];
   const int lane = threadIdx.x;
-  // member count: consecutive slots whose suffix has rank g
+  // member count: consecutive slots of group g
   uint32_t k = 0;
   for (;;) {
     uint64_t t = g + k + lane;
-    bool in = t < a.N && a.rank[a.sa[t]] == (uint32_t)g;
+    bool in = t < a.N && a.grp[t] == (uint32_t)g && a.pc[t] != 0;
     unsigned long long m = __ballot(in);
     if (m == ~0ULL) { k += 64; continue; }
     k += __ffsll((long long)~m) - 1;
@@ -234,18 +275,17 @@ __global__ __launch_bounds__(64) void hard_groups_kernel(MergeArgs a, const uint
   const uint64_t C = a.off[g + k] - base;
   if (lane == 0) atomicAdd(hard_chars, (unsigned long long)C);
   for (uint64_t e = lane; e < C; e += 64) {
-    // member holding element e
-    uint32_t lo = 0, hi = k;
+    uint32_t lo = 0, hi = k;                // member holding element e
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (a.off[g + mid] - base <= e) lo = mid; else hi = mid; }
     const uint32_t m = lo;
     const uint32_t j = (uint32_t)(e - (a.off[g + m] - base));
     const uint32_t i = a.sa[g + m];
-    const uint32_t wd = a.pos_word[i];
+    const uint32_t wd = a.posrec[i].w;
     const uint32_t pos = a.ilist[a.wistart[wd] + j];
     uint64_t r = j;
     for (uint32_t m2 = 0; m2 < k; m2++) {
       if (m2 == m) continue;
-      const uint32_t wd2 = a.pos_word[a.sa[g + m2]];
+      const uint32_t wd2 = a.posrec[a.sa[g + m2]].w;
       const uint32_t *lst = a.ilist + a.wistart[wd2];
       uint32_t l2 = 0, h2 = a.wocc[wd2];         // # entries < pos
       while (l2 < h2) { uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
@@ -253,7 +293,7 @@ __global__ __launch_bounds__(64) void hard_groups_kernel(MergeArgs a, const uint
     }
     const uint64_t x = base + r;
     a.bwt[x] = fix_char(a.pc[g + m]);
-    if (a.want_sa) a.out_sa[x] = a.bwsai[pos] - (uint64_t)(a.wend[wd] - i);
+    if (a.want_sa) a.out_sa[x] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
   }
 }
 
@@ -266,18 +306,18 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   DBuf<uint32_t> istart_lex(c, d), wistart(c, d);
   exclusive_sum_u32(c, occ_lex, istart_lex.p, d);
   hipLaunchKernelGGL(wistart_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, wistart.p);
-  DBuf<uint32_t> cnt(c, N + 1);
-  DBuf<uint8_t> pc(c, N), hard(c, N), cls(c, N);
+  DBuf<uint4> posrec(c, N);
+  DBuf<uint32_t> cnt(c, N + 8), grp(c, N + 8);
+  DBuf<uint8_t> pc(c, N + 8), hard(c, N);
   DBuf<uint64_t> off(c, N + 1);
   PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream));
   hard.zero();
-  hipLaunchKernelGGL(slot_info_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, d, w, so.sa.p,
-                     ix.pos_word.p, ix.wend.p, D.wocc.p, cnt.p, pc.p);
+  hipLaunchKernelGGL(posrec_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, d, w, ix.pos_word.p,
+                     ix.endpos.p, so.rank.p, D.wocc.p, posrec.p);
+  hipLaunchKernelGGL(slot_gather_kernel, dim3(cdiv(cdiv64(N, 8), 256)), dim3(256), 0, c->stream, N, so.sa.p, posrec.p,
+                     cnt.p, pc.p, grp.p);
   exclusive_sum_u32_u64(c, cnt.p, off.p, N + 1);
-  hipLaunchKernelGGL(group_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.sa.p, so.rank.p, cnt.p, pc.p,
-                     flags ? 1 : 0, hard.p);
-  hipLaunchKernelGGL(classify_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.sa.p, so.rank.p, cnt.p, pc.p,
-                     hard.p, cls.p);
+  hipLaunchKernelGGL(group_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, grp.p, pc.p, flags ? 1 : 0, hard.p);
   DBuf<uint32_t> hlist(c, N), nh_d(c, 1);
   select_index_u32(c, hard.p, hlist.p, nh_d.p, N);
   PFP_HIP(hipMemcpyAsync(c->h_scalars, off.p + N, 8, hipMemcpyDeviceToHost, c->stream));
@@ -291,10 +331,10 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   out.n_out = n_out;
   MergeArgs a{};
   a.N = N; a.n_out = n_out; a.d = d; a.w = w; a.want_sa = flags ? 1 : 0;
-  a.b = D.bytes.p; a.sa = so.sa.p; a.rank = so.rank.p; a.pos_word = ix.pos_word.p; a.wend = ix.wend.p;
-  a.wocc = D.wocc.p; a.wistart = wistart.p; a.cnt = cnt.p; a.pc = pc.p; a.cls = cls.p; a.off = off.p;
+  a.sa = so.sa.p; a.endpos = ix.endpos.p; a.wocc = D.wocc.p; a.wistart = wistart.p; a.grp = grp.p;
+  a.posrec = posrec.p; a.pc = pc.p; a.hard = hard.p; a.off = off.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p; a.bwt = out.d_bwt; a.out_sa = out.d_sa;
-  hipLaunchKernelGGL(expand_kernel, dim3(cdiv(cdiv64(n_out, 16), 256)), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(expand_kernel, dim3(cdiv(N, kSlots)), dim3(256), 0, c->stream, a);
   out.hard_groups = nh;
   if (nh) {
     DBuf<unsigned long long> hc(c, 1);

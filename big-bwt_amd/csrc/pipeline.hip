@@ -117,7 +117,7 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
   }
   {
     PhaseTimer t(c, &st.ms_sa_dict);
-    sort_dict_suffixes(c, ch.D.bytes.p, ch.D.dsize, ch.ix.pos_word.p, ch.ix.wend.p, ch.D.d, ch.so);
+    sort_dict_suffixes(c, ch.D.bytes.p, ch.D.dsize, ch.ix.endpos.p, ch.so);
     if (c->debug) validate_suffix_order(c, ch.D.bytes.p, ch.so, true, "dict SA");
     compute_lexrank(c, ch.D, ch.so, ch.ix);
     if (c->debug) validate_lexrank(c, ch.D, ch.ix);
@@ -421,7 +421,7 @@ int pfp_gsacak(pfp_ctx *c, const uint8_t *s, uint32_t *SA, uint64_t n) {
   PFP_HIP(hipSetDevice(c->device));
   Dictionary D; DictIndex ix; SuffixOrder so;
   dictionary_from_host(c, s, n, D, ix);
-  sort_dict_suffixes(c, D.bytes.p, n, ix.pos_word.p, ix.wend.p, D.d, so);
+  sort_dict_suffixes(c, D.bytes.p, n, ix.endpos.p, so);
   d2h(c, SA, so.sa.p, n);
   sync(c);
   return PFP_OK;
@@ -495,7 +495,7 @@ int pfp_merge(pfp_ctx *c, const uint8_t *dict, uint64_t dict_size, const uint32_
   D.wocc.alloc(c, D.d);
   h2d(c, D.wocc.p, occ, D.d);
   if (c->debug) validate_index(c, D, ix);
-  sort_dict_suffixes(c, D.bytes.p, D.dsize, ix.pos_word.p, ix.wend.p, D.d, so);
+  sort_dict_suffixes(c, D.bytes.p, D.dsize, ix.endpos.p, so);
   if (c->debug) validate_suffix_order(c, D.bytes.p, so, true, "dict SA");
   compute_lexrank(c, D, so, ix);
   if (c->debug) validate_lexrank(c, D, ix);

@@ -17,34 +17,80 @@
 #include "kernels.hpp"
 #include "prims.hpp"
 #include "devutil.hpp"
+#include <algorithm>
 
 namespace pfp {
 
 enum : int { MODE_DICT = 0, MODE_PLAIN = 1 };
 
 struct SufGeom {
-  int mode; uint64_t N; const uint32_t *pos_word; const uint32_t *wend;
+  int mode; uint64_t N; const uint32_t *endpos;   // endpos[i] = position of the terminator of i's word
 };
 // length of the suffix string starting at i, terminator included
 __device__ __forceinline__ uint64_t suf_len(const SufGeom &g, uint32_t i) {
-  if (g.mode == MODE_DICT) return (uint64_t)g.wend[g.pos_word[i]] - i + 1;
+  if (g.mode == MODE_DICT) return (uint64_t)g.endpos[i] - i + 1;
   return g.N - i;
 }
 
-// first 8 bytes of every dictionary suffix, big-endian, zero after the word terminator
-__global__ void init_keys_dict_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
-                                      uint32_t *__restrict__ val) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Alphabet-packed initial keys.  The bytes that occur in the dictionary are renumbered densely
+// (0 = past-the-terminator pad, 1 = the 0x01 terminator, 2.. = the other bytes in byte order) and
+// the first `cpk` = 64/bits characters of every suffix are packed into one 64-bit key, first
+// character in the most significant field.  For FASTA-like alphabets (<= 14 distinct bytes) that
+// is 16 characters per key, so the first device-wide sort already orders 16-character prefixes
+// and one whole doubling round over all N suffixes disappears.
+struct KeyPack {
+  int bits, cpk;
+  uint64_t ones, highs;     // 1 in the lowest / highest bit of each of the cpk fields
+  uint8_t lut[256];
+};
+
+__global__ __launch_bounds__(256) void byte_presence_kernel(const uint8_t *__restrict__ s, uint64_t N,
+                                                            uint32_t *__restrict__ present /*[8]*/) {
+  __shared__ uint32_t m[8];
+  if (threadIdx.x < 8) m[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; i < N; i += (uint64_t)gridDim.x * 256 * 16) {
+    uint4 v = *reinterpret_cast<const uint4 *>(s + i);     // buffer is zero padded past N
+    uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        uint32_t c = (w4[q] >> (8 * b)) & 0xff;
+#pragma unroll
+        for (int k = 0; k < 8; k++) loc[k] |= ((c >> 5) == (uint32_t)k) ? (1u << (c & 31)) : 0u;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) if (loc[k]) atomicOr(&m[k], loc[k]);
+  __syncthreads();
+  if (threadIdx.x < 8 && m[threadIdx.x]) atomicOr(&present[threadIdx.x], m[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyPack kp,
+                                                               uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+  __shared__ uint8_t lut[256];
+  lut[threadIdx.x] = kp.lut[threadIdx.x];
+  __syncthreads();
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  uint64_t k = __builtin_bswap64(ld8u(s + i));
-  uint64_t v = k ^ 0x0101010101010101ULL;
-  uint64_t z = ~(((v & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | v | 0x7F7F7F7F7F7F7F7FULL);
-  if (z) {
-    int idx = __clzll((long long)z) >> 3;          // first terminator byte
-    k &= ~0ULL << (56 - 8 * idx);
+  uint4 a = ld16u(s + i), b = ld16u(s + i + 16);
+  const uint32_t w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint64_t k = 0;
+  bool live = true;
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    if (j < kp.cpk) {
+      uint32_t c = (w8[j >> 2] >> (8 * (j & 3))) & 0xff;
+      uint32_t code = live ? lut[c] : 0u;
+      k = (k << kp.bits) | code;
+      if (c <= kEndOfWord) live = false;
+    }
   }
   key[i] = k; val[i] = (uint32_t)i;
 }
+
 __global__ void init_keys_bytes_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
                                        uint32_t *__restrict__ val) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,21 +134,29 @@ __global__ void heads_kernel(uint64_t m, const uint64_t *__restrict__ key, const
 
 // write the refined order back and decide which suffixes stay unresolved.
 // sorted_len = prefix length that is sorted after this round.
+// Round 0 (key0 != nullptr) decides "whole string inside the sorted prefix" from the packed key
+// itself (some field holds the terminator code 1): no gather.
 __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, const uint32_t *__restrict__ aslot,
                                   const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead,
-                                  const uint8_t *__restrict__ hd, uint32_t *__restrict__ sa,
-                                  uint32_t *__restrict__ rank, uint8_t *__restrict__ keep) {
+                                  const uint8_t *__restrict__ hd, const uint64_t *__restrict__ key0, uint64_t ones,
+                                  uint64_t highs, uint32_t *__restrict__ sa, uint32_t *__restrict__ rank,
+                                  uint8_t *__restrict__ keep) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   uint32_t i = val[a];
   sa[aslot[a]] = i;
   rank[i] = newhead[a];
   bool single = hd[a] && (a + 1 == m || hd[a + 1]);
-  bool fin = (g.mode == MODE_DICT) && suf_len(g, i) <= sorted_len;
+  bool fin = false;
+  if (!single && g.mode == MODE_DICT) {
+    if (key0) { uint64_t v = key0[a] ^ ones; fin = ((v - ones) & ~v & highs) != 0; }
+    else fin = suf_len(g, i) <= sorted_len;
+  }
   keep[a] = (!single && !fin) ? 1 : 0;
 }
 
-static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> &val, uint64_t h0, SuffixOrder &out) {
+static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> &val, uint64_t h0, SuffixOrder &out,
+                     int key0_bits = 64, uint64_t ones = 0, uint64_t highs = 0) {
   // precondition: key/val hold the initial (prefix key, position) pairs for all N positions
   const uint64_t N = g.N;
   const int TB = 256;
@@ -111,16 +165,20 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   DBuf<uint64_t> keyo(c, N);
   DBuf<uint32_t> valo(c, N), aslot(c, N), aslot2(c, N), hv(c, N), newhead(c, N), cnt(c, 1);
   DBuf<uint8_t> hd(c, N + 1), keep(c, N);
-  sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, N, 0, 64);
+  sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, N, 0, key0_bits);
   hipLaunchKernelGGL(iota32_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, aslot.p, N);
   uint64_t m = N, h = h0;
   out.rounds = 0;
+  bool first = true;
   const int keybits = 32 + bits_for(N);
   for (;;) {
     hipLaunchKernelGGL(heads_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p);
     inclusive_max_u32(c, hv.p, newhead.p, m);
+    const bool round0 = first && ones != 0;
+    first = false;
     hipLaunchKernelGGL(write_back_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p,
-                       newhead.p, hd.p, out.sa.p, out.rank.p, keep.p);
+                       newhead.p, hd.p, round0 ? keyo.p : (const uint64_t *)nullptr, ones, highs, out.sa.p,
+                       out.rank.p, keep.p);
     select_flagged_u32(c, aslot.p, keep.p, aslot2.p, cnt.p, m);
     PFP_HIP(hipGetLastError());
     uint32_t m2 = read_scalar(c, cnt.p);
@@ -136,20 +194,37 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   }
 }
 
-void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *pos_word, const uint32_t *wend,
-                        uint64_t d, SuffixOrder &out) {
-  (void)d;
+void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out) {
   PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
-  SufGeom g{MODE_DICT, N, pos_word, wend};
+  SufGeom g{MODE_DICT, N, endpos};
+  // which byte values occur -> dense codes
+  DBuf<uint32_t> present(c, 8);
+  present.zero();
+  hipLaunchKernelGGL(byte_presence_kernel, dim3(std::min<uint64_t>(cdiv64(N, 4096), (uint64_t)c->n_cu * 8)), dim3(256), 0,
+                     c->stream, bytes, N, present.p);
+  uint32_t hp[8];
+  PFP_HIP(hipMemcpyAsync(c->h_scalars, present.p, 32, hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  memcpy(hp, c->h_scalars, 32);
+  KeyPack kp{};
+  int code = 2;
+  for (int b = 0; b < 256; b++) {
+    bool on = (hp[b >> 5] >> (b & 31)) & 1u;
+    kp.lut[b] = b == 0 ? 0 : (b == 1 ? 1 : (on ? (uint8_t)code++ : 0));
+  }
+  PFP_REQUIRE(code <= 256, PFP_EFORMAT, "alphabet overflow");
+  kp.bits = bits_for((uint64_t)(code - 1));
+  kp.cpk = std::min(64 / kp.bits, 32);
+  for (int f = 0; f < kp.cpk; f++) { kp.ones |= 1ull << (f * kp.bits); kp.highs |= 1ull << (f * kp.bits + kp.bits - 1); }
   DBuf<uint64_t> key(c, N);
   DBuf<uint32_t> val(c, N);
-  hipLaunchKernelGGL(init_keys_dict_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, key.p, val.p);
-  doubling(c, g, key, val, 8, out);
+  hipLaunchKernelGGL(init_keys_packed_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kp, key.p, val.p);
+  doubling(c, g, key, val, (uint64_t)kp.cpk, out, kp.bits * kp.cpk, kp.ones, kp.highs);
 }
 
 void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrder &out) {
   PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "text too large for 32-bit suffix indices");
-  SufGeom g{MODE_PLAIN, N, nullptr, nullptr};
+  SufGeom g{MODE_PLAIN, N, nullptr};
   DBuf<uint64_t> key(c, N);
   DBuf<uint32_t> val(c, N);
   hipLaunchKernelGGL(init_keys_bytes_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, key.p, val.p);
@@ -158,7 +233,7 @@ void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrde
 
 void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out) {
   PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "parse too large for 32-bit suffix indices");
-  SufGeom g{MODE_PLAIN, N, nullptr, nullptr};
+  SufGeom g{MODE_PLAIN, N, nullptr};
   DBuf<uint64_t> key(c, N);
   DBuf<uint32_t> val(c, N);
   hipLaunchKernelGGL(init_keys_int_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, sym, N, key.p, val.p);

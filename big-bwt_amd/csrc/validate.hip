@@ -49,6 +49,8 @@ void validate_index(pfp_ctx *c, const Dictionary &D, const DictIndex &ix) {
   auto b = fetch(c, D.bytes.p, D.dsize);
   auto pw = fetch(c, ix.pos_word.p, D.dsize);
   auto we = fetch(c, ix.wend.p, D.d + 1);
+  auto ep = fetch(c, ix.endpos.p, D.dsize);
+  for (uint64_t i = 0; i < D.dsize; i++) if (pw[i] > D.d || ep[i] != we[pw[i]]) VFAIL("index: endpos wrong at " + std::to_string(i));
   uint32_t wd = 0;
   for (uint64_t i = 0; i < D.dsize; i++) {
     if (pw[i] != wd) VFAIL("index: pos_word wrong at " + std::to_string(i));
