@@ -94,6 +94,7 @@ struct pfp_ctx {
   int device = 0;
   pfp_pool pool;
   bool debug = false;             // PFP_DEBUG=1: validate every intermediate on the host
+  uint64_t max_phrase = 1u << 15; // fused chain: split phrases longer than this with extra triggers (0 = off)
   hipStream_t stream = nullptr;
   std::string err;
   bool profiling = false;

@@ -19,12 +19,21 @@ struct StagedText {
 };
 
 // ---------------------------------------------------------------- stage 1a (scan.hip)
-struct KRParams { uint32_t negpw, pinv, pshift, plimit; };
+struct KRParams {
+  static constexpr uint32_t kMaxExtra = 32;
+  uint32_t negpw, pinv, pshift, plimit;
+  uint32_t nextra;            // extra trigger hashes (fused chain only), 0 in the reference-exact scan
+  uint64_t bloom;             // bit (h & 63) set for every extra hash
+  uint32_t extra[kMaxExtra];
+};
 KRParams make_kr_params(int w, uint64_t p);
 void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p, uint16_t *flags16,
-                uint32_t *block_counts, unsigned long long *first_bad);
+                uint32_t *block_counts, unsigned long long *first_bad, const KRParams *kp_override = nullptr);
 uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, DBuf<uint64_t> &d_ends,
-                   uint64_t *n_used);
+                   uint64_t *n_used, const KRParams *kp_override = nullptr);
+// fused chain: reference triggers plus a few extra window hashes that split phrases longer than max_phrase
+uint64_t scan_text_adaptive(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, uint64_t max_phrase,
+                            DBuf<uint64_t> &d_ends, uint64_t *n_used, uint32_t *n_extra);
 
 // ---------------------------------------------------------------- stage 1b (phrase.hip)
 // Distinct phrases (the dictionary) in first-occurrence order plus the parse as word ids.

@@ -140,8 +140,9 @@ __global__ void posrec_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_
 // per SA(D) slot: count, preceding char (0 = emits nothing) and group head, 8 slots per thread
 __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const uint32_t *__restrict__ sa,
                                                           const uint4 *__restrict__ posrec,
+                                                          const uint32_t *__restrict__ wistart,
                                                           uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc,
-                                                          uint32_t *__restrict__ grp) {
+                                                          uint32_t *__restrict__ grp, uint32_t *__restrict__ ist) {
   uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
   if (t0 >= N) return;
   if (t0 + 8 <= N) {
@@ -157,8 +158,16 @@ __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const uint
     uint32_t lo = r[0].y | (r[1].y << 8) | (r[2].y << 16) | (r[3].y << 24);
     uint32_t hi = r[4].y | (r[5].y << 8) | (r[6].y << 16) | (r[7].y << 24);
     *reinterpret_cast<uint2 *>(pc + t0) = make_uint2(lo, hi);
+    uint32_t is[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) is[k] = r[k].y ? wistart[r[k].w] : 0u;
+    *reinterpret_cast<uint4 *>(ist + t0) = make_uint4(is[0], is[1], is[2], is[3]);
+    *reinterpret_cast<uint4 *>(ist + t0 + 4) = make_uint4(is[4], is[5], is[6], is[7]);
   } else {
-    for (uint64_t t = t0; t < N; t++) { uint4 r = posrec[sa[t]]; cnt[t] = r.x; pc[t] = (uint8_t)r.y; grp[t] = r.z; }
+    for (uint64_t t = t0; t < N; t++) {
+      uint4 r = posrec[sa[t]];
+      cnt[t] = r.x; pc[t] = (uint8_t)r.y; grp[t] = r.z; ist[t] = r.y ? wistart[r.w] : 0u;
+    }
   }
 }
 
@@ -183,8 +192,7 @@ __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank,
 
 struct MergeArgs {
   uint64_t N, n_out; uint32_t d; int w; int want_sa;
-  const uint32_t *sa, *endpos, *wocc, *wistart, *grp;
-  const uint4 *posrec;
+  const uint32_t *sa, *endpos, *grp, *ist;
   const uint8_t *pc, *hard; const uint64_t *off;
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
   uint8_t *bwt; uint64_t *out_sa;
@@ -192,22 +200,31 @@ struct MergeArgs {
 
 __device__ __forceinline__ uint8_t fix_char(uint8_t ch) { return ch == kDollar ? 0 : ch; }  // pfbwt.cpp:126
 
-// Expansion of fill and full-word entries.  One workgroup owns kSlots consecutive SA(D) slots,
-// i.e. one contiguous range of the output; slot offsets, classes and chars are staged in LDS and
-// every thread then produces 16 consecutive BWT bytes per iteration (binary search in LDS for the
-// first one, forward walk for the rest) and stores them with one 16-byte store.
+// Expansion.  One workgroup owns kSlots consecutive SA(D) slots, i.e. one contiguous range of
+// the output; slot offsets, classes and chars are staged in LDS and every thread then produces 16
+// consecutive BWT bytes per iteration (binary search in LDS for the first one, forward walk for
+// the rest) and stores them with one 16-byte store.
+//   fill entry      : the preceding char, occ times                       (pfbwt.cpp:527-533)
+//   full-word entry : bwlast[ilist[..]] per occurrence                    (pfbwt.cpp:153-197)
+//   hard entry      : each occurrence is ranked among all occurrences of all members of its group
+//                     by BWT(P) position - own index + lower_bound in every other member's
+//                     inverted list - and written to that slot of the group's range: the
+//                     data-parallel form of the reference's heap merge (pfbwt.cpp:537-556).
 constexpr int kSlots = 2048;
-__global__ __launch_bounds__(256) void expand_kernel(MergeArgs a) {
+__global__ __launch_bounds__(256) void expand_kernel(MergeArgs a, unsigned long long *__restrict__ stats) {
   __shared__ uint64_t loff[kSlots + 1];
   __shared__ uint8_t lpc[kSlots], lcls[kSlots];
   const uint64_t t0 = (uint64_t)blockIdx.x * kSlots;
   const int ns = (a.N - t0) >= (uint64_t)kSlots ? kSlots : (int)(a.N - t0);
   const uint64_t base = a.off[t0];
+  unsigned long long my_hard = 0, my_groups = 0;
   for (int s = threadIdx.x; s <= ns; s += 256) loff[s] = a.off[t0 + s] - base;
   for (int s = threadIdx.x; s < ns; s += 256) {
     uint8_t ch = a.pc[t0 + s];
     lpc[s] = ch;
-    lcls[s] = ch == 0 ? CLS_NONE : (ch == kEndOfWord ? CLS_FULL : (a.hard[a.grp[t0 + s]] ? CLS_HARD : CLS_FILL));
+    uint8_t cl = ch == 0 ? CLS_NONE : (ch == kEndOfWord ? CLS_FULL : (a.hard[a.grp[t0 + s]] ? CLS_HARD : CLS_FILL));
+    lcls[s] = cl;
+    if (cl == CLS_HARD && a.grp[t0 + s] == t0 + s) my_groups++;
   }
   __syncthreads();
   const uint64_t L = loff[ns];
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(256) void expand_kernel(MergeArgs a) {
     int s = lo;
     uint64_t nxt = loff[s + 1];
     const int nb = (L - x0) >= 16 ? 16 : (int)(L - x0);
-    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, hardmask = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       if (k < nb) {
@@ -229,72 +246,50 @@ __global__ __launch_bounds__(256) void expand_kernel(MergeArgs a) {
           ch = fix_char(lpc[s]);
           if (a.want_sa) {
             const uint32_t i = a.sa[t0 + s];
-            const uint32_t wd = a.posrec[i].w;
-            const uint64_t pos = a.ilist[a.wistart[wd] + (uint32_t)(x - loff[s])];
+            const uint64_t pos = a.ilist[a.ist[t0 + s] + (uint32_t)(x - loff[s])];
             a.out_sa[base + x] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
           }
         } else if (cl == CLS_FULL) {
-          const uint32_t i = a.sa[t0 + s];
-          const uint32_t wd = a.posrec[i].w;
-          const uint64_t pos = a.ilist[a.wistart[wd] + (uint32_t)(x - loff[s])];
+          const uint64_t pos = a.ilist[a.ist[t0 + s] + (uint32_t)(x - loff[s])];
           ch = a.bwlast[pos];
-          if (a.want_sa) a.out_sa[base + x] = (base + x == 0) ? a.n_out - 1 : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
+          if (a.want_sa) {
+            const uint32_t i = a.sa[t0 + s];
+            a.out_sa[base + x] = (base + x == 0) ? a.n_out - 1 : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
+          }
+        } else if (cl == CLS_HARD) {
+          hardmask |= 1u << k;
+          my_hard++;
+          const uint64_t t = t0 + s;
+          const uint64_t g = a.grp[t];
+          const uint32_t j = (uint32_t)(x - loff[s]);
+          const uint32_t pos = a.ilist[a.ist[t] + j];
+          uint64_t r = j;
+          for (uint64_t t2 = g; t2 < a.N && a.grp[t2] == (uint32_t)g && a.pc[t2] != 0; t2++) {
+            if (t2 == t) continue;
+            const uint32_t *lst = a.ilist + a.ist[t2];
+            uint32_t l2 = 0, h2 = (uint32_t)(a.off[t2 + 1] - a.off[t2]);      // # entries < pos
+            while (l2 < h2) { uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
+            r += l2;
+          }
+          const uint64_t xo = a.off[g] + r;
+          a.bwt[xo] = fix_char(lpc[s]);
+          if (a.want_sa) { const uint32_t i = a.sa[t]; a.out_sa[xo] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i); }
         }
         const uint32_t sh = (uint32_t)ch << (8 * (k & 3));
         if (k < 4) r0 |= sh; else if (k < 8) r1 |= sh; else if (k < 12) r2 |= sh; else r3 |= sh;
       }
     }
     uint8_t *dst = a.bwt + base + x0;
-    if (nb == 16) st16u(dst, make_uint4(r0, r1, r2, r3));
-    else {
+    if (nb == 16 && hardmask == 0) st16u(dst, make_uint4(r0, r1, r2, r3));
+    else {   // positions of hard entries belong to whoever ranks into them: never touch them here
       const uint32_t rr[4] = {r0, r1, r2, r3};
 #pragma unroll
-      for (int k = 0; k < 16; k++) if (k < nb) dst[k] = (uint8_t)(rr[k >> 2] >> (8 * (k & 3)));
+      for (int k = 0; k < 16; k++) if (k < nb && !((hardmask >> k) & 1u)) dst[k] = (uint8_t)(rr[k >> 2] >> (8 * (k & 3)));
     }
   }
-}
-
-// one wave per hard group: rank every (member, occurrence) by its BWT(P) position
-__global__ __launch_bounds__(64) void hard_groups_kernel(MergeArgs a, const uint32_t *__restrict__ hlist, uint32_t nh,
-                                                         unsigned long long *__restrict__ hard_chars) {
-  uint32_t gi = blockIdx.x;
-  if (gi >= nh) return;
-  const uint64_t g = hlist[gi];
-  const int lane = threadIdx.x;
-  // member count: consecutive slots of group g
-  uint32_t k = 0;
-  for (;;) {
-    uint64_t t = g + k + lane;
-    bool in = t < a.N && a.grp[t] == (uint32_t)g && a.pc[t] != 0;
-    unsigned long long m = __ballot(in);
-    if (m == ~0ULL) { k += 64; continue; }
-    k += __ffsll((long long)~m) - 1;
-    break;
-  }
-  const uint64_t base = a.off[g];
-  const uint64_t C = a.off[g + k] - base;
-  if (lane == 0) atomicAdd(hard_chars, (unsigned long long)C);
-  for (uint64_t e = lane; e < C; e += 64) {
-    uint32_t lo = 0, hi = k;                // member holding element e
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (a.off[g + mid] - base <= e) lo = mid; else hi = mid; }
-    const uint32_t m = lo;
-    const uint32_t j = (uint32_t)(e - (a.off[g + m] - base));
-    const uint32_t i = a.sa[g + m];
-    const uint32_t wd = a.posrec[i].w;
-    const uint32_t pos = a.ilist[a.wistart[wd] + j];
-    uint64_t r = j;
-    for (uint32_t m2 = 0; m2 < k; m2++) {
-      if (m2 == m) continue;
-      const uint32_t wd2 = a.posrec[a.sa[g + m2]].w;
-      const uint32_t *lst = a.ilist + a.wistart[wd2];
-      uint32_t l2 = 0, h2 = a.wocc[wd2];         // # entries < pos
-      while (l2 < h2) { uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
-      r += l2;
-    }
-    const uint64_t x = base + r;
-    a.bwt[x] = fix_char(a.pc[g + m]);
-    if (a.want_sa) a.out_sa[x] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
-  }
+  // statistics (pfbwt.cpp:231-233 "Hard bwt chars"): one atomic per wave
+  for (int o = 32; o > 0; o >>= 1) { my_hard += __shfl_down(my_hard, o, 64); my_groups += __shfl_down(my_groups, o, 64); }
+  if ((threadIdx.x & 63) == 0 && (my_hard | my_groups)) { atomicAdd(&stats[0], my_hard); atomicAdd(&stats[1], my_groups); }
 }
 
 void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, const ParseBWT &pb,
@@ -307,7 +302,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   exclusive_sum_u32(c, occ_lex, istart_lex.p, d);
   hipLaunchKernelGGL(wistart_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, wistart.p);
   DBuf<uint4> posrec(c, N);
-  DBuf<uint32_t> cnt(c, N + 8), grp(c, N + 8);
+  DBuf<uint32_t> cnt(c, N + 8), grp(c, N + 8), ist(c, N + 8);
   DBuf<uint8_t> pc(c, N + 8), hard(c, N);
   DBuf<uint64_t> off(c, N + 1);
   PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream));
@@ -315,34 +310,27 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   hipLaunchKernelGGL(posrec_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, d, w, ix.pos_word.p,
                      ix.endpos.p, so.rank.p, D.wocc.p, posrec.p);
   hipLaunchKernelGGL(slot_gather_kernel, dim3(cdiv(cdiv64(N, 8), 256)), dim3(256), 0, c->stream, N, so.sa.p, posrec.p,
-                     cnt.p, pc.p, grp.p);
+                     wistart.p, cnt.p, pc.p, grp.p, ist.p);
   exclusive_sum_u32_u64(c, cnt.p, off.p, N + 1);
   hipLaunchKernelGGL(group_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, grp.p, pc.p, flags ? 1 : 0, hard.p);
-  DBuf<uint32_t> hlist(c, N), nh_d(c, 1);
-  select_index_u32(c, hard.p, hlist.p, nh_d.p, N);
-  PFP_HIP(hipMemcpyAsync(c->h_scalars, off.p + N, 8, hipMemcpyDeviceToHost, c->stream));
-  PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, nh_d.p, 4, hipMemcpyDeviceToHost, c->stream));
-  sync(c);
-  const uint64_t n_out = c->h_scalars[0];
-  uint32_t nh; memcpy(&nh, c->h_scalars + 1, 4);
+  const uint64_t n_out = read_scalar(c, off.p + N);
   PFP_REQUIRE(expect_n_out == 0 || n_out == expect_n_out, PFP_EFORMAT,
               "merge: sum of occurrence counts (" + std::to_string(n_out) + ") != text length + 1 (" +
                   std::to_string(expect_n_out) + ")");
   out.n_out = n_out;
   MergeArgs a{};
   a.N = N; a.n_out = n_out; a.d = d; a.w = w; a.want_sa = flags ? 1 : 0;
-  a.sa = so.sa.p; a.endpos = ix.endpos.p; a.wocc = D.wocc.p; a.wistart = wistart.p; a.grp = grp.p;
-  a.posrec = posrec.p; a.pc = pc.p; a.hard = hard.p; a.off = off.p;
+  a.sa = so.sa.p; a.endpos = ix.endpos.p; a.grp = grp.p; a.ist = ist.p;
+  a.pc = pc.p; a.hard = hard.p; a.off = off.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p; a.bwt = out.d_bwt; a.out_sa = out.d_sa;
-  hipLaunchKernelGGL(expand_kernel, dim3(cdiv(N, kSlots)), dim3(256), 0, c->stream, a);
-  out.hard_groups = nh;
-  if (nh) {
-    DBuf<unsigned long long> hc(c, 1);
-    hc.zero();
-    hipLaunchKernelGGL(hard_groups_kernel, dim3(nh), dim3(64), 0, c->stream, a, hlist.p, nh, hc.p);
-    out.hard_chars = read_scalar(c, hc.p);
-  }
+  DBuf<unsigned long long> hstats(c, 2);
+  hstats.zero();
+  hipLaunchKernelGGL(expand_kernel, dim3(cdiv(N, kSlots)), dim3(256), 0, c->stream, a, hstats.p);
   PFP_HIP(hipGetLastError());
+  PFP_HIP(hipMemcpyAsync(c->h_scalars, hstats.p, 16, hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  out.hard_chars = c->h_scalars[0];
+  out.hard_groups = c->h_scalars[1];
 }
 
 // ------------------------------------------------------------------ output packing

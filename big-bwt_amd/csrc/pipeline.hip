@@ -101,11 +101,14 @@ static void check_args(int w, uint64_t p, int flags) {
 }
 
 // stage 1 on a staged text: scan, dictionary, dictionary suffix order, lexicographic ranks
-static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool want_sai) {
+static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool want_sai, bool exact_reference_parse) {
   pfp_stats &st = c->stats;
   {
     PhaseTimer t(c, &st.ms_scan);
-    ch.n_ends = scan_text(c, ch.tx, n, w, p, ch.ends, &ch.n_used);
+    uint32_t n_extra = 0;
+    if (exact_reference_parse || !c->max_phrase) ch.n_ends = scan_text(c, ch.tx, n, w, p, ch.ends, &ch.n_used);
+    else ch.n_ends = scan_text_adaptive(c, ch.tx, n, w, p, c->max_phrase, ch.ends, &ch.n_used, &n_extra);
+    st.extra_triggers = n_extra;
     if (c->debug) validate_scan(c, ch.ends, ch.n_ends, ch.n_used, w);
   }
   {
@@ -139,7 +142,7 @@ static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, 
   pfp_stats &st = c->stats;
   st = pfp_stats{};
   auto t0 = std::chrono::steady_clock::now();
-  run_parse(c, ch, n, w, p, flags != 0);
+  run_parse(c, ch, n, w, p, flags != 0, false);
   {
     PhaseTimer t(c, &st.ms_sa_parse);
     parse_bwt(c, ch.sym.p, ch.D.P, ch.D.last.p, flags ? ch.D.sai.p : nullptr, ch.occ_lex.p, ch.D.d, ch.pb);
@@ -277,6 +280,7 @@ const char *pfp_last_error(const pfp_ctx *c) { return c ? c->err.c_str() : "null
 void *pfp_ctx_stream(pfp_ctx *c) { return c ? (void *)c->stream : nullptr; }
 void pfp_free(void *p) { free(p); }
 void pfp_set_profiling(pfp_ctx *c, int on) { if (c) c->profiling = on != 0; }
+void pfp_set_max_phrase(pfp_ctx *c, uint64_t max_phrase) { if (c) c->max_phrase = max_phrase; }
 int pfp_get_stats(const pfp_ctx *c, pfp_stats *st) {
   if (!c || !st) return PFP_EINVAL;
   *st = c->stats;
@@ -326,7 +330,7 @@ int pfp_parse(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, in
   c->stats = pfp_stats{};
   Chain ch;
   ch.tx.stage(c, text, false, n, w);
-  run_parse(c, ch, n, w, p, want_sai != 0);
+  run_parse(c, ch, n, w, p, want_sai != 0, true);
   const uint32_t d = (uint32_t)ch.D.d;
   const uint64_t P = ch.D.P;
   // .dict in lexicographic order

@@ -32,10 +32,16 @@ __device__ __forceinline__ uint32_t kr_reduce(uint64_t T) {
   return r < r2 ? r : r2;
 }
 
+// trigger test: `hash % p == 0` (newscan.cpp:367) or, in the fused chain only, membership in the
+// small set of extra trigger hashes that splits giant phrases (see scan_text_adaptive)
 __device__ __forceinline__ bool kr_divides(uint32_t h, const KRParams &kp) {
   uint32_t x = h * kp.pinv;
   x = (x >> kp.pshift) | (kp.pshift ? (x << (32 - kp.pshift)) : 0u);
-  return x <= kp.plimit;
+  bool t = x <= kp.plimit;
+  if (kp.bloom && ((kp.bloom >> (h & 63)) & 1ull)) {
+    for (uint32_t q = 0; q < kp.nextra; q++) t |= (h == kp.extra[q]);
+  }
+  return t;
 }
 
 __device__ __forceinline__ uint32_t byte_of(const uint32_t (&r)[8], int k) {
@@ -197,8 +203,8 @@ static void launch_flag(pfp_ctx *c, int nblocks, const uint8_t *tbase, uint64_t 
 }
 
 void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p, uint16_t *flags16,
-                uint32_t *block_counts, unsigned long long *first_bad) {
-  KRParams kp = make_kr_params(w, p);
+                uint32_t *block_counts, unsigned long long *first_bad, const KRParams *kp_override) {
+  KRParams kp = kp_override ? *kp_override : make_kr_params(w, p);
   uint64_t nchunks = cdiv64(n, 16);
   int nblocks = (int)cdiv64(nchunks, 256);
   if (nblocks == 0) return;
@@ -217,8 +223,8 @@ void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p,
 // If a byte <= 2 is found before n, *n_used is set to its position and the scan is redone on
 // the prefix (the reference stops reading there: newscan.cpp:364).
 uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, DBuf<uint64_t> &d_ends,
-                   uint64_t *n_used) {
-  PFP_REQUIRE(w >= 1 && w <= 255, PFP_EINVAL, "window size out of range");
+                   uint64_t *n_used, const KRParams *kp_override) {
+  PFP_REQUIRE(w >= 1 && w <= 4096, PFP_EINVAL, "window size out of range");
   uint64_t cur_n = n;
   for (int attempt = 0; attempt < 2; attempt++) {
     uint64_t nchunks = cdiv64(cur_n, 16);
@@ -230,7 +236,7 @@ uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t
     DBuf<unsigned long long> fbad(c, 1);
     PFP_HIP(hipMemsetAsync(fbad.p, 0xff, 8, c->stream));
     PFP_HIP(hipMemsetAsync(bcnt.p + nblocks, 0, 4, c->stream));
-    scan_flags(c, tx.tbase(), cur_n, w, p, flags16.p, bcnt.p, fbad.p);
+    scan_flags(c, tx.tbase(), cur_n, w, p, flags16.p, bcnt.p, fbad.p, kp_override);
     exclusive_sum_u32(c, bcnt.p, boff.p, (size_t)nblocks + 1);
     // total + first_bad in one sync
     PFP_HIP(hipMemcpyAsync(c->h_scalars, boff.p + nblocks, 4, hipMemcpyDeviceToHost, c->stream));
@@ -252,6 +258,84 @@ uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t
     return total;
   }
   return 0;
+}
+
+// ---------------------------------------------------------------- adaptive extra triggers
+//
+// A text with a multi-megabyte low-complexity stretch (the N runs of a chromosome) yields one
+// giant phrase; its suffixes share prefixes as long as the stretch and prefix doubling over the
+// dictionary needs log2(length) full rounds for it.  Prefix-free parsing is correct for ANY set
+// of trigger windows, and the final BWT/SA are functions of the text alone,
+// so the fused chain may enlarge the reference's trigger set {hash % p == 0} by a few specific
+// window hashes taken from inside giant phrases: every occurrence of such a window then also
+// ends a phrase, a periodic run collapses into many copies of one short phrase, and the
+// dictionary keeps short words only.  The staged entry points (pfp_scan / pfp_parse), whose
+// outputs are the reference's files, never do this.
+
+__global__ void giant_phrases_kernel(const uint64_t *__restrict__ ends, uint64_t ne, uint64_t n, int w,
+                                     uint64_t max_len, uint32_t *__restrict__ count, uint64_t *__restrict__ picks,
+                                     uint32_t cap) {
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > ne) return;
+  uint64_t e = k < ne ? ends[k] + 1 : n + (uint64_t)w;             // T' index of the last byte
+  uint64_t s = k == 0 ? 0 : ends[k - 1] + 2 - (uint64_t)w;         // T' index of the first byte
+  uint64_t len = e - s + 1;
+  if (len <= max_len) return;
+  uint32_t i = atomicAdd(count, 1u);
+  if (i < cap) picks[i] = s + max_len / 2;                         // first of kCand candidate window ends, well inside
+}
+// hashes of kCand consecutive windows starting at every pick (one block per pick)
+constexpr uint32_t kCand = 256;
+__global__ void window_hash_kernel(const uint8_t *__restrict__ tbase, int w, const uint64_t *__restrict__ picks,
+                                   uint32_t *__restrict__ out) {
+  uint64_t e = picks[blockIdx.x] + threadIdx.x;
+  uint32_t h = 0;
+  for (int k = 0; k < w; k++) h = kr_reduce<8>(((uint64_t)h << 8) | tbase[e - (uint64_t)(w - 1) + (uint64_t)k]);
+  out[blockIdx.x * kCand + threadIdx.x] = h;
+}
+
+uint64_t scan_text_adaptive(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, uint64_t max_phrase,
+                            DBuf<uint64_t> &d_ends, uint64_t *n_used, uint32_t *n_extra) {
+  KRParams kp = make_kr_params(w, p);
+  *n_extra = 0;
+  uint64_t ne = scan_text(c, tx, n, w, p, d_ends, n_used, &kp);
+  if (!max_phrase || max_phrase < 4 * (uint64_t)w + 2 * kCand + 64) return ne;
+  const uint32_t cap = 8;
+  DBuf<uint32_t> cnt(c, 1), hashes(c, cap * kCand);
+  DBuf<uint64_t> picks(c, cap);
+  std::vector<uint32_t> hv(cap * kCand);
+  for (int iter = 0; iter < 4 && kp.nextra + cap <= KRParams::kMaxExtra; iter++) {
+    cnt.zero();
+    hipLaunchKernelGGL(giant_phrases_kernel, dim3(cdiv(ne + 1, 256)), dim3(256), 0, c->stream, d_ends.p, ne, *n_used, w,
+                       max_phrase, cnt.p, picks.p, cap);
+    uint32_t ng = read_scalar(c, cnt.p);
+    if (!ng) break;
+    uint32_t take = ng < cap ? ng : cap;
+    hipLaunchKernelGGL(window_hash_kernel, dim3(take), dim3(kCand), 0, c->stream, tx.tbase(), w, picks.p, hashes.p);
+    PFP_HIP(hipMemcpyAsync(hv.data(), hashes.p, (size_t)take * kCand * 4, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    // per giant phrase: the candidate window that is rarest among kCand consecutive ones.  A
+    // window seen more than 4 times there recurs every < 64 bytes (a run of one repeated char,
+    // a short period): adding it would only trade the giant phrase for millions of tiny ones.
+    uint32_t added = 0;
+    for (uint32_t q = 0; q < take; q++) {
+      const uint32_t *cand = hv.data() + (size_t)q * kCand;
+      uint32_t best = 0, best_mult = kCand + 1;
+      for (uint32_t x = 0; x < kCand; x++) {
+        uint32_t mult = 0;
+        for (uint32_t y = 0; y < kCand; y++) mult += cand[y] == cand[x];
+        if (mult < best_mult) { best_mult = mult; best = cand[x]; }
+      }
+      if (best_mult > 4) continue;
+      bool dup = false;
+      for (uint32_t z = 0; z < kp.nextra; z++) dup |= kp.extra[z] == best;
+      if (!dup) { kp.extra[kp.nextra++] = best; kp.bloom |= 1ull << (best & 63); added++; }
+    }
+    if (!added) break;
+    ne = scan_text(c, tx, *n_used, w, p, d_ends, n_used, &kp);
+  }
+  *n_extra = kp.nextra;
+  return ne;
 }
 
 }  // namespace pfp

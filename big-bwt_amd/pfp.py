@@ -30,7 +30,7 @@ ERRORS = {0: "PFP_OK", -1: "PFP_EINVAL", -2: "PFP_ENODEV", -3: "PFP_EHIP", -4: "
 SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror", "pfp_version", "pfp_ctx_stream",
            "pfp_free", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak",
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_dev", "pfp_get_stats",
-           "pfp_set_profiling", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue"]
+           "pfp_set_profiling", "pfp_set_max_phrase", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue"]
 
 
 class PfpError(RuntimeError):
@@ -57,6 +57,7 @@ class Stats(C.Structure):
     _fields_ = [("n", C.c_uint64), ("n_phrases", C.c_uint64), ("n_words", C.c_uint64), ("dict_size", C.c_uint64),
                 ("sa_rounds_dict", C.c_uint64), ("sa_rounds_parse", C.c_uint64),
                 ("hard_groups", C.c_uint64), ("hard_chars", C.c_uint64), ("hash_reseeds", C.c_uint64),
+                ("extra_triggers", C.c_uint64),
                 ("ms_scan", C.c_double), ("ms_phrases", C.c_double), ("ms_sa_dict", C.c_double),
                 ("ms_sa_parse", C.c_double), ("ms_merge", C.c_double), ("ms_total", C.c_double)]
 
@@ -90,6 +91,7 @@ def load_library():
         lib.pfp_ctx_destroy.restype = None
         lib.pfp_free.restype = None
         lib.pfp_set_profiling.restype = None
+        lib.pfp_set_max_phrase.restype = None
         lib.pfp_parse_result_free.restype = None
         lib.pfp_bwt_result_free.restype = None
         _lib = lib
@@ -167,6 +169,10 @@ class Context:
 
     def set_profiling(self, on=True):
         self.lib.pfp_set_profiling(self._h, C.c_int(1 if on else 0))
+
+    def set_max_phrase(self, max_phrase):
+        """fused chain: split phrases longer than this with extra trigger windows (0 = reference parse)"""
+        self.lib.pfp_set_max_phrase(self._h, C.c_uint64(max_phrase))
 
     def stats(self):
         st = Stats()

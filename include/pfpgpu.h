@@ -140,11 +140,17 @@ typedef struct {
   uint64_t sa_rounds_dict, sa_rounds_parse;
   uint64_t hard_groups, hard_chars;
   uint64_t hash_reseeds;
+  uint64_t extra_triggers;   /* window hashes added by the fused chain to split giant phrases */
   double ms_scan, ms_phrases, ms_sa_dict, ms_sa_parse, ms_merge, ms_total; /* host wall, synced */
 } pfp_stats;
 int pfp_get_stats(const pfp_ctx *ctx, pfp_stats *st);
 /* when set (default 0) every pipeline phase is bracketed by a stream sync so ms_* are filled */
 void pfp_set_profiling(pfp_ctx *ctx, int on);
+/* Fused chain only (pfp_bigbwt / pfp_bigbwt_dev): phrases longer than max_phrase bytes are split
+ * by adding a few extra trigger windows taken from inside them (default 32768; 0 = parse exactly
+ * as the reference does).  The .bwt/.sa/.ssa/.esa outputs do not depend on the parse
+ * (SURVEY.md 2.2-Q11); pfp_scan / pfp_parse always use the reference's trigger set. */
+void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
 
 /* ---- micro entry points used by bench.py's roofline leg and by the parity tests ---- */
 /* copy a device-resident text into the ctx's padded staging buffer (T' = Dollar.T.Dollar^w) */

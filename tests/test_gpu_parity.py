@@ -59,6 +59,33 @@ def test_stage_files_match_reference_golden(golden, O, pkg, ctx, idx):
     assert sha(out["bwt"]) == c["runs"]["0"]["bwt_sha256"]
 
 
+@pytest.mark.parametrize("max_phrase", [0, 700, 3000])
+def test_outputs_do_not_depend_on_the_parse(golden, O, pkg, ctx, max_phrase):
+    """fused chain with adaptive extra triggers (giant-phrase splitting) on/off: identical
+    .bwt/.sa/.ssa/.esa; the staged pfp_parse keeps the reference's parse."""
+    try:
+        ctx.set_max_phrase(max_phrase)
+        used = 0
+        for c in golden:
+            if c["n"] > 200000:
+                continue
+            text = make_text(c["spec"], O)
+            for flags in (0, 1, 6):
+                r = c["runs"][str(flags)]
+                got = ctx.bigbwt(text, c["w"], c["p"], flags)
+                used += ctx.stats()["extra_triggers"]
+                assert sha(got["bwt"]) == r["bwt_sha256"], (c["name"], flags, max_phrase)
+                if flags & 1:
+                    assert sha(got["sa"]) == r["sa_sha256"]
+                if flags & 2:
+                    assert sha(got["ssa"]) == r["ssa_sha256"] and sha(got["esa"]) == r["esa_sha256"]
+            ps = ctx.parse(text, c["w"], c["p"])
+            assert sha(ps["dict"]) == c["runs"]["6"]["dict_sha256"]
+        assert (used > 0) == (max_phrase > 0)
+    finally:
+        ctx.set_max_phrase(1 << 15)
+
+
 def test_scan_matches_oracle(O, ctx):
     """K1/K2 against KR_window::addchar restated on the CPU, many (w,p) incl. even/odd/huge p."""
     text = O.gen_fasta(50000, 2, 0.001, 21)
