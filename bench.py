@@ -215,6 +215,7 @@ def main():
             "cpu_baseline": cpu,
             "phases_ms": {k: round(st[k], 3) for k in ("ms_scan", "ms_phrases", "ms_sa_dict", "ms_sa_parse", "ms_merge", "ms_total")},
             "sa_rounds": {"dict": st["sa_rounds_dict"], "parse": st["sa_rounds_parse"]},
+            "merge_stats": {k: st[k] for k in ("hard_groups", "hard_chars", "hard_big_groups", "hard_max_chars", "hard_max_members", "extra_triggers")},
             "verified": {"bwt_is_permutation_of_text_plus_eos": verified, "bit_exact_vs_reference_on_cpu_sample": parity_sample},
         }
     if dist is not None:

@@ -95,7 +95,7 @@ struct BwtOutputs {
   uint64_t n_out = 0;      // n+1
   uint8_t *d_bwt = nullptr;    // [n+1] device, caller-provided
   uint64_t *d_sa = nullptr;    // [n+1] device, caller-provided when flags != 0
-  uint64_t hard_groups = 0, hard_chars = 0;
+  uint64_t hard_groups = 0, hard_chars = 0, hard_big_groups = 0, hard_max_chars = 0, hard_max_members = 0;
 };
 void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, const ParseBWT &pb,
                const uint32_t *occ_lex, int w, int flags, uint64_t expect_n_out, BwtOutputs &out);

@@ -14,6 +14,8 @@
 #include "kernels.hpp"
 #include "prims.hpp"
 #include "devutil.hpp"
+#include <algorithm>
+#include <cstdlib>
 
 namespace pfp {
 
@@ -191,7 +193,7 @@ __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank,
 }
 
 struct MergeArgs {
-  uint64_t N, n_out; uint32_t d; int w; int want_sa;
+  uint64_t N, n_out; uint32_t d; int w; int want_sa; int dbg_mode;
   const uint32_t *sa, *endpos, *grp, *ist;
   const uint8_t *pc, *hard; const uint64_t *off;
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
@@ -211,85 +213,189 @@ __device__ __forceinline__ uint8_t fix_char(uint8_t ch) { return ch == kDollar ?
 //                     inverted list - and written to that slot of the group's range: the
 //                     data-parallel form of the reference's heap merge (pfbwt.cpp:537-556).
 constexpr int kSlots = 2048;
-__global__ __launch_bounds__(256) void expand_kernel(MergeArgs a, unsigned long long *__restrict__ stats) {
-  __shared__ uint64_t loff[kSlots + 1];
-  __shared__ uint8_t lpc[kSlots], lcls[kSlots];
+constexpr uint64_t kExpandQuota = 1u << 16;   // output bytes one workgroup expands before the rest is shared
+
+struct ExpandLds {
+  uint64_t loff[kSlots + 1];
+  uint8_t lpc[kSlots], lcls[kSlots];
+};
+
+__device__ __forceinline__ void expand_stage(const MergeArgs &a, ExpandLds &L, uint64_t t0, int ns, uint64_t base) {
+  for (int s = threadIdx.x; s <= ns; s += 256) L.loff[s] = a.off[t0 + s] - base;
+  for (int s = threadIdx.x; s < ns; s += 256) {
+    uint8_t ch = a.pc[t0 + s];
+    L.lpc[s] = ch;
+    L.lcls[s] = ch == 0 ? CLS_NONE : (ch == kEndOfWord ? CLS_FULL : (a.hard[a.grp[t0 + s]] ? CLS_HARD : CLS_FILL));
+  }
+  __syncthreads();
+}
+
+// 16 output bytes starting at block-relative offset x0 (< Ltot)
+__device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
+                                          uint64_t x0, uint64_t Ltot) {
+  int lo = 0, hi = ns;                    // loff[lo] <= x0 < loff[hi]
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (L.loff[mid] <= x0) lo = mid; else hi = mid; }
+  int s = lo;
+  uint64_t nxt = L.loff[s + 1];
+  const int nb = (Ltot - x0) >= 16 ? 16 : (int)(Ltot - x0);
+  uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    if (k < nb) {
+      const uint64_t x = x0 + k;
+      while (x >= nxt) { s++; nxt = L.loff[s + 1]; }
+      const uint8_t cl = L.lcls[s];
+      uint32_t ch = 0;
+      if (cl == CLS_FILL) {
+        ch = fix_char(L.lpc[s]);
+        if (a.want_sa) {
+          const uint32_t i = a.sa[t0 + s];
+          const uint64_t pos = a.ilist[a.ist[t0 + s] + (uint32_t)(x - L.loff[s])];
+          a.out_sa[base + x] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
+        }
+      } else if (cl == CLS_FULL) {
+        const uint64_t pos = a.ilist[a.ist[t0 + s] + (uint32_t)(x - L.loff[s])];
+        ch = a.bwlast[pos];
+        if (a.want_sa) {
+          const uint32_t i = a.sa[t0 + s];
+          a.out_sa[base + x] = (base + x == 0) ? a.n_out - 1 : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
+        }
+      }   // CLS_HARD: left 0 here, written by the hard-group kernels that run after this one
+      const uint32_t sh = (uint32_t)ch << (8 * (k & 3));
+      if (k < 4) r0 |= sh; else if (k < 8) r1 |= sh; else if (k < 12) r2 |= sh; else r3 |= sh;
+    }
+  }
+  uint8_t *dst = a.bwt + base + x0;
+  if (nb == 16) st16u(dst, make_uint4(r0, r1, r2, r3));
+  else {
+    const uint32_t rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int k = 0; k < 16; k++) if (k < nb) dst[k] = (uint8_t)(rr[k >> 2] >> (8 * (k & 3)));
+  }
+}
+
+__global__ __launch_bounds__(256) void expand_kernel(MergeArgs a, uint32_t *__restrict__ heavy, uint32_t *__restrict__ nheavy,
+                                                     uint32_t heavy_cap) {
+  __shared__ ExpandLds L;
   const uint64_t t0 = (uint64_t)blockIdx.x * kSlots;
   const int ns = (a.N - t0) >= (uint64_t)kSlots ? kSlots : (int)(a.N - t0);
   const uint64_t base = a.off[t0];
-  unsigned long long my_hard = 0, my_groups = 0;
-  for (int s = threadIdx.x; s <= ns; s += 256) loff[s] = a.off[t0 + s] - base;
-  for (int s = threadIdx.x; s < ns; s += 256) {
-    uint8_t ch = a.pc[t0 + s];
-    lpc[s] = ch;
-    uint8_t cl = ch == 0 ? CLS_NONE : (ch == kEndOfWord ? CLS_FULL : (a.hard[a.grp[t0 + s]] ? CLS_HARD : CLS_FILL));
-    lcls[s] = cl;
-    if (cl == CLS_HARD && a.grp[t0 + s] == t0 + s) my_groups++;
+  expand_stage(a, L, t0, ns, base);
+  const uint64_t Ltot = L.loff[ns];
+  // a block whose slots emit more than the quota (a word with hundreds of thousands of
+  // occurrences) finishes only its first quota here; expand_heavy_kernel shares the rest
+  const uint64_t mine = Ltot <= kExpandQuota ? Ltot : kExpandQuota;
+  if (Ltot > kExpandQuota && threadIdx.x == 0) { uint32_t i = atomicAdd(nheavy, 1u); if (i < heavy_cap) heavy[i] = blockIdx.x; }
+  for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < mine; x0 += 256 * 16) expand_16(a, L, t0, ns, base, x0, Ltot);
+}
+
+__global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgs a, const uint32_t *__restrict__ heavy, uint32_t nheavy) {
+  __shared__ ExpandLds L;
+  for (uint32_t q = 0; q < nheavy; q++) {
+    const uint64_t t0 = (uint64_t)heavy[q] * kSlots;
+    const int ns = (a.N - t0) >= (uint64_t)kSlots ? kSlots : (int)(a.N - t0);
+    const uint64_t base = a.off[t0];
+    __syncthreads();
+    expand_stage(a, L, t0, ns, base);
+    const uint64_t Ltot = L.loff[ns];
+    for (uint64_t x0 = kExpandQuota + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; x0 < Ltot; x0 += (uint64_t)gridDim.x * 256 * 16)
+      expand_16(a, L, t0, ns, base, x0, Ltot);
   }
-  __syncthreads();
-  const uint64_t L = loff[ns];
-  for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < L; x0 += 256 * 16) {
-    int lo = 0, hi = ns;                    // loff[lo] <= x0 < loff[hi]
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (loff[mid] <= x0) lo = mid; else hi = mid; }
-    int s = lo;
-    uint64_t nxt = loff[s + 1];
-    const int nb = (L - x0) >= 16 ? 16 : (int)(L - x0);
-    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, hardmask = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (k < nb) {
-        const uint64_t x = x0 + k;
-        while (x >= nxt) { s++; nxt = loff[s + 1]; }
-        const uint8_t cl = lcls[s];
-        uint32_t ch = 0;
-        if (cl == CLS_FILL) {
-          ch = fix_char(lpc[s]);
-          if (a.want_sa) {
-            const uint32_t i = a.sa[t0 + s];
-            const uint64_t pos = a.ilist[a.ist[t0 + s] + (uint32_t)(x - loff[s])];
-            a.out_sa[base + x] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
-          }
-        } else if (cl == CLS_FULL) {
-          const uint64_t pos = a.ilist[a.ist[t0 + s] + (uint32_t)(x - loff[s])];
-          ch = a.bwlast[pos];
-          if (a.want_sa) {
-            const uint32_t i = a.sa[t0 + s];
-            a.out_sa[base + x] = (base + x == 0) ? a.n_out - 1 : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
-          }
-        } else if (cl == CLS_HARD) {
-          hardmask |= 1u << k;
-          my_hard++;
-          const uint64_t t = t0 + s;
-          const uint64_t g = a.grp[t];
-          const uint32_t j = (uint32_t)(x - loff[s]);
-          const uint32_t pos = a.ilist[a.ist[t] + j];
-          uint64_t r = j;
-          for (uint64_t t2 = g; t2 < a.N && a.grp[t2] == (uint32_t)g && a.pc[t2] != 0; t2++) {
-            if (t2 == t) continue;
-            const uint32_t *lst = a.ilist + a.ist[t2];
-            uint32_t l2 = 0, h2 = (uint32_t)(a.off[t2 + 1] - a.off[t2]);      // # entries < pos
-            while (l2 < h2) { uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
-            r += l2;
-          }
-          const uint64_t xo = a.off[g] + r;
-          a.bwt[xo] = fix_char(lpc[s]);
-          if (a.want_sa) { const uint32_t i = a.sa[t]; a.out_sa[xo] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i); }
-        }
-        const uint32_t sh = (uint32_t)ch << (8 * (k & 3));
-        if (k < 4) r0 |= sh; else if (k < 8) r1 |= sh; else if (k < 12) r2 |= sh; else r3 |= sh;
+}
+
+// Hard groups.  One wave scans 64 consecutive slots for hard group heads and processes each such
+// group cooperatively.  Every occurrence (member, j) must land at the rank of its BWT(P) position
+// among all occurrences of the group - the reference pops a heap (pfbwt.cpp:537-556):
+//   * groups of up to kHardLds occurrences: positions staged in LDS, each lane counts the smaller
+//     ones with broadcast LDS reads (all-pairs, no dependent global loads);
+//   * larger groups (few members with long inverted lists): own index + lower_bound in every other
+//     member's inverted list.
+constexpr int kHardLds = 1024;
+struct BigGroup { uint64_t g; uint64_t E; uint32_t k; uint32_t pad; };
+__global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, unsigned long long *__restrict__ stats,
+                                                          BigGroup *__restrict__ big, uint32_t big_cap) {
+  __shared__ uint32_t lpos[4][kHardLds];
+  __shared__ uint32_t lsl[4][kHardLds];
+  __shared__ uint8_t lch[4][kHardLds];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long my_chars = 0, my_groups = 0;
+  for (uint64_t tbase = ((uint64_t)blockIdx.x * 4 + wv) * 64; tbase < a.N; tbase += (uint64_t)gridDim.x * 256) {
+  const uint64_t tme = tbase + lane;
+  const bool head = tme < a.N && a.hard[tme] && a.grp[tme] == (uint32_t)tme;
+  unsigned long long heads = __ballot(head);
+  while (heads) {
+    const int hl = __ffsll((long long)heads) - 1;
+    heads &= heads - 1;
+    const uint64_t g = tbase + hl;
+    // members: consecutive slots with this group id
+    uint32_t k = 0;
+    for (;;) {
+      const uint64_t t = g + k + lane;
+      const bool in = t < a.N && a.grp[t] == (uint32_t)g && a.pc[t] != 0;
+      const unsigned long long mm = __ballot(in);
+      if (mm == ~0ULL) { k += 64; continue; }
+      k += __ffsll((long long)~mm) - 1;
+      break;
+    }
+    const uint64_t base = a.off[g];
+    const uint64_t E = a.off[g + k] - base;
+    if (lane == 0) { my_chars += E; my_groups += 1; }
+    if (E <= (uint64_t)kHardLds) {
+      for (uint32_t m = lane; m < k; m += 64) {          // stage (position, char, suffix length) per occurrence
+        const uint64_t t = g + m;
+        const uint32_t o0 = (uint32_t)(a.off[t] - base), occ = (uint32_t)(a.off[t + 1] - a.off[t]);
+        const uint32_t is = a.ist[t];
+        const uint8_t ch = fix_char(a.pc[t]);
+        uint32_t sl = 0;
+        if (a.want_sa) { const uint32_t i = a.sa[t]; sl = a.endpos[i] - i; }
+        for (uint32_t j = 0; j < occ; j++) { lpos[wv][o0 + j] = a.ilist[is + j]; lch[wv][o0 + j] = ch; lsl[wv][o0 + j] = sl; }
       }
-    }
-    uint8_t *dst = a.bwt + base + x0;
-    if (nb == 16 && hardmask == 0) st16u(dst, make_uint4(r0, r1, r2, r3));
-    else {   // positions of hard entries belong to whoever ranks into them: never touch them here
-      const uint32_t rr[4] = {r0, r1, r2, r3};
-#pragma unroll
-      for (int k = 0; k < 16; k++) if (k < nb && !((hardmask >> k) & 1u)) dst[k] = (uint8_t)(rr[k >> 2] >> (8 * (k & 3)));
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      for (uint32_t e = lane; e < (uint32_t)E; e += 64) {
+        const uint32_t pos = lpos[wv][e];
+        uint32_t r = 0;
+        for (uint32_t q = 0; q < (uint32_t)E; q++) r += lpos[wv][q] < pos;
+        a.bwt[base + r] = lch[wv][e];
+        if (a.want_sa) a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)lsl[wv][e];
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else if (lane == 0) {     // too large for LDS: queued for hard_big_kernel (whole-grid, one thread per occurrence)
+      const unsigned long long idx = atomicAdd(&stats[2], 1ull);
+      if (idx < big_cap) big[idx] = BigGroup{g, E, k, 0};
     }
   }
-  // statistics (pfbwt.cpp:231-233 "Hard bwt chars"): one atomic per wave
-  for (int o = 32; o > 0; o >>= 1) { my_hard += __shfl_down(my_hard, o, 64); my_groups += __shfl_down(my_groups, o, 64); }
-  if ((threadIdx.x & 63) == 0 && (my_hard | my_groups)) { atomicAdd(&stats[0], my_hard); atomicAdd(&stats[1], my_groups); }
+  }
+  // statistics (pfbwt.cpp:231-233 "Hard bwt chars"): lane 0 of every wave holds its totals
+  if (lane == 0 && (my_chars | my_groups)) { atomicAdd(&stats[0], my_chars); atomicAdd(&stats[1], my_groups); }
+}
+
+// large hard groups: one thread per occurrence, rank = own index + lower_bound in every other
+// member's inverted list
+__global__ __launch_bounds__(256) void hard_big_kernel(MergeArgs a, const BigGroup *__restrict__ big, uint32_t nbig,
+                                                       const uint64_t *__restrict__ estart, uint64_t total) {
+  for (uint64_t ge = (uint64_t)blockIdx.x * 256 + threadIdx.x; ge < total; ge += (uint64_t)gridDim.x * 256) {
+    uint32_t lo = 0, hi = nbig;               // estart[lo] <= ge < estart[hi]
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (estart[mid] <= ge) lo = mid; else hi = mid; }
+    const uint64_t g = big[lo].g, e = ge - estart[lo];
+    const uint32_t k = big[lo].k;
+    const uint64_t base = a.off[g];
+    uint32_t ml = 0, mh = k;                  // member holding occurrence e
+    while (mh - ml > 1) { uint32_t mid = (ml + mh) >> 1; if (a.off[g + mid] - base <= e) ml = mid; else mh = mid; }
+    const uint64_t t = g + ml;
+    const uint32_t j = (uint32_t)(e - (a.off[t] - base));
+    const uint32_t pos = a.ilist[a.ist[t] + j];
+    uint64_t r = j;
+    for (uint64_t t2 = g; t2 < g + k; t2++) {
+      if (t2 == t) continue;
+      const uint32_t *lst = a.ilist + a.ist[t2];
+      uint32_t l2 = 0, h2 = (uint32_t)(a.off[t2 + 1] - a.off[t2]);      // # entries < pos
+      while (l2 < h2) { uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
+      r += l2;
+    }
+    a.bwt[base + r] = fix_char(a.pc[t]);
+    if (a.want_sa) { const uint32_t i = a.sa[t]; a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i); }
+  }
 }
 
 void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, const ParseBWT &pb,
@@ -320,17 +426,52 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   out.n_out = n_out;
   MergeArgs a{};
   a.N = N; a.n_out = n_out; a.d = d; a.w = w; a.want_sa = flags ? 1 : 0;
+  { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
   a.sa = so.sa.p; a.endpos = ix.endpos.p; a.grp = grp.p; a.ist = ist.p;
   a.pc = pc.p; a.hard = hard.p; a.off = off.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p; a.bwt = out.d_bwt; a.out_sa = out.d_sa;
-  DBuf<unsigned long long> hstats(c, 2);
+  DBuf<unsigned long long> hstats(c, 5);
   hstats.zero();
-  hipLaunchKernelGGL(expand_kernel, dim3(cdiv(N, kSlots)), dim3(256), 0, c->stream, a, hstats.p);
-  PFP_HIP(hipGetLastError());
-  PFP_HIP(hipMemcpyAsync(c->h_scalars, hstats.p, 16, hipMemcpyDeviceToHost, c->stream));
-  sync(c);
+  uint32_t big_cap = 1u << 16;
+  DBuf<BigGroup> big(c, big_cap);
+  {
+    const uint32_t nblk = (uint32_t)cdiv64(N, kSlots);
+    DBuf<uint32_t> heavy(c, nblk), nheavy(c, 1);
+    nheavy.zero();
+    hipLaunchKernelGGL(expand_kernel, dim3(nblk), dim3(256), 0, c->stream, a, heavy.p, nheavy.p, nblk);
+    const uint32_t nh = read_scalar(c, nheavy.p);
+    if (nh) hipLaunchKernelGGL(expand_heavy_kernel, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, heavy.p, nh);
+  }
+  for (;;) {
+    hipLaunchKernelGGL(hard_groups_kernel, dim3((int)std::min<uint64_t>(cdiv64(N, 256), (uint64_t)c->n_cu * 8)), dim3(256), 0,
+                       c->stream, a, hstats.p, big.p, big_cap);
+    PFP_HIP(hipGetLastError());
+    PFP_HIP(hipMemcpyAsync(c->h_scalars, hstats.p, 40, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    if (c->h_scalars[2] <= big_cap) break;
+    big_cap = (uint32_t)std::min<uint64_t>(c->h_scalars[2], 0xFFFFFFFFull);   // rare: redo with a queue that fits
+    big.alloc(c, big_cap);
+    hstats.zero();
+  }
   out.hard_chars = c->h_scalars[0];
   out.hard_groups = c->h_scalars[1];
+  out.hard_big_groups = c->h_scalars[2]; out.hard_max_chars = c->h_scalars[3]; out.hard_max_members = c->h_scalars[4];
+  const uint32_t nbig = (uint32_t)c->h_scalars[2];
+  if (nbig) {
+    // occurrences of the queued groups, laid end to end
+    std::vector<BigGroup> hb(nbig);
+    PFP_HIP(hipMemcpyAsync(hb.data(), big.p, nbig * sizeof(BigGroup), hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    std::vector<uint64_t> es(nbig + 1, 0);
+    for (uint32_t q = 0; q < nbig; q++) es[q + 1] = es[q] + hb[q].E;
+    DBuf<uint64_t> estart(c, nbig + 1);
+    PFP_HIP(hipMemcpyAsync(estart.p, es.data(), (nbig + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    const uint64_t total = es[nbig];
+    const int nb = (int)std::min<uint64_t>(cdiv64(total, 256), (uint64_t)c->n_cu * 32);
+    hipLaunchKernelGGL(hard_big_kernel, dim3(nb), dim3(256), 0, c->stream, a, big.p, nbig, estart.p, total);
+    PFP_HIP(hipGetLastError());
+    sync(c);
+  }
 }
 
 // ------------------------------------------------------------------ output packing

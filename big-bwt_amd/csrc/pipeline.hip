@@ -155,6 +155,7 @@ static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, 
     bo.d_bwt = d_bwt; bo.d_sa = d_sa;
     merge_bwt(c, ch.D, ch.ix, ch.so, ch.pb, ch.occ_lex.p, w, flags, ch.n_used + 1, bo);
     st.hard_groups = bo.hard_groups; st.hard_chars = bo.hard_chars;
+    st.hard_big_groups = bo.hard_big_groups; st.hard_max_chars = bo.hard_max_chars; st.hard_max_members = bo.hard_max_members;
   }
   sync(c);
   st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -56,7 +56,9 @@ class _BwtResult(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n", C.c_uint64), ("n_phrases", C.c_uint64), ("n_words", C.c_uint64), ("dict_size", C.c_uint64),
                 ("sa_rounds_dict", C.c_uint64), ("sa_rounds_parse", C.c_uint64),
-                ("hard_groups", C.c_uint64), ("hard_chars", C.c_uint64), ("hash_reseeds", C.c_uint64),
+                ("hard_groups", C.c_uint64), ("hard_chars", C.c_uint64),
+                ("hard_big_groups", C.c_uint64), ("hard_max_chars", C.c_uint64), ("hard_max_members", C.c_uint64),
+                ("hash_reseeds", C.c_uint64),
                 ("extra_triggers", C.c_uint64),
                 ("ms_scan", C.c_double), ("ms_phrases", C.c_double), ("ms_sa_dict", C.c_double),
                 ("ms_sa_parse", C.c_double), ("ms_merge", C.c_double), ("ms_total", C.c_double)]

@@ -139,6 +139,7 @@ typedef struct {
   uint64_t n, n_phrases, n_words, dict_size;
   uint64_t sa_rounds_dict, sa_rounds_parse;
   uint64_t hard_groups, hard_chars;
+  uint64_t hard_big_groups, hard_max_chars, hard_max_members;
   uint64_t hash_reseeds;
   uint64_t extra_triggers;   /* window hashes added by the fused chain to split giant phrases */
   double ms_scan, ms_phrases, ms_sa_dict, ms_sa_parse, ms_merge, ms_total; /* host wall, synced */
