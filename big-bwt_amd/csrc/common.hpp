@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <map>
 #include "../../include/pfpgpu.h"
 
 namespace pfp {
@@ -90,9 +91,43 @@ struct pfp_pool {
   }
 };
 
+// Per-kernel timing with HIP events on the context's own stream (bench.py's roofline leg):
+// every instrumented launch is bracketed by two events; pfp_get_kernel_trace resolves them.
+struct pfp_ktrace {
+  struct Pending { const char *name; uint64_t bytes; hipEvent_t a, b; };
+  struct Agg { uint64_t launches = 0; double ms = 0; uint64_t bytes = 0; };
+  bool on = false;
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+  std::map<std::string, Agg> agg;
+  hipEvent_t get() {
+    if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void resolve() {   // caller has synchronised the stream
+    for (auto &p : pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        Agg &g = agg[p.name];
+        g.launches++; g.ms += ms; g.bytes += p.bytes;
+      }
+      free_events.push_back(p.a); free_events.push_back(p.b);
+    }
+    pending.clear();
+  }
+  void destroy() {
+    for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : free_events) (void)hipEventDestroy(e);
+    pending.clear(); free_events.clear(); agg.clear();
+  }
+};
+
 struct pfp_ctx {
   int device = 0;
   pfp_pool pool;
+  pfp_ktrace kt;
   bool debug = false;             // PFP_DEBUG=1: validate every intermediate on the host
   uint64_t max_phrase = 1u << 15; // fused chain: split phrases longer than this with extra triggers (0 = off)
   hipStream_t stream = nullptr;
@@ -162,6 +197,20 @@ inline T read_scalar(pfp_ctx *c, const T *dptr) {
   memcpy(&v, c->h_scalars, sizeof(T));
   return v;
 }
+
+// brackets the launches issued in its scope with two events (no-op unless tracing is on);
+// algo_bytes = algorithmic bytes of those launches (DESIGN.md lists the formula per kernel)
+struct KScope {
+  pfp_ctx *c; size_t idx = (size_t)-1;
+  KScope(pfp_ctx *ctx, const char *name, uint64_t algo_bytes) : c(ctx) {
+    if (!c->kt.on) return;
+    pfp_ktrace::Pending p{name, algo_bytes, c->kt.get(), c->kt.get()};
+    (void)hipEventRecord(p.a, c->stream);
+    idx = c->kt.pending.size();
+    c->kt.pending.push_back(p);
+  }
+  ~KScope() { if (idx != (size_t)-1) (void)hipEventRecord(c->kt.pending[idx].b, c->stream); }
+};
 
 struct PhaseTimer {
   pfp_ctx *c; double *slot; std::chrono::steady_clock::time_point t0;

@@ -413,12 +413,15 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   DBuf<uint64_t> off(c, N + 1);
   PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream));
   hard.zero();
+  { KScope ks(c, "pfp::posrec_kernel", N * (1 + 4 + 4 + 4 + 16));
   hipLaunchKernelGGL(posrec_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, d, w, ix.pos_word.p,
-                     ix.endpos.p, so.rank.p, D.wocc.p, posrec.p);
+                     ix.endpos.p, so.rank.p, D.wocc.p, posrec.p); }
+  { KScope ks(c, "pfp::slot_gather_kernel", N * (4 + 16 + 13));
   hipLaunchKernelGGL(slot_gather_kernel, dim3(cdiv(cdiv64(N, 8), 256)), dim3(256), 0, c->stream, N, so.sa.p, posrec.p,
-                     wistart.p, cnt.p, pc.p, grp.p, ist.p);
+                     wistart.p, cnt.p, pc.p, grp.p, ist.p); }
   exclusive_sum_u32_u64(c, cnt.p, off.p, N + 1);
-  hipLaunchKernelGGL(group_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, grp.p, pc.p, flags ? 1 : 0, hard.p);
+  { KScope ks(c, "pfp::group_flags_kernel", N * 5);
+  hipLaunchKernelGGL(group_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, grp.p, pc.p, flags ? 1 : 0, hard.p); }
   const uint64_t n_out = read_scalar(c, off.p + N);
   PFP_REQUIRE(expect_n_out == 0 || n_out == expect_n_out, PFP_EFORMAT,
               "merge: sum of occurrence counts (" + std::to_string(n_out) + ") != text length + 1 (" +
@@ -438,13 +441,16 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     const uint32_t nblk = (uint32_t)cdiv64(N, kSlots);
     DBuf<uint32_t> heavy(c, nblk), nheavy(c, 1);
     nheavy.zero();
-    hipLaunchKernelGGL(expand_kernel, dim3(nblk), dim3(256), 0, c->stream, a, heavy.p, nheavy.p, nblk);
+    { KScope ks(c, "pfp::expand_kernel", N * 14 + n_out * (flags ? 17 : 1));
+    hipLaunchKernelGGL(expand_kernel, dim3(nblk), dim3(256), 0, c->stream, a, heavy.p, nheavy.p, nblk); }
     const uint32_t nh = read_scalar(c, nheavy.p);
+    KScope ks2(c, "pfp::expand_heavy_kernel", 0);   // bytes are accounted in expand_kernel's n_out term
     if (nh) hipLaunchKernelGGL(expand_heavy_kernel, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, heavy.p, nh);
   }
   for (;;) {
-    hipLaunchKernelGGL(hard_groups_kernel, dim3((int)std::min<uint64_t>(cdiv64(N, 256), (uint64_t)c->n_cu * 8)), dim3(256), 0,
-                       c->stream, a, hstats.p, big.p, big_cap);
+    { KScope ks(c, "pfp::hard_groups_kernel", N * 5);
+      hipLaunchKernelGGL(hard_groups_kernel, dim3((int)std::min<uint64_t>(cdiv64(N, 256), (uint64_t)c->n_cu * 8)), dim3(256), 0,
+                         c->stream, a, hstats.p, big.p, big_cap); }
     PFP_HIP(hipGetLastError());
     PFP_HIP(hipMemcpyAsync(c->h_scalars, hstats.p, 40, hipMemcpyDeviceToHost, c->stream));
     sync(c);

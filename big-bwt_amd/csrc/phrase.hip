@@ -31,11 +31,12 @@ __device__ __forceinline__ uint64_t ph_start(const PhraseGeom &g, uint64_t k) { 
   return k == 0 ? 0 : g.ends[k - 1] + 2 - (uint64_t)g.w;
 }
 
+// One term of the commutative phrase hash.  The chunk is XORed with a position key and pushed
+// through a full-avalanche finaliser (two multiplies, three xor-shifts): with a single multiply the
+// top byte of a chunk only reaches the top byte of the term, and two SNPs that both fall in the
+// last byte of their 8-byte chunks then cancel with probability ~2^-8 (seen on 16 mutated copies).
 __device__ __forceinline__ uint64_t chunk_term(uint64_t x, uint64_t idx, uint64_t seed) {
-  uint64_t t = x ^ (seed + idx * 0x9E3779B97F4A7C15ULL);
-  t *= 0xD6E8FEB86659FD93ULL;
-  t ^= t >> 32;
-  return t;
+  return fmix64(x ^ (seed + idx * 0x9E3779B97F4A7C15ULL));
 }
 // contribution of the 16-byte piece at byte offset off of a phrase of length len
 __device__ __forceinline__ uint64_t piece_terms(const uint8_t *src, uint64_t off, uint64_t len, uint64_t seed) {
@@ -242,8 +243,9 @@ void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const
   uint32_t d = 0;
   for (int attempt = 0;; attempt++) {
     counters.zero();
+    { KScope kscope(c, "pfp::phrase_hash_kernel", n + (uint64_t)w * P + 16 * P);
     hipLaunchKernelGGL(phrase_hash_kernel, dim3(cdiv(P * 8, TB)), dim3(TB), 0, c->stream, tp, g, P, seed, hash.p,
-                       long_list.p, counters.p);
+                       long_list.p, counters.p); }
     uint32_t nlong = read_scalar(c, counters.p);
     if (nlong) {
       DBuf<unsigned long long> hsum(c, nlong);
@@ -254,8 +256,9 @@ void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const
                          nlong, hsum.p, hash.p);
     }
     sort_pairs_u64_u32(c, hash.p, ks.p, iota.p, vs.p, P, 0, 64);
+    { KScope kscope(c, "pfp::dedup_verify_kernel", 2 * (n + (uint64_t)w * P) + 16 * P);
     hipLaunchKernelGGL(dedup_verify_kernel, dim3(cdiv(P * 8, TB)), dim3(TB), 0, c->stream, tp, g, P, ks.p, vs.p, head.p,
-                       counters.p + 1);
+                       counters.p + 1); }
     inclusive_sum_u32(c, head.p, hscan.p, P);
     PFP_HIP(hipGetLastError());
     PFP_HIP(hipMemcpyAsync(c->h_scalars, counters.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
@@ -264,6 +267,32 @@ void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const
     uint32_t coll; memcpy(&coll, c->h_scalars, 4);
     memcpy(&d, c->h_scalars + 1, 4);
     if (!coll) break;
+    if (c->debug) {   // PFP_DEBUG: describe the first offending pair on the host
+      std::vector<uint64_t> hk(P), he(n_ends);
+      std::vector<uint32_t> hv(P);
+      PFP_HIP(hipMemcpy(hk.data(), ks.p, P * 8, hipMemcpyDeviceToHost));
+      PFP_HIP(hipMemcpy(hv.data(), vs.p, P * 4, hipMemcpyDeviceToHost));
+      PFP_HIP(hipMemcpy(he.data(), ends.p, n_ends * 8, hipMemcpyDeviceToHost));
+      std::vector<uint8_t> ht(n + w + 1);
+      PFP_HIP(hipMemcpy(ht.data(), tp, n + w + 1, hipMemcpyDeviceToHost));
+      auto pst = [&](uint64_t k) { return k == 0 ? 0 : he[k - 1] + 2 - (uint64_t)w; };
+      auto pen = [&](uint64_t k) { return k < n_ends ? he[k] + 1 : n + (uint64_t)w; };
+      int shown = 0;
+      for (uint64_t i = 1; i < P && shown < 5; i++) {
+        if (hk[i] != hk[i - 1]) continue;
+        uint64_t a = hv[i], b = hv[i - 1];
+        uint64_t sa = pst(a), la = pen(a) - sa + 1, sb = pst(b), lb = pen(b) - sb + 1;
+        bool diff = la != lb || memcmp(&ht[sa], &ht[sb], la) != 0;
+        if (!diff) continue;
+        uint64_t fd = 0; while (fd < la && fd < lb && ht[sa + fd] == ht[sb + fd]) fd++;
+        fprintf(stderr, "PFP_DEBUG collision: i=%llu hash=%016llx a=%llu (start %llu len %llu) b=%llu (start %llu len %llu) first diff at %llu\n",
+                (unsigned long long)i, (unsigned long long)hk[i], (unsigned long long)a, (unsigned long long)sa,
+                (unsigned long long)la, (unsigned long long)b, (unsigned long long)sb, (unsigned long long)lb,
+                (unsigned long long)fd);
+        shown++;
+      }
+      if (!shown) fprintf(stderr, "PFP_DEBUG collision flag set but no offending pair found on the host (verify kernel false positive)\n");
+    }
     PFP_REQUIRE(attempt < 3, PFP_ECOLLISION, "phrase hash collision survived 4 seeds (newscan.cpp:282-286)");
     seed = seed * 0x9E3779B97F4A7C15ULL + 0x7F4A7C15ULL;
     D.reseeds++;

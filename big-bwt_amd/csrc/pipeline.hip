@@ -271,6 +271,7 @@ void pfp_ctx_destroy(pfp_ctx *c) {
   delete staged_of(c);
   delete reinterpret_cast<K1Scratch *>(c->k1scratch);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->kt.destroy();
   c->pool.destroy();
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -281,6 +282,30 @@ const char *pfp_last_error(const pfp_ctx *c) { return c ? c->err.c_str() : "null
 void *pfp_ctx_stream(pfp_ctx *c) { return c ? (void *)c->stream : nullptr; }
 void pfp_free(void *p) { free(p); }
 void pfp_set_profiling(pfp_ctx *c, int on) { if (c) c->profiling = on != 0; }
+void pfp_set_kernel_trace(pfp_ctx *c, int on) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->kt.resolve();
+  c->kt.agg.clear();
+  c->kt.on = on != 0;
+}
+int pfp_get_kernel_trace(pfp_ctx *c, pfp_kernel_stat *out, int cap) {
+  if (!c) return PFP_EINVAL;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->kt.resolve();
+  int k = 0;
+  for (auto &kv : c->kt.agg) {
+    if (out && k < cap) {
+      memset(&out[k], 0, sizeof out[k]);
+      strncpy(out[k].name, kv.first.c_str(), sizeof out[k].name - 1);
+      out[k].launches = kv.second.launches; out[k].total_ms = kv.second.ms; out[k].algo_bytes = kv.second.bytes;
+    }
+    k++;
+  }
+  return k;
+}
 void pfp_set_max_phrase(pfp_ctx *c, uint64_t max_phrase) { if (c) c->max_phrase = max_phrase; }
 int pfp_get_stats(const pfp_ctx *c, pfp_stats *st) {
   if (!c || !st) return PFP_EINVAL;

@@ -208,6 +208,7 @@ void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p,
   uint64_t nchunks = cdiv64(n, 16);
   int nblocks = (int)cdiv64(nchunks, 256);
   if (nblocks == 0) return;
+  KScope ks(c, "pfp::kr_flag_kernel", n + n / 8);
   switch (w) {
 #define CASE(W) case W: launch_flag<W>(c, nblocks, tbase, n, kp, flags16, block_counts, first_bad); break;
     CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17)
@@ -252,6 +253,7 @@ uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t
       continue;
     }
     d_ends.alloc(c, (size_t)total + 1);
+    KScope ks(c, "pfp::kr_compact_kernel", nchunks * 2 + (uint64_t)total * 8);
     if (total)
       hipLaunchKernelGGL(kr_compact_kernel, dim3(nblocks), dim3(256), 0, c->stream, flags16.p, nchunks, boff.p, d_ends.p);
     PFP_HIP(hipGetLastError());

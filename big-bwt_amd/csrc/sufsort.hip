@@ -172,13 +172,15 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   bool first = true;
   const int keybits = 32 + bits_for(N);
   for (;;) {
-    hipLaunchKernelGGL(heads_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p);
+    { KScope ks(c, "pfp::heads_kernel", m * 17);
+    hipLaunchKernelGGL(heads_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p); }
     inclusive_max_u32(c, hv.p, newhead.p, m);
     const bool round0 = first && ones != 0;
     first = false;
+    { KScope ks(c, "pfp::write_back_kernel", m * (13 + (round0 ? 8 : 4) + 9));
     hipLaunchKernelGGL(write_back_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p,
                        newhead.p, hd.p, round0 ? keyo.p : (const uint64_t *)nullptr, ones, highs, out.sa.p,
-                       out.rank.p, keep.p);
+                       out.rank.p, keep.p); }
     select_flagged_u32(c, aslot.p, keep.p, aslot2.p, cnt.p, m);
     PFP_HIP(hipGetLastError());
     uint32_t m2 = read_scalar(c, cnt.p);
@@ -186,8 +188,9 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     m = m2;
     if (m == 0) break;
     PFP_REQUIRE(h < 2 * N, PFP_EHIP, "suffix sort failed to converge");
+    { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 4 + 4 + 4 + 12));
     hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, out.sa.p,
-                       out.rank.p, key.p, val.p);
+                       out.rank.p, key.p, val.p); }
     sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, keybits);
     h *= 2;
     out.rounds++;
@@ -218,7 +221,8 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   for (int f = 0; f < kp.cpk; f++) { kp.ones |= 1ull << (f * kp.bits); kp.highs |= 1ull << (f * kp.bits + kp.bits - 1); }
   DBuf<uint64_t> key(c, N);
   DBuf<uint32_t> val(c, N);
-  hipLaunchKernelGGL(init_keys_packed_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kp, key.p, val.p);
+  { KScope ks(c, "pfp::init_keys_packed_kernel", N * 13);
+    hipLaunchKernelGGL(init_keys_packed_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kp, key.p, val.p); }
   doubling(c, g, key, val, (uint64_t)kp.cpk, out, kp.bits * kp.cpk, kp.ones, kp.highs);
 }
 

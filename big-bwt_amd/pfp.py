@@ -30,7 +30,7 @@ ERRORS = {0: "PFP_OK", -1: "PFP_EINVAL", -2: "PFP_ENODEV", -3: "PFP_EHIP", -4: "
 SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror", "pfp_version", "pfp_ctx_stream",
            "pfp_free", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak",
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_dev", "pfp_get_stats",
-           "pfp_set_profiling", "pfp_set_max_phrase", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue"]
+           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue"]
 
 
 class PfpError(RuntimeError):
@@ -51,6 +51,10 @@ class _BwtResult(C.Structure):
                 ("sa", C.POINTER(C.c_uint8)), ("sa_bytes", C.c_uint64),
                 ("ssa", C.POINTER(C.c_uint8)), ("ssa_bytes", C.c_uint64),
                 ("esa", C.POINTER(C.c_uint8)), ("esa_bytes", C.c_uint64)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_uint64), ("total_ms", C.c_double), ("algo_bytes", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -94,6 +98,7 @@ def load_library():
         lib.pfp_free.restype = None
         lib.pfp_set_profiling.restype = None
         lib.pfp_set_max_phrase.restype = None
+        lib.pfp_set_kernel_trace.restype = None
         lib.pfp_parse_result_free.restype = None
         lib.pfp_bwt_result_free.restype = None
         _lib = lib
@@ -171,6 +176,20 @@ class Context:
 
     def set_profiling(self, on=True):
         self.lib.pfp_set_profiling(self._h, C.c_int(1 if on else 0))
+
+    def set_kernel_trace(self, on=True):
+        """start (and clear) / stop per-kernel HIP-event timing on the ctx stream"""
+        self.lib.pfp_set_kernel_trace(self._h, C.c_int(1 if on else 0))
+
+    def kernel_trace(self):
+        """rows {name, launches, total_ms, algo_bytes} accumulated since set_kernel_trace(True)"""
+        n = self.lib.pfp_get_kernel_trace(self._h, None, C.c_int(0))
+        if n <= 0:
+            return []
+        arr = (KernelStat * n)()
+        self.lib.pfp_get_kernel_trace(self._h, arr, C.c_int(n))
+        return [dict(name=r.name.decode(), launches=int(r.launches), total_ms=float(r.total_ms), algo_bytes=int(r.algo_bytes))
+                for r in arr]
 
     def set_max_phrase(self, max_phrase):
         """fused chain: split phrases longer than this with extra trigger windows (0 = reference parse)"""

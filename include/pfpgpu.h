@@ -147,6 +147,14 @@ typedef struct {
 int pfp_get_stats(const pfp_ctx *ctx, pfp_stats *st);
 /* when set (default 0) every pipeline phase is bracketed by a stream sync so ms_* are filled */
 void pfp_set_profiling(pfp_ctx *ctx, int on);
+/* Per-kernel device times measured with HIP events on the ctx stream.  pfp_set_kernel_trace(ctx,1)
+ * clears the table and starts recording; pfp_get_kernel_trace synchronises, resolves the events
+ * and returns the number of rows (rows beyond cap are counted, not written).  algo_bytes is the
+ * sum over the launches of the kernel's algorithmic bytes (DESIGN.md "kernels"). */
+typedef struct { char name[64]; uint64_t launches; double total_ms; uint64_t algo_bytes; } pfp_kernel_stat;
+void pfp_set_kernel_trace(pfp_ctx *ctx, int on);
+int pfp_get_kernel_trace(pfp_ctx *ctx, pfp_kernel_stat *out, int cap);
+
 /* Fused chain only (pfp_bigbwt / pfp_bigbwt_dev): phrases longer than max_phrase bytes are split
  * by adding a few extra trigger windows taken from inside them (default 32768; 0 = parse exactly
  * as the reference does).  The .bwt/.sa/.ssa/.esa outputs do not depend on the parse

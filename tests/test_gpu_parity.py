@@ -147,6 +147,17 @@ def test_special_byte_truncates_like_reference(O, ctx):
     assert np.array_equal(got["bwt"], want["bwt"]) and len(got["bwt"]) == 12346
 
 
+def test_many_snp_variants_do_not_collide(O, pkg, ctx):
+    """48 copies at 1 % SNP rate: thousands of phrase variants that differ in two bytes.  A weak
+    phrase hash (high chunk byte reaching only the top byte of the term) produced verified
+    collisions on exactly this shape; the dedup must stay exact and need no reseed."""
+    text = O.gen_fasta(100000, 48, 0.01, 77)
+    got = ctx.bigbwt(text, 10, 100, pkg.FLAG_SA)
+    assert ctx.stats()["hash_reseeds"] == 0
+    want = O.bigbwt(text, 10, 100, O.FLAG_SA)
+    assert np.array_equal(got["bwt"], want["bwt"]) and np.array_equal(pkg.unpack5(got["sa"]), want["sa"])
+
+
 def test_mid_size_against_oracle(O, pkg, ctx):
     """~24 MB, 8 near-identical copies: every output against the oracle."""
     text = O.gen_fasta(3000000, 8, 0.001, 31)
