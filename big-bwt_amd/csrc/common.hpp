@@ -139,6 +139,7 @@ struct pfp_ctx {
   uint64_t *h_scalars = nullptr;  // 16 x u64, pinned
   void *staged = nullptr;         // pfp::StagedText kept by pfp_stage_text_dev
   void *k1scratch = nullptr;      // scratch of pfp_scan_k1_enqueue
+  void *dist = nullptr;           // DistState of the multi-GPU entry points
 };
 
 namespace pfp {

@@ -52,6 +52,12 @@ struct Dictionary {
 };
 void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const DBuf<uint64_t> &ends, uint64_t n_ends,
                       bool want_sai, Dictionary &D);
+// multi-GPU: a shard owns phrases [k0,k0+P) of its local scan; sai values are shifted by sai_base
+void build_dictionary_shard(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const DBuf<uint64_t> &ends,
+                            uint64_t n_ends, uint64_t k0, uint64_t P, bool want_sai, uint64_t sai_base, Dictionary &D);
+// multi-GPU: dictionary of a union of word lists; D.pid[u] = id of union word u, occ = sum of weights
+void build_dictionary_words(pfp_ctx *c, const uint8_t *bytes, const uint64_t *wstart, const uint32_t *wlen, uint64_t U,
+                            const uint32_t *weight, uint64_t total_bytes, Dictionary &D);
 // dictionary from a reference-format .dict/.occ pair already in device memory
 void dictionary_from_bytes(pfp_ctx *c, Dictionary &D);
 
@@ -97,8 +103,10 @@ struct BwtOutputs {
   uint64_t *d_sa = nullptr;    // [n+1] device, caller-provided when flags != 0
   uint64_t hard_groups = 0, hard_chars = 0, hard_big_groups = 0, hard_max_chars = 0, hard_max_members = 0;
 };
+// emits BWT positions [out_lo,out_hi) into out.d_bwt[0..) / out.d_sa[0..) (default: everything)
 void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, const ParseBWT &pb,
-               const uint32_t *occ_lex, int w, int flags, uint64_t expect_n_out, BwtOutputs &out);
+               const uint32_t *occ_lex, int w, int flags, uint64_t expect_n_out, BwtOutputs &out, uint64_t out_lo = 0,
+               uint64_t out_hi = ~0ull);
 
 // 5-byte packing and run sampling of finished device outputs
 void pack5_dev(pfp_ctx *c, const uint64_t *vals, uint64_t cnt, uint8_t *out5);

@@ -194,6 +194,7 @@ __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank,
 
 struct MergeArgs {
   uint64_t N, n_out; uint32_t d; int w; int want_sa; int dbg_mode;
+  uint64_t out_lo, out_hi;   // this call emits BWT positions [out_lo,out_hi) only (multi-GPU slices); bwt/out_sa are indexed by global position
   const uint32_t *sa, *endpos, *grp, *ist;
   const uint8_t *pc, *hard; const uint64_t *off;
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
@@ -233,6 +234,7 @@ __device__ __forceinline__ void expand_stage(const MergeArgs &a, ExpandLds &L, u
 // 16 output bytes starting at block-relative offset x0 (< Ltot)
 __device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
                                           uint64_t x0, uint64_t Ltot) {
+  if (base + x0 + 16 <= a.out_lo || base + x0 >= a.out_hi) return;     // outside this rank's slice
   int lo = 0, hi = ns;                    // loff[lo] <= x0 < loff[hi]
   while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (L.loff[mid] <= x0) lo = mid; else hi = mid; }
   int s = lo;
@@ -246,9 +248,10 @@ __device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L
       while (x >= nxt) { s++; nxt = L.loff[s + 1]; }
       const uint8_t cl = L.lcls[s];
       uint32_t ch = 0;
+      const bool in_slice = base + x >= a.out_lo && base + x < a.out_hi;
       if (cl == CLS_FILL) {
         ch = fix_char(L.lpc[s]);
-        if (a.want_sa) {
+        if (a.want_sa && in_slice) {
           const uint32_t i = a.sa[t0 + s];
           const uint64_t pos = a.ilist[a.ist[t0 + s] + (uint32_t)(x - L.loff[s])];
           a.out_sa[base + x] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
@@ -256,7 +259,7 @@ __device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L
       } else if (cl == CLS_FULL) {
         const uint64_t pos = a.ilist[a.ist[t0 + s] + (uint32_t)(x - L.loff[s])];
         ch = a.bwlast[pos];
-        if (a.want_sa) {
+        if (a.want_sa && in_slice) {
           const uint32_t i = a.sa[t0 + s];
           a.out_sa[base + x] = (base + x == 0) ? a.n_out - 1 : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
         }
@@ -266,11 +269,12 @@ __device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L
     }
   }
   uint8_t *dst = a.bwt + base + x0;
-  if (nb == 16) st16u(dst, make_uint4(r0, r1, r2, r3));
+  if (nb == 16 && base + x0 >= a.out_lo && base + x0 + 16 <= a.out_hi) st16u(dst, make_uint4(r0, r1, r2, r3));
   else {
     const uint32_t rr[4] = {r0, r1, r2, r3};
 #pragma unroll
-    for (int k = 0; k < 16; k++) if (k < nb) dst[k] = (uint8_t)(rr[k >> 2] >> (8 * (k & 3)));
+    for (int k = 0; k < 16; k++)
+      if (k < nb && base + x0 + k >= a.out_lo && base + x0 + k < a.out_hi) dst[k] = (uint8_t)(rr[k >> 2] >> (8 * (k & 3)));
   }
 }
 
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(256) void expand_kernel(MergeArgs a, uint32_t *__re
   const uint64_t base = a.off[t0];
   expand_stage(a, L, t0, ns, base);
   const uint64_t Ltot = L.loff[ns];
+  if (base + Ltot <= a.out_lo || base >= a.out_hi) return;
   // a block whose slots emit more than the quota (a word with hundreds of thousands of
   // occurrences) finishes only its first quota here; expand_heavy_kernel shares the rest
   const uint64_t mine = Ltot <= kExpandQuota ? Ltot : kExpandQuota;
@@ -339,6 +344,7 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, unsigned 
     }
     const uint64_t base = a.off[g];
     const uint64_t E = a.off[g + k] - base;
+    if (base + E <= a.out_lo || base >= a.out_hi) continue;     // group lies outside this rank's slice
     if (lane == 0) { my_chars += E; my_groups += 1; }
     if (E <= (uint64_t)kHardLds) {
       for (uint32_t m = lane; m < k; m += 64) {          // stage (position, char, suffix length) per occurrence
@@ -356,8 +362,10 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, unsigned 
         const uint32_t pos = lpos[wv][e];
         uint32_t r = 0;
         for (uint32_t q = 0; q < (uint32_t)E; q++) r += lpos[wv][q] < pos;
-        a.bwt[base + r] = lch[wv][e];
-        if (a.want_sa) a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)lsl[wv][e];
+        if (base + r >= a.out_lo && base + r < a.out_hi) {
+          a.bwt[base + r] = lch[wv][e];
+          if (a.want_sa) a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)lsl[wv][e];
+        }
       }
       __builtin_amdgcn_wave_barrier();
     } else if (lane == 0) {     // too large for LDS: queued for hard_big_kernel (whole-grid, one thread per occurrence)
@@ -393,13 +401,16 @@ __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgs a, const BigGro
       while (l2 < h2) { uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
       r += l2;
     }
-    a.bwt[base + r] = fix_char(a.pc[t]);
-    if (a.want_sa) { const uint32_t i = a.sa[t]; a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i); }
+    if (base + r >= a.out_lo && base + r < a.out_hi) {
+      a.bwt[base + r] = fix_char(a.pc[t]);
+      if (a.want_sa) { const uint32_t i = a.sa[t]; a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i); }
+    }
   }
 }
 
 void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, const ParseBWT &pb,
-               const uint32_t *occ_lex, int w, int flags, uint64_t expect_n_out, BwtOutputs &out) {
+               const uint32_t *occ_lex, int w, int flags, uint64_t expect_n_out, BwtOutputs &out, uint64_t out_lo,
+               uint64_t out_hi) {
   const uint64_t N = D.dsize;
   const uint32_t d = (uint32_t)D.d;
   PFP_REQUIRE(!flags || pb.bwsai.p, PFP_EINVAL, "SA output requested without sa info");
@@ -432,7 +443,10 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
   a.sa = so.sa.p; a.endpos = ix.endpos.p; a.grp = grp.p; a.ist = ist.p;
   a.pc = pc.p; a.hard = hard.p; a.off = off.p;
-  a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p; a.bwt = out.d_bwt; a.out_sa = out.d_sa;
+  a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p;
+  // the caller's buffers hold positions [out_lo, out_hi): rebase so that kernels index by global position
+  a.out_lo = out_lo; a.out_hi = out_hi < n_out ? out_hi : n_out;
+  a.bwt = out.d_bwt - out_lo; a.out_sa = out.d_sa ? out.d_sa - out_lo : nullptr;
   DBuf<unsigned long long> hstats(c, 5);
   hstats.zero();
   uint32_t big_cap = 1u << 16;

@@ -21,13 +21,22 @@ namespace pfp {
 
 constexpr uint32_t kLongPhrase = 8192;  // phrases longer than this are split across blocks
 
+// Where phrase k lives.  Implicit mode: phrase k0+k of the scan (ends[], overlap w) - k0 > 0 lets a
+// text shard own only the phrases that END inside it (multi-GPU).  Explicit mode (xstart != null):
+// an arbitrary word list over a byte buffer (the union of the ranks' local dictionaries).
 struct PhraseGeom {
   const uint64_t *ends; uint64_t ne; uint64_t n; int w;
+  uint64_t k0;
+  const uint64_t *xstart; const uint32_t *xlen;
 };
-__device__ __forceinline__ uint64_t ph_end(const PhraseGeom &g, uint64_t k) {   // T' index of last byte
+__device__ __forceinline__ uint64_t ph_end(const PhraseGeom &g, uint64_t k) {   // index of last byte
+  if (g.xstart) return g.xstart[k] + g.xlen[k] - 1;
+  k += g.k0;
   return k < g.ne ? g.ends[k] + 1 : g.n + (uint64_t)g.w;
 }
-__device__ __forceinline__ uint64_t ph_start(const PhraseGeom &g, uint64_t k) { // T' index of first byte
+__device__ __forceinline__ uint64_t ph_start(const PhraseGeom &g, uint64_t k) { // index of first byte
+  if (g.xstart) return g.xstart[k];
+  k += g.k0;
   return k == 0 ? 0 : g.ends[k - 1] + 2 - (uint64_t)g.w;
 }
 
@@ -146,8 +155,16 @@ __global__ void collect_words_kernel(uint64_t P, const uint32_t *__restrict__ he
   hpos[hw] = (uint32_t)i;
 }
 
+// weighted occurrence counts (explicit mode): occ of a distinct word = sum of the weights of its copies
+__global__ void weighted_occ_kernel(uint64_t P, const uint32_t *__restrict__ hscan, const uint32_t *__restrict__ vs,
+                                    const uint32_t *__restrict__ weight, uint32_t *__restrict__ hocc) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P) atomicAdd(&hocc[hscan[i] - 1], weight[vs[i]]);
+}
+
 __global__ void finish_words_kernel(PhraseGeom g, uint32_t d, const uint32_t *__restrict__ rep_sorted,
                                     const uint32_t *__restrict__ hw_sorted, const uint32_t *__restrict__ hpos,
+                                    const uint32_t *__restrict__ hocc,
                                     uint32_t *__restrict__ fo_of_hw, uint32_t *__restrict__ wlen,
                                     uint32_t *__restrict__ wlen1, uint64_t *__restrict__ wsrc,
                                     uint32_t *__restrict__ wocc, uint32_t *__restrict__ toolong) {
@@ -162,7 +179,7 @@ __global__ void finish_words_kernel(PhraseGeom g, uint32_t d, const uint32_t *__
   wlen[j] = (uint32_t)len;
   wlen1[j] = (uint32_t)len + 1;
   wsrc[j] = s;
-  wocc[j] = hpos[hw + 1] - hpos[hw];
+  wocc[j] = hocc ? hocc[hw] : hpos[hw + 1] - hpos[hw];
 }
 
 __global__ void assign_pid_kernel(uint64_t P, const uint32_t *__restrict__ hscan, const uint32_t *__restrict__ vs,
@@ -218,21 +235,23 @@ __global__ __launch_bounds__(256) void dict_copy_long_kernel(const uint8_t *__re
 }
 
 // .last (newscan.cpp:296) and .sai (newscan.cpp:298-301)
-__global__ void last_sai_kernel(const uint8_t *__restrict__ tp, PhraseGeom g, uint64_t P, uint8_t *__restrict__ last,
-                                uint64_t *__restrict__ sai) {
+__global__ void last_sai_kernel(const uint8_t *__restrict__ tp, PhraseGeom g, uint64_t P, uint64_t sai_base,
+                                uint8_t *__restrict__ last, uint64_t *__restrict__ sai) {
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P) return;
   uint64_t e = ph_end(g, k);
   last[k] = tp[e - (uint64_t)g.w];
-  if (sai) sai[k] = e;
+  if (sai) sai[k] = e + sai_base;
 }
 
-void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const DBuf<uint64_t> &ends, uint64_t n_ends,
-                      bool want_sai, Dictionary &D) {
-  const uint64_t P = n_ends + 1;
-  PFP_REQUIRE(P <= 0xFFFFFFFEull, PFP_ELIMIT, "parse has more than 2^32-2 phrases (bwtparse.c:93); use a larger -p");
-  PhraseGeom g{ends.p, n_ends, n, w};
-  const uint8_t *tp = tx.tprime();
+// Core of the dictionary build over any phrase geometry.  weight == nullptr: every phrase counts
+// once; otherwise occ of a distinct word is the sum of its copies' weights.  hbytes = total bytes
+// the phrases cover (for the kernel-trace byte accounting only).
+static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, uint64_t P, const uint32_t *weight,
+                                  uint64_t hbytes, bool want_last, bool want_sai, uint64_t sai_base, Dictionary &D) {
+  PFP_REQUIRE(P >= 1 && P <= 0xFFFFFFFEull, PFP_ELIMIT,
+              "parse has more than 2^32-2 phrases (bwtparse.c:93); use a larger -p");
+  const uint64_t n = hbytes;
   D.P = P;
   const int TB = 256;
   DBuf<uint64_t> hash(c, P), ks(c, P);
@@ -243,7 +262,7 @@ void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const
   uint32_t d = 0;
   for (int attempt = 0;; attempt++) {
     counters.zero();
-    { KScope kscope(c, "pfp::phrase_hash_kernel", n + (uint64_t)w * P + 16 * P);
+    { KScope kscope(c, "pfp::phrase_hash_kernel", n + 16 * P);
     hipLaunchKernelGGL(phrase_hash_kernel, dim3(cdiv(P * 8, TB)), dim3(TB), 0, c->stream, tp, g, P, seed, hash.p,
                        long_list.p, counters.p); }
     uint32_t nlong = read_scalar(c, counters.p);
@@ -256,7 +275,7 @@ void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const
                          nlong, hsum.p, hash.p);
     }
     sort_pairs_u64_u32(c, hash.p, ks.p, iota.p, vs.p, P, 0, 64);
-    { KScope kscope(c, "pfp::dedup_verify_kernel", 2 * (n + (uint64_t)w * P) + 16 * P);
+    { KScope kscope(c, "pfp::dedup_verify_kernel", 2 * n + 16 * P);
     hipLaunchKernelGGL(dedup_verify_kernel, dim3(cdiv(P * 8, TB)), dim3(TB), 0, c->stream, tp, g, P, ks.p, vs.p, head.p,
                        counters.p + 1); }
     inclusive_sum_u32(c, head.p, hscan.p, P);
@@ -267,32 +286,6 @@ void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const
     uint32_t coll; memcpy(&coll, c->h_scalars, 4);
     memcpy(&d, c->h_scalars + 1, 4);
     if (!coll) break;
-    if (c->debug) {   // PFP_DEBUG: describe the first offending pair on the host
-      std::vector<uint64_t> hk(P), he(n_ends);
-      std::vector<uint32_t> hv(P);
-      PFP_HIP(hipMemcpy(hk.data(), ks.p, P * 8, hipMemcpyDeviceToHost));
-      PFP_HIP(hipMemcpy(hv.data(), vs.p, P * 4, hipMemcpyDeviceToHost));
-      PFP_HIP(hipMemcpy(he.data(), ends.p, n_ends * 8, hipMemcpyDeviceToHost));
-      std::vector<uint8_t> ht(n + w + 1);
-      PFP_HIP(hipMemcpy(ht.data(), tp, n + w + 1, hipMemcpyDeviceToHost));
-      auto pst = [&](uint64_t k) { return k == 0 ? 0 : he[k - 1] + 2 - (uint64_t)w; };
-      auto pen = [&](uint64_t k) { return k < n_ends ? he[k] + 1 : n + (uint64_t)w; };
-      int shown = 0;
-      for (uint64_t i = 1; i < P && shown < 5; i++) {
-        if (hk[i] != hk[i - 1]) continue;
-        uint64_t a = hv[i], b = hv[i - 1];
-        uint64_t sa = pst(a), la = pen(a) - sa + 1, sb = pst(b), lb = pen(b) - sb + 1;
-        bool diff = la != lb || memcmp(&ht[sa], &ht[sb], la) != 0;
-        if (!diff) continue;
-        uint64_t fd = 0; while (fd < la && fd < lb && ht[sa + fd] == ht[sb + fd]) fd++;
-        fprintf(stderr, "PFP_DEBUG collision: i=%llu hash=%016llx a=%llu (start %llu len %llu) b=%llu (start %llu len %llu) first diff at %llu\n",
-                (unsigned long long)i, (unsigned long long)hk[i], (unsigned long long)a, (unsigned long long)sa,
-                (unsigned long long)la, (unsigned long long)b, (unsigned long long)sb, (unsigned long long)lb,
-                (unsigned long long)fd);
-        shown++;
-      }
-      if (!shown) fprintf(stderr, "PFP_DEBUG collision flag set but no offending pair found on the host (verify kernel false positive)\n");
-    }
     PFP_REQUIRE(attempt < 3, PFP_ECOLLISION, "phrase hash collision survived 4 seeds (newscan.cpp:282-286)");
     seed = seed * 0x9E3779B97F4A7C15ULL + 0x7F4A7C15ULL;
     D.reseeds++;
@@ -300,6 +293,12 @@ void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const
   D.d = d;
   // words in first-occurrence order
   DBuf<uint32_t> hrep(c, d), hpos(c, (size_t)d + 1), hwi(c, d), rep_sorted(c, d), hw_sorted(c, d), fo_of_hw(c, d);
+  DBuf<uint32_t> hocc;
+  if (weight) {
+    hocc.alloc(c, d);
+    hocc.zero();
+    hipLaunchKernelGGL(weighted_occ_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, P, hscan.p, vs.p, weight, hocc.p);
+  }
   hipLaunchKernelGGL(collect_words_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, P, head.p, hscan.p, vs.p, hrep.p,
                      hpos.p, d);
   hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, hwi.p, (uint64_t)d);
@@ -308,7 +307,8 @@ void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const
   DBuf<uint32_t> wlen1(c, (size_t)d + 1);
   DBuf<uint64_t> wsrc(c, d);
   hipLaunchKernelGGL(finish_words_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, g, d, rep_sorted.p, hw_sorted.p,
-                     hpos.p, fo_of_hw.p, D.wlen.p, wlen1.p, wsrc.p, D.wocc.p, counters.p + 2);
+                     hpos.p, weight ? hocc.p : (const uint32_t *)nullptr, fo_of_hw.p, D.wlen.p, wlen1.p, wsrc.p, D.wocc.p,
+                     counters.p + 2);
   hipLaunchKernelGGL(assign_pid_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, P, hscan.p, vs.p, fo_of_hw.p, D.pid.p);
   exclusive_sum_u32_u64(c, wlen1.p, D.woff.p, (size_t)d + 1);
   PFP_HIP(hipMemcpyAsync(c->h_scalars, D.woff.p + d, 8, hipMemcpyDeviceToHost, c->stream));
@@ -326,11 +326,33 @@ void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const
   if (nlongw)
     hipLaunchKernelGGL(dict_copy_long_kernel, dim3(c->n_cu * 4), dim3(TB), 0, c->stream, tp, wsrc.p, D.wlen.p, D.woff.p,
                        D.bytes.p, long_list.p, nlongw);
-  D.last.alloc(c, P);
-  if (want_sai) D.sai.alloc(c, P);
-  hipLaunchKernelGGL(last_sai_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, tp, g, P, D.last.p,
-                     want_sai ? D.sai.p : (uint64_t *)nullptr);
+  if (want_last) {
+    D.last.alloc(c, P);
+    if (want_sai) D.sai.alloc(c, P);
+    hipLaunchKernelGGL(last_sai_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, tp, g, P, sai_base, D.last.p,
+                       want_sai ? D.sai.p : (uint64_t *)nullptr);
+  }
   PFP_HIP(hipGetLastError());
+}
+
+void build_dictionary(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const DBuf<uint64_t> &ends, uint64_t n_ends,
+                      bool want_sai, Dictionary &D) {
+  PhraseGeom g{ends.p, n_ends, n, w, 0, nullptr, nullptr};
+  build_dictionary_core(c, tx.tprime(), g, n_ends + 1, nullptr, n + (uint64_t)w * (n_ends + 1), true, want_sai, 0, D);
+}
+
+// a text shard owning phrases [k0, k0+P) of its local scan (multi-GPU); sai values shifted to global positions
+void build_dictionary_shard(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, const DBuf<uint64_t> &ends,
+                            uint64_t n_ends, uint64_t k0, uint64_t P, bool want_sai, uint64_t sai_base, Dictionary &D) {
+  PhraseGeom g{ends.p, n_ends, n, w, k0, nullptr, nullptr};
+  build_dictionary_core(c, tx.tprime(), g, P, nullptr, n + (uint64_t)w * P, true, want_sai, sai_base, D);
+}
+
+// union of word lists (each word `weight` times): the global dictionary of a multi-GPU run
+void build_dictionary_words(pfp_ctx *c, const uint8_t *bytes, const uint64_t *wstart, const uint32_t *wlen, uint64_t U,
+                            const uint32_t *weight, uint64_t total_bytes, Dictionary &D) {
+  PhraseGeom g{nullptr, 0, 0, 0, 0, wstart, wlen};
+  build_dictionary_core(c, bytes, g, U, weight, total_bytes, false, false, 0, D);
 }
 
 }  // namespace pfp

@@ -264,10 +264,12 @@ int pfp_ctx_create(pfp_ctx **out, int device) {
 struct K1Scratch { pfp::DBuf<uint16_t> flags; pfp::DBuf<uint32_t> bcnt; pfp::DBuf<unsigned long long> fbad; uint64_t n = 0; };
 static pfp::StagedText *&staged_of(pfp_ctx *c) { return *reinterpret_cast<pfp::StagedText **>(&c->staged); }
 
+void pfp_dist_release(pfp_ctx *c);
 void pfp_ctx_destroy(pfp_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  pfp_dist_release(c);
   delete staged_of(c);
   delete reinterpret_cast<K1Scratch *>(c->k1scratch);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -589,6 +591,173 @@ int pfp_bigbwt(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, i
   return PFP_OK;
   PFP_CATCH(c)
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- multi-GPU chain (one rank's share)
+//
+// the text is sharded over the ranks, phrases are independent units.  Every rank
+//   1. pfp_dist_local_parse : scans (halo + its shard), owns the phrases that END inside the shard,
+//                             deduplicates them locally                       [n/R bytes of work]
+//   -- allgather of the local dictionaries (RCCL, done by the caller) --
+//   2. pfp_dist_global      : deduplicates the union into the global dictionary, suffix-sorts it
+//                             (replicated: O(|D|) << n for repetitive input), translates its own
+//                             parse to global lexicographic ranks
+//   -- allgather of parse symbols / last / sai --
+//   3. pfp_dist_merge       : BWT of the parse (replicated) and the slice [lo,hi) of the final BWT/SA
+// The collectives live in big-bwt_amd/dist.py (torch.distributed over RCCL/xGMI).
+struct DistState {
+  StagedText tx;
+  DBuf<uint64_t> ends;
+  uint64_t n_ends = 0, n_local = 0, k0 = 0, P_local = 0;
+  int w = 0;
+  Dictionary L;                 // local dictionary + local parse
+  Dictionary G;                 // global dictionary (identical on every rank)
+  DictIndex ix;
+  SuffixOrder so;
+  DBuf<uint32_t> occ_lex;
+};
+static DistState *dist_of(pfp_ctx *c) {
+  if (!c->dist) c->dist = new DistState();
+  return reinterpret_cast<DistState *>(c->dist);
+}
+
+__global__ void count_below_kernel(const uint64_t *__restrict__ ends, uint64_t ne, uint64_t bound, uint64_t *out) {
+  uint64_t lo = 0, hi = ne;                   // first index with ends[idx] >= bound
+  while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ends[mid] < bound) lo = mid + 1; else hi = mid; }
+  out[0] = lo;
+  out[1] = ne ? ends[ne - 1] : ~0ull;
+}
+__global__ void dist_sym_kernel(uint64_t P, const uint32_t *__restrict__ lpid, uint64_t word_base,
+                                const uint32_t *__restrict__ gid_of_union, const uint32_t *__restrict__ lexrank,
+                                uint32_t *__restrict__ sym) {
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < P) sym[k] = lexrank[gid_of_union[word_base + lpid[k]]] + 1;
+}
+
+extern "C" {
+
+int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p, int is_first,
+                         int is_last, uint64_t global_offset, int want_sai, uint64_t out_sizes[4]) {
+  if (!c || (!d_text && n) || !out_sizes) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  check_args(w, p, 0);
+  PFP_REQUIRE(is_first ? halo_len == 0 : halo_len >= (uint64_t)w, PFP_EINVAL, "halo must hold at least one window");
+  PFP_REQUIRE(halo_len <= n, PFP_EINVAL, "halo longer than the local text");
+  DistState *ds = dist_of(c);
+  *ds = DistState();
+  ds->w = w; ds->n_local = n;
+  ds->tx.stage(c, d_text, true, n, w);
+  uint64_t used = 0;
+  ds->n_ends = scan_text(c, ds->tx, n, w, p, ds->ends, &used);    // reference trigger set: identical on all ranks
+  PFP_REQUIRE(used == n, PFP_EFORMAT, "bytes <= 2 inside a text shard are not supported in the multi-GPU chain");
+  DBuf<uint64_t> tmp(c, 2);
+  hipLaunchKernelGGL(count_below_kernel, dim3(1), dim3(1), 0, c->stream, ds->ends.p, ds->n_ends, halo_len, tmp.p);
+  PFP_HIP(hipMemcpyAsync(c->h_scalars, tmp.p, 16, hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  ds->k0 = is_first ? 0 : c->h_scalars[0];
+  const uint64_t last_end = c->h_scalars[1];
+  PFP_REQUIRE(is_first || ds->k0 >= 1, PFP_ELIMIT, "no phrase boundary inside the halo: a phrase is longer than the halo");
+  const uint64_t kend = is_last ? ds->n_ends + 1 : ds->n_ends;      // the partial tail phrase belongs to the next rank
+  PFP_REQUIRE(kend > ds->k0, PFP_ESHORT, "text shard holds no complete phrase");
+  ds->P_local = kend - ds->k0;
+  // T' index x of the local text is global text position global_offset - halo_len + x - 1; sai = end position + 1
+  const uint64_t sai_base = global_offset - halo_len;
+  build_dictionary_shard(c, ds->tx, n, w, ds->ends, ds->n_ends, ds->k0, ds->P_local, want_sai != 0, sai_base, ds->L);
+  out_sizes[0] = ds->L.dsize - 1;      // local dictionary bytes without the final 0x00
+  out_sizes[1] = ds->L.d;
+  out_sizes[2] = ds->P_local;
+  out_sizes[3] = last_end;             // local position of the last trigger (the next rank's halo must reach it)
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_dist_export_local(pfp_ctx *c, void *d_dict, void *d_occ, void *d_last, void *d_sai) {
+  if (!c || !c->dist) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  if (d_dict) PFP_HIP(hipMemcpyAsync(d_dict, ds->L.bytes.p, ds->L.dsize - 1, hipMemcpyDeviceToDevice, c->stream));
+  if (d_occ) PFP_HIP(hipMemcpyAsync(d_occ, ds->L.wocc.p, ds->L.d * 4, hipMemcpyDeviceToDevice, c->stream));
+  if (d_last) PFP_HIP(hipMemcpyAsync(d_last, ds->L.last.p, ds->P_local, hipMemcpyDeviceToDevice, c->stream));
+  if (d_sai) {
+    PFP_REQUIRE(ds->L.sai.p, PFP_EINVAL, "sa info was not requested in pfp_dist_local_parse");
+    PFP_HIP(hipMemcpyAsync(d_sai, ds->L.sai.p, ds->P_local * 8, hipMemcpyDeviceToDevice, c->stream));
+  }
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_dist_global(pfp_ctx *c, const void *d_union, uint64_t union_bytes, const void *d_union_occ, uint64_t n_union,
+                    uint64_t my_word_base, void *d_sym_out, uint64_t out_info[3]) {
+  if (!c || !c->dist || !d_union || !d_union_occ || !d_sym_out || !out_info) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  PFP_REQUIRE(n_union >= 1 && my_word_base + ds->L.d <= n_union, PFP_EINVAL, "inconsistent union layout");
+  // the union is itself a (not sorted, not duplicate-free) dictionary: words + 0x01, closed by one 0x00
+  Dictionary U; DictIndex uix;
+  U.dsize = union_bytes + 1; U.d = n_union;
+  U.bytes.alloc(c, U.dsize + 64);
+  PFP_HIP(hipMemcpyAsync(U.bytes.p, d_union, union_bytes, hipMemcpyDeviceToDevice, c->stream));
+  PFP_HIP(hipMemsetAsync(U.bytes.p + union_bytes, 0, 65, c->stream));
+  build_dict_index(c, U, uix);
+  U.woff.alloc(c, n_union + 1); U.wlen.alloc(c, n_union);
+  hipLaunchKernelGGL(words_from_wend_kernel, dim3(cdiv(n_union, TB)), dim3(TB), 0, c->stream, (uint32_t)n_union, uix.wend.p,
+                     U.woff.p, U.wlen.p);
+  ds->G = Dictionary();
+  build_dictionary_words(c, U.bytes.p, U.woff.p, U.wlen.p, n_union, (const uint32_t *)d_union_occ, union_bytes, ds->G);
+  if (c->debug) { Dictionary &G = ds->G; (void)G; }
+  build_dict_index(c, ds->G, ds->ix);
+  sort_dict_suffixes(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, ds->so);
+  if (c->debug) validate_suffix_order(c, ds->G.bytes.p, ds->so, true, "global dict SA");
+  compute_lexrank(c, ds->G, ds->so, ds->ix);
+  const uint32_t d = (uint32_t)ds->G.d;
+  ds->occ_lex.alloc(c, d);
+  hipLaunchKernelGGL(occ_lex_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ds->ix.lexrank.p, ds->G.wocc.p,
+                     ds->occ_lex.p, (uint32_t *)nullptr);
+  hipLaunchKernelGGL(dist_sym_kernel, dim3(cdiv(ds->P_local, TB)), dim3(TB), 0, c->stream, ds->P_local, ds->L.pid.p,
+                     my_word_base, ds->G.pid.p, ds->ix.lexrank.p, (uint32_t *)d_sym_out);
+  PFP_HIP(hipGetLastError());
+  sync(c);
+  out_info[0] = ds->G.d; out_info[1] = ds->G.dsize; out_info[2] = ds->so.rounds;
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last, const void *d_sai, int flags,
+                   uint64_t n_total, uint64_t out_lo, uint64_t out_hi, void *d_bwt_slice, void *d_sa_slice) {
+  if (!c || !c->dist || !d_sym || !d_last || !d_bwt_slice || (flags && (!d_sai || !d_sa_slice))) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  check_args(ds->w, 10, flags);
+  PFP_REQUIRE(out_lo <= out_hi && out_hi <= n_total + 1, PFP_EINVAL, "bad output slice");
+  ParseBWT pb;
+  parse_bwt(c, (const uint32_t *)d_sym, P, (const uint8_t *)d_last, flags ? (const uint64_t *)d_sai : nullptr,
+            ds->occ_lex.p, ds->G.d, pb);
+  if (c->debug) validate_parse_bwt(c, pb);
+  BwtOutputs bo;
+  bo.d_bwt = (uint8_t *)d_bwt_slice; bo.d_sa = (uint64_t *)d_sa_slice;
+  merge_bwt(c, ds->G, ds->ix, ds->so, pb, ds->occ_lex.p, ds->w, flags, n_total + 1, bo, out_lo, out_hi);
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+void pfp_dist_release(pfp_ctx *c) {
+  if (!c || !c->dist) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  delete reinterpret_cast<DistState *>(c->dist);
+  c->dist = nullptr;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---------------------------------------------------------------- micro entry points
 int pfp_stage_text_dev(pfp_ctx *c, const void *d_text, uint64_t n, int w) {

@@ -30,7 +30,8 @@ ERRORS = {0: "PFP_OK", -1: "PFP_EINVAL", -2: "PFP_ENODEV", -3: "PFP_EHIP", -4: "
 SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror", "pfp_version", "pfp_ctx_stream",
            "pfp_free", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak",
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_dev", "pfp_get_stats",
-           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue"]
+           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
+           "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_merge", "pfp_dist_release"]
 
 
 class PfpError(RuntimeError):
@@ -99,6 +100,7 @@ def load_library():
         lib.pfp_set_profiling.restype = None
         lib.pfp_set_max_phrase.restype = None
         lib.pfp_set_kernel_trace.restype = None
+        lib.pfp_dist_release.restype = None
         lib.pfp_parse_result_free.restype = None
         lib.pfp_bwt_result_free.restype = None
         _lib = lib
@@ -289,6 +291,33 @@ class Context:
                                             C.c_int(flags), C.c_void_p(d_bwt_ptr),
                                             C.c_void_p(d_sa_ptr) if d_sa_ptr else None, C.byref(used)))
         return used.value
+
+    # -- multi-GPU chain, one rank's share (device pointers; collectives are the caller's: dist.py)
+    def dist_local_parse(self, d_text_ptr, n, halo_len, w, p, is_first, is_last, global_offset, want_sai):
+        sizes = (C.c_uint64 * 4)()
+        self._check(self.lib.pfp_dist_local_parse(self._h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_uint64(halo_len),
+                                                  C.c_int(w), C.c_uint64(p), C.c_int(int(is_first)), C.c_int(int(is_last)),
+                                                  C.c_uint64(global_offset), C.c_int(int(want_sai)), sizes))
+        return dict(dict_bytes=int(sizes[0]), words=int(sizes[1]), phrases=int(sizes[2]), last_trigger=int(sizes[3]))
+
+    def dist_export_local(self, d_dict=None, d_occ=None, d_last=None, d_sai=None):
+        vp = lambda x: C.c_void_p(x) if x else None
+        self._check(self.lib.pfp_dist_export_local(self._h, vp(d_dict), vp(d_occ), vp(d_last), vp(d_sai)))
+
+    def dist_global(self, d_union, union_bytes, d_union_occ, n_union, my_word_base, d_sym_out):
+        info = (C.c_uint64 * 3)()
+        self._check(self.lib.pfp_dist_global(self._h, C.c_void_p(d_union), C.c_uint64(union_bytes), C.c_void_p(d_union_occ),
+                                             C.c_uint64(n_union), C.c_uint64(my_word_base), C.c_void_p(d_sym_out), info))
+        return dict(words=int(info[0]), dict_bytes=int(info[1]), rounds=int(info[2]))
+
+    def dist_merge(self, d_sym, P, d_last, d_sai, flags, n_total, out_lo, out_hi, d_bwt_slice, d_sa_slice=None):
+        self._check(self.lib.pfp_dist_merge(self._h, C.c_void_p(d_sym), C.c_uint64(P), C.c_void_p(d_last),
+                                            C.c_void_p(d_sai) if d_sai else None, C.c_int(flags), C.c_uint64(n_total),
+                                            C.c_uint64(out_lo), C.c_uint64(out_hi), C.c_void_p(d_bwt_slice),
+                                            C.c_void_p(d_sa_slice) if d_sa_slice else None))
+
+    def dist_release(self):
+        self.lib.pfp_dist_release(self._h)
 
     def stage_text_dev(self, d_text_ptr, n, w=10):
         self._check(self.lib.pfp_stage_text_dev(self._h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_int(w)))

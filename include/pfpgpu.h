@@ -161,6 +161,34 @@ int pfp_get_kernel_trace(pfp_ctx *ctx, pfp_kernel_stat *out, int cap);
  * (SURVEY.md 2.2-Q11); pfp_scan / pfp_parse always use the reference's trigger set. */
 void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
 
+/* ------------------------------------------------------------------------------------
+ * Multi-GPU chain, one rank's share (the reference's analogue is the byte-range
+ * threading of pscan.hpp:114-165 and the output-range threading of pfthreads.hpp:456-493).
+ * The caller (big-bwt_amd/dist.py, torch.distributed over RCCL) shards the text, moves the
+ * halos and runs the allgathers between the steps; all pointers are device pointers.
+ *   pfp_dist_local_parse : d_text = halo (the last halo_len bytes of the previous shard; 0 for the
+ *       first rank) followed by this rank's shard, n bytes in all; global_offset = position of the
+ *       shard's first byte in the whole text.  Owns the phrases that end inside the shard.
+ *       out_sizes = {local dict bytes, local words, local phrases, local position of last trigger}
+ *   pfp_dist_export_local: copies the local dictionary (words + 0x01), its occ (u32), last (u8)
+ *       and sai (u64) into caller buffers (any may be NULL)
+ *   pfp_dist_global      : d_union = the ranks' local dictionaries back to back, d_union_occ their
+ *       occ; my_word_base = index of this rank's first word in the union.  Builds the global
+ *       dictionary and writes this rank's parse as global 1-based ranks (u32[local phrases]).
+ *       out_info = {global words, global dict bytes, doubling rounds}
+ *   pfp_dist_merge       : d_sym/d_last/d_sai = the whole parse in text order (all ranks);
+ *       n_total = text length; emits BWT positions [out_lo,out_hi) into d_bwt_slice (u8) and, with
+ *       flags, SA values into d_sa_slice (u64).
+ * ------------------------------------------------------------------------------------ */
+int pfp_dist_local_parse(pfp_ctx *ctx, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p,
+                         int is_first, int is_last, uint64_t global_offset, int want_sai, uint64_t out_sizes[4]);
+int pfp_dist_export_local(pfp_ctx *ctx, void *d_dict, void *d_occ, void *d_last, void *d_sai);
+int pfp_dist_global(pfp_ctx *ctx, const void *d_union, uint64_t union_bytes, const void *d_union_occ,
+                    uint64_t n_union, uint64_t my_word_base, void *d_sym_out, uint64_t out_info[3]);
+int pfp_dist_merge(pfp_ctx *ctx, const void *d_sym, uint64_t P, const void *d_last, const void *d_sai, int flags,
+                   uint64_t n_total, uint64_t out_lo, uint64_t out_hi, void *d_bwt_slice, void *d_sa_slice);
+void pfp_dist_release(pfp_ctx *ctx);
+
 /* ---- micro entry points used by bench.py's roofline leg and by the parity tests ---- */
 /* copy a device-resident text into the ctx's padded staging buffer (T' = Dollar.T.Dollar^w) */
 int pfp_stage_text_dev(pfp_ctx *ctx, const void *d_text, uint64_t n, int w);

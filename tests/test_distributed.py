@@ -1,0 +1,173 @@
+"""Multi-rank path.  CPU: the collective plumbing of big-bwt_amd/dist.py under torch.distributed
+(gloo, world_size 2, 127.0.0.1).  GPU: the whole distributed chain with R virtual ranks on one
+card, bit for bit against the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _toy_phases(rank, size):
+    """same protocol as dist.phases: yields ('allgather', tensor), gets the list back"""
+    a = torch.arange(3 + 2 * rank, dtype=torch.uint8) + 10 * rank          # different lengths per rank
+    got = yield ("allgather", a)
+    b = torch.tensor([sum(int(t.sum()) for t in got) + rank], dtype=torch.int64)
+    got2 = yield ("allgather", b)
+    return torch.cat(got).tolist(), [int(t.item()) for t in got2]
+
+
+def _worker(rank, size, port, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    entry.load_package()
+    import importlib
+    d = importlib.import_module("bigbwt_amd.dist")
+    # 1. variable-length allgather
+    t = torch.arange(5 + 3 * rank, dtype=torch.int32) * (rank + 1)
+    parts = d.all_gather_var(t)
+    ok = len(parts) == size and all(p.numel() == 5 + 3 * r and int(p.sum()) == int((torch.arange(5 + 3 * r) * (r + 1)).sum())
+                                    for r, p in enumerate(parts))
+    # 2. the driver loop of dist.run on a toy generator (no GPU needed)
+    gen = _toy_phases(rank, size)
+    reply = None
+    try:
+        while True:
+            kind, payload = gen.send(reply)
+            reply = d.all_gather_var(payload)
+    except StopIteration as fin:
+        res = fin.value
+    # 3. slice bounds tile the output exactly
+    bounds = [d.slice_bounds(1001, r, size) for r in range(size)]
+    ok &= bounds[0][0] == 0 and bounds[-1][1] == 1001 and all(bounds[i][1] == bounds[i + 1][0] for i in range(size - 1))
+    q.put((rank, ok, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_plumbing_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_cat = list(range(0, 3)) + [10 + i for i in range(5)]
+    for rank, ok, res in out:
+        assert ok
+        assert res[0] == want_cat
+        assert res[1] == [sum(want_cat) + 0, sum(want_cat) + 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [2, 3])
+def test_distributed_chain_matches_oracle(O, pkg, R):
+    """R virtual ranks on one GPU: text shards -> halo -> local parse -> union dictionary ->
+    replicated sorts -> output slices; concatenated slices must equal the oracle's files."""
+    import importlib
+    d = importlib.import_module("bigbwt_amd.dist")
+    dev = torch.device("cuda:0")
+    text = O.gen_fasta(150000, 6, 0.002, 41)
+    n = len(text)
+    cuts = [0] + [n * (r + 1) // R + (7 * r - 3) for r in range(R - 1)] + [n]     # uneven, unaligned shards
+    ctxs = [pkg.Context(0) for _ in range(R)]
+    try:
+        for flags in (0, pkg.FLAG_SA):
+            shards = [torch.from_numpy(text[cuts[r]:cuts[r + 1]].copy()).to(dev) for r in range(R)]
+            res = d.simulate(ctxs, shards, 10, 100, flags, halo=4096)
+            bwt = torch.cat([r["bwt"] for r in res]).cpu().numpy()
+            want = O.bigbwt(text, 10, 100, flags)
+            assert res[0]["lo"] == 0 and res[-1]["hi"] == n + 1
+            assert np.array_equal(bwt, want["bwt"]), (R, flags)
+            if flags:
+                sa = torch.cat([r["sa"] for r in res]).cpu().numpy().astype(np.uint64)
+                assert sa[0] == n and np.array_equal(sa[1:], want["sa"])
+            assert sum(r["stats"]["local"]["phrases"] for r in res) == res[0]["stats"]["phrases_total"]
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.gpu
+def test_distributed_halo_too_small_is_reported(O, pkg):
+    import importlib
+    d = importlib.import_module("bigbwt_amd.dist")
+    dev = torch.device("cuda:0")
+    text = O.gen_fasta(60000, 2, 0.0, 43)
+    ctxs = [pkg.Context(0), pkg.Context(0)]
+    try:
+        shards = [torch.from_numpy(text[:50000].copy()).to(dev), torch.from_numpy(text[50000:].copy()).to(dev)]
+        with pytest.raises(pkg.PfpError):
+            d.simulate(ctxs, shards, 10, 100, 0, halo=12)      # 12 bytes cannot hold a phrase boundary
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def _gpu_worker(rank, size, port, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    pkg = entry.load_package()
+    O = entry.load_oracle()
+    import importlib
+    d = importlib.import_module("bigbwt_amd.dist")
+    dev = torch.device("cuda:0")
+    text = O.gen_fasta(120000, 4, 0.002, 47)
+    n = len(text)
+    lo, hi = n * rank // size, n * (rank + 1) // size
+    shard = torch.from_numpy(text[lo:hi].copy()).to(dev)
+    ctx = pkg.Context(0)
+    res = d.run(ctx, shard, 10, 100, pkg.FLAG_SA, halo=8192)
+    q.put((rank, res["lo"], res["hi"], res["bwt"].cpu().numpy(), res["sa"].cpu().numpy()))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_distributed_run_two_processes_one_gpu(O):
+    """dist.run under real torch.distributed with two PROCESSES (gloo rendezvous, both on cuda:0):
+    everything of the N>1 path except the RCCL transport itself."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    text = O.gen_fasta(120000, 4, 0.002, 47)
+    want = O.bigbwt(text, 10, 100, O.FLAG_SA)
+    bwt = np.concatenate([o[3] for o in out])
+    sa = np.concatenate([o[4] for o in out]).astype(np.uint64)
+    assert out[0][1] == 0 and out[1][2] == len(text) + 1
+    assert np.array_equal(bwt, want["bwt"])
+    assert sa[0] == len(text) and np.array_equal(sa[1:], want["sa"])
