@@ -8,8 +8,12 @@ sort -> BWT of the parse -> merge) over one synthetic input that is already resi
 the timed region starts, leaving the finished .bwt (and the SA values, for workloads that ask
 for them) in HBM.  Workload (BASELINE.json configs[1]): synthetic human-chr1-shaped FASTA,
 249e6 random ACGT bases with one 18 Mb and two 10 kb blocks of N, 60-column lines, one header,
--w 10 -p 100, BWT only (~253 MB).  One process per GPU; for N > 1 every rank builds the BWT of
-its own text of that shape (independent objects, no data-path collective: weak scaling).
+-w 10 -p 100, BWT only (~253 MB).  One process per GPU.  For N > 1 the ranks build ONE BWT of a
+collection of N such chromosomes (rank r holds variant r of the same base sequence, 0.1 % SNPs -
+a pangenome slice per GPU, weak scaling): text shards + halo exchange, allgatherv of the local
+dictionaries and of the parse over RCCL, replicated dictionary/parse suffix sorts, output-range
+sharded merge (big-bwt_amd/dist.py).  `--multi independent` instead lets every rank build the BWT
+of its own text with no collective.
 
 Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the library's own
 stream, `cpu_baseline` is the real reference (oracle/_ref, built from the reference's sources)
@@ -41,8 +45,9 @@ WORKLOADS = {
 }
 
 
-def make_text(dev, wl, seed):
-    """GEN-shaped synthetic FASTA built directly in HBM (SURVEY.md section 4 family; torch RNG)."""
+def make_text(dev, wl, seed, variant=0, variant_rate=1e-3):
+    """GEN-shaped synthetic FASTA built directly in HBM (SURVEY.md section 4 family; torch RNG).
+    variant > 0: the same base sequence with its own SNPs and header (one member of a collection)."""
     G, C_, r = wl["G"], wl["C"], wl["r"]
     assert G % 60 == 0
     gen = torch.Generator(device=dev)
@@ -51,6 +56,12 @@ def make_text(dev, wl, seed):
     base = lut[torch.randint(0, 4, (G,), generator=gen, device=dev, dtype=torch.int64)]
     for st, ln in wl["nblocks"]:
         base[st:st + ln] = ord("N")
+    if variant > 0:
+        gen.manual_seed(seed * 7919 + variant)
+        k = int(G * variant_rate)
+        pos = torch.randint(0, G, (k,), generator=gen, device=dev)
+        keep = base[pos] != ord("N")
+        base[pos[keep]] = lut[torch.randint(0, 4, (int(keep.sum()),), generator=gen, device=dev, dtype=torch.int64)]
     parts = []
     nl = torch.full((G // 60, 1), ord("\n"), dtype=torch.uint8, device=dev)
     for c in range(C_):
@@ -60,7 +71,7 @@ def make_text(dev, wl, seed):
             k = int(G * r)
             pos = torch.randint(0, G, (k,), generator=gen, device=dev)
             seq[pos] = lut[torch.randint(0, 4, (k,), generator=gen, device=dev, dtype=torch.int64)]
-        parts.append(torch.tensor(list(b">copy%d\n" % c), dtype=torch.uint8, device=dev))
+        parts.append(torch.tensor(list(b">copy%d\n" % (c + variant * C_)), dtype=torch.uint8, device=dev))
         parts.append(torch.cat([seq.view(-1, 60), nl], dim=1).reshape(-1))
     text = torch.cat(parts).contiguous()
     del base, parts
@@ -109,6 +120,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample-mb", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi", default="collection", choices=["collection", "independent"],
+                    help="N>1: one BWT of a sharded collection (RCCL exchanges) or one independent text per GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,8 +132,11 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        # PFP_BENCH_BACKEND=gloo PFP_BENCH_ONE_GPU=1: rehearsal of the N>1 path on a one-GPU box (all ranks on cuda:0)
+        dist.init_process_group(backend=os.environ.get("PFP_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if os.environ.get("PFP_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -129,20 +145,32 @@ def main():
     w, p, flags = wl["w"], wl["p"], wl["flags"]
     O = entry.load_oracle() if rank == 0 else None
 
-    seed = 2 + 1000 * rank
-    text = make_text(dev, wl, seed)
-    if rank == 0:
-        while first_window_triggers(text, w, p, O):      # reject such inputs
-            seed += 1
-            text = make_text(dev, wl, seed)
+    collection = world > 1 and args.multi == "collection"
+    seed = 2 if collection else 2 + 1000 * rank
+    while True:                                           # reject inputs whose first window triggers
+        text = make_text(dev, wl, seed, variant=rank if collection else 0)
+        bad = torch.tensor([1 if (rank == 0 and first_window_triggers(text, w, p, O)) else 0], dtype=torch.int64, device=dev)
+        if collection:
+            dist.broadcast(bad, src=0)                    # every shard derives from the same base seed
+        if int(bad.item()) == 0:
+            break
+        seed += 1
     n = text.numel()
     bwt = torch.empty(n + 1 + 16, dtype=torch.uint8, device=dev)
-    sa = torch.empty(n + 1, dtype=torch.int64, device=dev) if flags else None
+    sa = torch.empty(n + 1, dtype=torch.int64, device=dev) if (flags and not collection) else None
     torch.cuda.synchronize()
 
     ctx = pkg.Context(local_rank)
+    dist_mod_pfp = None
+    last_result = {}
+    if collection:
+        import importlib
+        dist_mod_pfp = importlib.import_module("bigbwt_amd.dist")
 
     def step():
+        if collection:
+            last_result["r"] = dist_mod_pfp.run(ctx, text, w, p, flags)
+            return n
         return ctx.bigbwt_dev(text.data_ptr(), n, bwt.data_ptr(), sa.data_ptr() if flags else None, w, p, flags)
 
     def barrier():
@@ -180,8 +208,16 @@ def main():
 
     # ---- correctness of what was just measured (outside the timed region)
     hist_t = torch.bincount(text.to(torch.int64), minlength=256)
-    hist_t[0] += 1
-    hist_b = torch.bincount(bwt[: n + 1].to(torch.int64), minlength=256)
+    if collection:
+        res = last_result["r"]
+        hist_b = torch.bincount(res["bwt"].to(torch.int64), minlength=256)
+        dist.all_reduce(hist_t); dist.all_reduce(hist_b)
+        hist_t[0] += 1
+        dstats = res["stats"]
+        st["n_phrases"], st["n_words"], st["dict_size"] = dstats["phrases_total"], dstats["glob"]["words"], dstats["glob"]["dict_bytes"]
+    else:
+        hist_t[0] += 1
+        hist_b = torch.bincount(bwt[: n + 1].to(torch.int64), minlength=256)
     verified = bool(torch.equal(hist_t, hist_b))
 
     out = None
@@ -205,14 +241,16 @@ def main():
                         share_of_step=round(dom["ms_per_step"] / ms_per_step, 3))
         scan_row = next((x for x in rows if x["kernel"] == "pfp::kr_flag_kernel"), None)
         # the host-buffer entry point (pageable H2D of the text + D2H of the .bwt included): reported, never `value`
-        host_text = text.cpu().numpy()
-        t1 = time.perf_counter()
-        hb = ctx.bigbwt(host_text, w, p, flags)
-        host_s = time.perf_counter() - t1
-        host_boundary = dict(MBps=round(n / host_s / 1e6, 1), seconds=round(host_s, 4),
-                             note="pfp_bigbwt: pageable host text in, host .bwt/.ssa/.esa out (PCIe inclusive)")
-        host_ok = bool(np.array_equal(hb["bwt"], bwt[: n + 1].cpu().numpy()))
-        del hb
+        host_boundary, host_ok = None, None
+        if world == 1:
+            host_text = text.cpu().numpy()
+            t1 = time.perf_counter()
+            hb = ctx.bigbwt(host_text, w, p, flags)
+            host_s = time.perf_counter() - t1
+            host_boundary = dict(MBps=round(n / host_s / 1e6, 1), seconds=round(host_s, 4),
+                                 note="pfp_bigbwt: pageable host text in, host .bwt/.ssa/.esa out (PCIe inclusive)")
+            host_ok = bool(np.array_equal(hb["bwt"], bwt[: n + 1].cpu().numpy()))
+            del hb
         cpu = None
         parity_sample = None
         if not args.no_cpu_baseline and world == 1:
@@ -228,7 +266,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "bytes_per_gpu": n, "w": w, "p": p, "flags": flags,
                        "phrases": st["n_phrases"], "words": st["n_words"], "dict_bytes": st["dict_size"],
-                       "parallelism": f"{world} independent texts (one per GPU)" if world > 1 else "1 GPU"},
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       (f"{world} shards of one collection: halo + allgatherv of dictionaries and parse over RCCL, "
+                                        f"replicated dictionary/parse sorts, output-sliced merge") if collection else
+                                       f"{world} independent texts (one per GPU), no collective")},
             "roofline": roofline,
             "kernels": rows[:12],
             "scan_pass_k1": scan_row,
