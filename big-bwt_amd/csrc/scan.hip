@@ -32,11 +32,26 @@ __device__ __forceinline__ uint32_t kr_reduce(uint64_t T) {
   return r < r2 ? r : r2;
 }
 
+// Rolling-step reduction: exact r = T mod q for T = hi:lo < 2^40, built from FULL-RATE 24-bit
+// multiplies only (v_mul_hi_u32_u24 / v_mul_u32_u24; the 32-bit v_mul_hi/lo are quarter rate):
+//   a = T >> 16 (< 2^24);  qhat = (a * floor(2^48/q)) >> 32  in {Q-1, Q}  (deficit < 2^-14.9 + 2^-8)
+//   qhat < 2^10, so qhat*q mod 2^32 is two 24-bit products;  r = T - qhat*q in [0, 2q).
+constexpr uint32_t kB48 = 140737u;   // floor(2^48 / 1999999973)
+static_assert((uint64_t)kB48 * kPrime <= (1ull << 48) && (uint64_t)(kB48 + 1) * kPrime > (1ull << 48), "barrett48");
+__device__ __forceinline__ uint32_t kr_reduce40(uint32_t lo, uint32_t hi) {
+  const uint32_t a = __builtin_amdgcn_alignbit(hi, lo, 16) & 0xFFFFFFu;
+  const uint32_t qhat = (uint32_t)(((uint64_t)a * (uint64_t)kB48) >> 32) & 0x3FFu;
+  const uint32_t prod = __umul24(qhat, kPrime & 0xFFFFu) + (__umul24(qhat, kPrime >> 16) << 16);
+  const uint32_t r = lo - prod;
+  const uint32_t r2 = r - kPrime;
+  return r < r2 ? r : r2;
+}
+
 // trigger test: `hash % p == 0` (newscan.cpp:367) or, in the fused chain only, membership in the
 // small set of extra trigger hashes that splits giant phrases (see scan_text_adaptive)
 __device__ __forceinline__ bool kr_divides(uint32_t h, const KRParams &kp) {
   uint32_t x = h * kp.pinv;
-  x = (x >> kp.pshift) | (kp.pshift ? (x << (32 - kp.pshift)) : 0u);
+  x = __builtin_amdgcn_alignbit(x, x, kp.pshift);      // rotate right by the power of two in p
   bool t = x <= kp.plimit;
   if (kp.bloom && ((kp.bloom >> (h & 63)) & 1ull)) {
     for (uint32_t q = 0; q < kp.nextra; q++) t |= (h == kp.extra[q]);
@@ -85,15 +100,20 @@ __global__ __launch_bounds__(256) void kr_flag_kernel(const uint8_t *__restrict_
     }
     if (W % 3 == 1) { h = kr_reduce<8>(((uint64_t)h << 8) | byte_of(r, k)); }
     if (W % 3 == 2) { h = kr_reduce<15>(((uint64_t)h << 16) | (byte_of(r, k) << 8) | byte_of(r, k + 1)); }
-    const uint64_t lo_valid = (uint64_t)(W - 1);  // words shorter than w+1 are never saved (newscan.cpp:248)
-    if (kr_divides(h, kp) && pos0 >= lo_valid) mask |= 1u;
+    mask = kr_divides(h, kp) ? 1u : 0u;
 #pragma unroll
     for (int j = 1; j < 16; j++) {
-      uint32_t cin = byte_of(r, 16 + j), cout = byte_of(r, 16 + j - W);
-      uint64_t T = (uint64_t)cout * kp.negpw + (((uint64_t)h << 8) | cin);  // < 2^40
-      h = kr_reduce<8>(T);
-      if (kr_divides(h, kp) && pos0 + j >= lo_valid && pos0 + j < n) mask |= 1u << j;
+      const uint32_t cin = byte_of(r, 16 + j), cout = byte_of(r, 16 + j - W);
+      const uint64_t T = (uint64_t)cout * kp.negpw + (((uint64_t)h << 8) | cin);  // < 2^40
+      h = kr_reduce40((uint32_t)T, (uint32_t)(T >> 32));
+      mask |= (kr_divides(h, kp) ? 1u : 0u) << j;
     }
+    // positions before w-1 (words shorter than w+1 are never saved, newscan.cpp:248) and past the text end
+    const uint64_t lo_valid = (uint64_t)(W - 1);
+    uint32_t valid = 0xFFFFu;
+    if (pos0 < lo_valid) valid &= 0xFFFFu << (uint32_t)(lo_valid - pos0);
+    if (n - pos0 < 16) valid &= (1u << (uint32_t)(n - pos0)) - 1u;
+    mask &= valid;
     flags16[c] = (uint16_t)mask;
   }
   // block count of triggers
