@@ -315,13 +315,16 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgs a, const ui
 //     ones with broadcast LDS reads (all-pairs, no dependent global loads);
 //   * larger groups (few members with long inverted lists): own index + lower_bound in every other
 //     member's inverted list.
-constexpr int kHardLds = 1024;
+constexpr int kHardLds = 1024;   // occurrences of a group ranked in LDS
+constexpr int kHardMem = 256;    // members of such a group
 struct BigGroup { uint64_t g; uint64_t E; uint32_t k; uint32_t pad; };
 __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, unsigned long long *__restrict__ stats,
                                                           BigGroup *__restrict__ big, uint32_t big_cap) {
   __shared__ uint32_t lpos[4][kHardLds];
   __shared__ uint32_t lsl[4][kHardLds];
   __shared__ uint8_t lch[4][kHardLds];
+  __shared__ uint32_t lmoff[4][kHardMem + 1], lmist[4][kHardMem], lmsl[4][kHardMem];
+  __shared__ uint8_t lmch[4][kHardMem];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned long long my_chars = 0, my_groups = 0;
   for (uint64_t tbase = ((uint64_t)blockIdx.x * 4 + wv) * 64; tbase < a.N; tbase += (uint64_t)gridDim.x * 256) {
@@ -346,15 +349,27 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, unsigned 
     const uint64_t E = a.off[g + k] - base;
     if (base + E <= a.out_lo || base >= a.out_hi) continue;     // group lies outside this rank's slice
     if (lane == 0) { my_chars += E; my_groups += 1; }
-    if (E <= (uint64_t)kHardLds) {
-      for (uint32_t m = lane; m < k; m += 64) {          // stage (position, char, suffix length) per occurrence
+    if (E <= (uint64_t)kHardLds && k <= (uint32_t)kHardMem) {
+      // stage 1: member table (k <= E <= kHardLds): offset, inverted-list start, char, suffix length
+      for (uint32_t m = lane; m < k; m += 64) {
         const uint64_t t = g + m;
-        const uint32_t o0 = (uint32_t)(a.off[t] - base), occ = (uint32_t)(a.off[t + 1] - a.off[t]);
-        const uint32_t is = a.ist[t];
-        const uint8_t ch = fix_char(a.pc[t]);
+        lmoff[wv][m] = (uint32_t)(a.off[t] - base);
+        lmist[wv][m] = a.ist[t];
         uint32_t sl = 0;
         if (a.want_sa) { const uint32_t i = a.sa[t]; sl = a.endpos[i] - i; }
-        for (uint32_t j = 0; j < occ; j++) { lpos[wv][o0 + j] = a.ilist[is + j]; lch[wv][o0 + j] = ch; lsl[wv][o0 + j] = sl; }
+        lmsl[wv][m] = sl;
+        lmch[wv][m] = fix_char(a.pc[t]);
+      }
+      if (lane == 0) lmoff[wv][k] = (uint32_t)E;
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      // stage 2: one lane per occurrence - all 64 lanes issue independent ilist gathers
+      for (uint32_t e = lane; e < (uint32_t)E; e += 64) {
+        uint32_t lo = 0, hi = k;                 // lmoff[lo] <= e < lmoff[hi]
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lmoff[wv][mid] <= e) lo = mid; else hi = mid; }
+        lpos[wv][e] = a.ilist[lmist[wv][lo] + (e - lmoff[wv][lo])];
+        lch[wv][e] = lmch[wv][lo];
+        lsl[wv][e] = lmsl[wv][lo];
       }
       __builtin_amdgcn_wave_barrier();
       __threadfence_block();

@@ -110,17 +110,31 @@ __global__ void iota32_kernel(uint32_t *p, uint64_t n) {
   if (i < n) p[i] = (uint32_t)i;
 }
 
-// key of an unresolved suffix: (its group's head slot, 1 + rank of the suffix h further on)
-__global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ aslot,
-                                  const uint32_t *__restrict__ sa, const uint32_t *__restrict__ rank,
+// key of an unresolved suffix: (its group's head slot, 1 + rank of the suffix h further on).
+// The suffix position and its group travel with the active list (compact3_kernel), so the only
+// random access is rank[i+h].  In dictionary mode an unresolved suffix is always longer than the
+// sorted prefix h (otherwise write_back would have retired it), so i+h stays inside its word.
+__global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ act_i,
+                                  const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ rank,
                                   uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
-  uint32_t i = sa[aslot[a]];
-  uint64_t grp = rank[i];
-  uint64_t nxt = (h < suf_len(g, i)) ? (uint64_t)rank[i + h] + 1 : 0;
+  const uint32_t i = act_i[a];
+  const uint64_t grp = act_grp[a];
+  const uint64_t nxt = (g.mode == MODE_DICT || (uint64_t)i + h < g.N) ? (uint64_t)rank[i + h] + 1 : 0;
   key[a] = (grp << 32) | nxt;
   val[a] = i;
+}
+
+// stream compaction of the active list: (slot, suffix, group) of every suffix that stays unresolved
+__global__ void compact3_kernel(uint64_t m, const uint8_t *__restrict__ keep, const uint32_t *__restrict__ inc,
+                                const uint32_t *__restrict__ aslot, const uint32_t *__restrict__ val,
+                                const uint32_t *__restrict__ newhead, uint32_t *__restrict__ aslot2,
+                                uint32_t *__restrict__ act_i, uint32_t *__restrict__ act_grp) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m || !keep[a]) return;
+  const uint32_t o = inc[a] - 1;
+  aslot2[o] = aslot[a]; act_i[o] = val[a]; act_grp[o] = newhead[a];
 }
 
 __global__ void heads_kernel(uint64_t m, const uint64_t *__restrict__ key, const uint32_t *__restrict__ aslot,
@@ -163,7 +177,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   out.N = N;
   out.sa.alloc(c, N); out.rank.alloc(c, N);
   DBuf<uint64_t> keyo(c, N);
-  DBuf<uint32_t> valo(c, N), aslot(c, N), aslot2(c, N), hv(c, N), newhead(c, N), cnt(c, 1);
+  DBuf<uint32_t> valo(c, N), aslot(c, N), aslot2(c, N), hv(c, N), newhead(c, N), inc(c, N), act_i(c, N), act_grp(c, N);
   DBuf<uint8_t> hd(c, N + 1), keep(c, N);
   sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, N, 0, key0_bits);
   hipLaunchKernelGGL(iota32_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, aslot.p, N);
@@ -181,15 +195,18 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     hipLaunchKernelGGL(write_back_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p,
                        newhead.p, hd.p, round0 ? keyo.p : (const uint64_t *)nullptr, ones, highs, out.sa.p,
                        out.rank.p, keep.p); }
-    select_flagged_u32(c, aslot.p, keep.p, aslot2.p, cnt.p, m);
+    inclusive_count_eq_u8(c, keep.p, 1, inc.p, m);
+    { KScope ks(c, "pfp::compact3_kernel", m * 17);
+      hipLaunchKernelGGL(compact3_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keep.p, inc.p, aslot.p, valo.p,
+                         newhead.p, aslot2.p, act_i.p, act_grp.p); }
     PFP_HIP(hipGetLastError());
-    uint32_t m2 = read_scalar(c, cnt.p);
+    uint32_t m2 = read_scalar(c, inc.p + (m - 1));
     std::swap(aslot.p, aslot2.p);
     m = m2;
     if (m == 0) break;
     PFP_REQUIRE(h < 2 * N, PFP_EHIP, "suffix sort failed to converge");
-    { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 4 + 4 + 4 + 12));
-    hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, out.sa.p,
+    { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 4 + 12));
+    hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p,
                        out.rank.p, key.p, val.p); }
     sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, keybits);
     h *= 2;
