@@ -65,12 +65,16 @@ void dictionary_from_bytes(pfp_ctx *c, Dictionary &D);
 struct SuffixOrder {
   uint64_t N = 0;
   DBuf<uint32_t> sa;     // [N] suffix start positions in sorted order (ties: position order)
-  DBuf<uint32_t> rank;   // [N] rank[i] = first sa slot of i's group (equal strings share it)
+  DBuf<uint32_t> grp;    // [N] grp[t] = first sa slot of slot t's group (equal strings share it)
+  DBuf<uint32_t> rank;   // [N] rank[i] = grp[slot of i]; defined only where materialised (see below)
   uint64_t rounds = 0;
 };
 // Suffixes of the dictionary as 0x01-terminated strings (gsacak semantics):
 // endpos[i] = position of the terminator of the word containing i (the final 0x00 is its own word).
 void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out);
+// rank[] is written sparsely by the sorter; fill it for given positions (device array) / everywhere
+void materialize_ranks(pfp_ctx *c, SuffixOrder &so, const uint64_t *d_positions, uint64_t count);
+void materialize_all_ranks(pfp_ctx *c, SuffixOrder &so);
 // plain suffix array of an integer string with unique smallest last symbol (sacak_int)
 void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out);
 // plain suffix array of a byte string with s[N-1]==0 unique smallest (sacak)
@@ -84,7 +88,7 @@ struct DictIndex {        // per-position / per-word helper arrays over the dict
   DBuf<uint32_t> lexrank;    // [d] 0-based lexicographic rank of word j
 };
 void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix);
-void compute_lexrank(pfp_ctx *c, const Dictionary &D, const SuffixOrder &so, DictIndex &ix);
+void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrder &so, DictIndex &ix);
 
 struct ParseBWT {         // outputs of bwtparse.c in HBM
   uint64_t P = 0;
@@ -120,7 +124,7 @@ uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const uint64_t *sa, uin
 void validate_scan(pfp_ctx *c, const DBuf<uint64_t> &ends, uint64_t n_ends, uint64_t n, int w);
 void validate_dictionary(pfp_ctx *c, const Dictionary &D, int w);
 void validate_index(pfp_ctx *c, const Dictionary &D, const DictIndex &ix);
-void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, const SuffixOrder &so, bool dict_mode, const char *what);
+void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, SuffixOrder &so, bool dict_mode, const char *what);
 void validate_int_sa(pfp_ctx *c, const uint32_t *sym, const SuffixOrder &so);
 void validate_lexrank(pfp_ctx *c, const Dictionary &D, const DictIndex &ix);
 void validate_parse_bwt(pfp_ctx *c, const ParseBWT &pb);

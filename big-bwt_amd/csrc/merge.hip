@@ -65,7 +65,7 @@ __global__ void lexrank_from_order_kernel(uint32_t d, const uint32_t *__restrict
   if (r < d) lexrank[word_sorted[r]] = r;
 }
 
-void compute_lexrank(pfp_ctx *c, const Dictionary &D, const SuffixOrder &so, DictIndex &ix) {
+void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrder &so, DictIndex &ix) {
   const uint32_t d = (uint32_t)D.d;
   ix.lexrank.alloc(c, d);
   DBuf<uint32_t> key(c, d), val(c, d), keyo(c, d), valo(c, d);
@@ -121,55 +121,69 @@ void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t 
 
 // ------------------------------------------------------------------ stage 3: merge
 
-// Per dictionary POSITION, written in one streaming pass after the suffix sort: everything the
-// merge needs to know about the suffix starting there, so that the per-SLOT pass is a single
-// 16-byte gather instead of four dependent ones.
-//   x = number of BWT chars the suffix emits (occ of its word; 0 when the suffix is <= w long, pfbwt.cpp:151)
-//   y = preceding char, 1 (EndOfWord) when the suffix is a whole word (pfbwt.cpp:153)
-//   z = group head slot (equal suffixes share it)      w = word id
-__global__ void posrec_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t d, int w,
-                              const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ endpos,
-                              const uint32_t *__restrict__ rank, const uint32_t *__restrict__ wocc,
-                              uint4 *__restrict__ posrec) {
+// Per dictionary POSITION, one streaming pass: a 2-byte record {prev char, count code} so that the
+// per-SLOT pass gathers 2 bytes from an |D|*2-byte array (largely Infinity-Cache resident) instead
+// of dragging a 64-byte HBM sector per slot for a 16-byte record (rocprofv3 FETCH_SIZE showed 3.4x
+// the algorithmic bytes for that version, profiles/r01_pmc_traffic.txt).
+//   low byte  = preceding char, 1 (EndOfWord) when the suffix is a whole word (pfbwt.cpp:153),
+//               0 when the suffix emits nothing (<= w long, pfbwt.cpp:151)
+//   high byte = occurrences of its word, 255 = "255 or more: look it up"
+// With SA output every emitting slot also needs its word (inverted-list start): the record is then
+// 8 bytes {prev char, count code, 0, 0, word id} so that the slot pass still does ONE gather.
+template <class REC>
+__global__ void pprec_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t d, int w,
+                             const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ endpos,
+                             const uint32_t *__restrict__ wocc, REC *__restrict__ pp) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   uint32_t wd = pos_word[i];
   bool valid = wd < d && (endpos[i] - (uint32_t)i) > (uint32_t)w;
   uint32_t pc = (i == 0) ? kEndOfWord : b[i - 1];
-  posrec[i] = make_uint4(valid ? wocc[wd] : 0u, valid ? pc : 0u, rank[i], wd);
+  uint32_t occ = valid ? wocc[wd] : 0u;
+  uint32_t lo = valid ? (pc | ((occ < 255u ? occ : 255u) << 8)) : 0u;
+  if (sizeof(REC) == 2) pp[i] = (REC)lo;
+  else pp[i] = (REC)((uint64_t)lo | ((uint64_t)wd << 32));
 }
 
-// per SA(D) slot: count, preceding char (0 = emits nothing) and group head, 8 slots per thread
+// per SA(D) slot: count and preceding char (0 = emits nothing), 8 slots per thread; with SA output
+// also the start of the word's inverted list
+template <class REC>
 __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const uint32_t *__restrict__ sa,
-                                                          const uint4 *__restrict__ posrec,
+                                                          const REC *__restrict__ pp,
+                                                          const uint32_t *__restrict__ pos_word,
+                                                          const uint32_t *__restrict__ wocc,
                                                           const uint32_t *__restrict__ wistart,
                                                           uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc,
-                                                          uint32_t *__restrict__ grp, uint32_t *__restrict__ ist) {
+                                                          uint32_t *__restrict__ ist) {
   uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
   if (t0 >= N) return;
-  if (t0 + 8 <= N) {
+  uint32_t idx[8], c8[8], p8[8], w8[8];
+  const int nk = (N - t0) >= 8 ? 8 : (int)(N - t0);
+  if (nk == 8) {
     uint4 s0 = *reinterpret_cast<const uint4 *>(sa + t0), s1 = *reinterpret_cast<const uint4 *>(sa + t0 + 4);
-    const uint32_t idx[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    uint4 r[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) r[k] = posrec[idx[k]];
-    *reinterpret_cast<uint4 *>(cnt + t0) = make_uint4(r[0].x, r[1].x, r[2].x, r[3].x);
-    *reinterpret_cast<uint4 *>(cnt + t0 + 4) = make_uint4(r[4].x, r[5].x, r[6].x, r[7].x);
-    *reinterpret_cast<uint4 *>(grp + t0) = make_uint4(r[0].z, r[1].z, r[2].z, r[3].z);
-    *reinterpret_cast<uint4 *>(grp + t0 + 4) = make_uint4(r[4].z, r[5].z, r[6].z, r[7].z);
-    uint32_t lo = r[0].y | (r[1].y << 8) | (r[2].y << 16) | (r[3].y << 24);
-    uint32_t hi = r[4].y | (r[5].y << 8) | (r[6].y << 16) | (r[7].y << 24);
-    *reinterpret_cast<uint2 *>(pc + t0) = make_uint2(lo, hi);
-    uint32_t is[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) is[k] = r[k].y ? wistart[r[k].w] : 0u;
-    *reinterpret_cast<uint4 *>(ist + t0) = make_uint4(is[0], is[1], is[2], is[3]);
-    *reinterpret_cast<uint4 *>(ist + t0 + 4) = make_uint4(is[4], is[5], is[6], is[7]);
+    idx[0] = s0.x; idx[1] = s0.y; idx[2] = s0.z; idx[3] = s0.w; idx[4] = s1.x; idx[5] = s1.y; idx[6] = s1.z; idx[7] = s1.w;
   } else {
-    for (uint64_t t = t0; t < N; t++) {
-      uint4 r = posrec[sa[t]];
-      cnt[t] = r.x; pc[t] = (uint8_t)r.y; grp[t] = r.z; ist[t] = r.y ? wistart[r.w] : 0u;
-    }
+    for (int k = 0; k < 8; k++) idx[k] = k < nk ? sa[t0 + k] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint64_t v = (uint64_t)pp[idx[k]];
+    p8[k] = (uint32_t)v & 0xffu; c8[k] = ((uint32_t)v >> 8) & 0xffu; w8[k] = (uint32_t)(v >> 32);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) if (c8[k] == 255u) c8[k] = wocc[sizeof(REC) == 2 ? pos_word[idx[k]] : w8[k]];
+  if (nk == 8) {
+    *reinterpret_cast<uint4 *>(cnt + t0) = make_uint4(c8[0], c8[1], c8[2], c8[3]);
+    *reinterpret_cast<uint4 *>(cnt + t0 + 4) = make_uint4(c8[4], c8[5], c8[6], c8[7]);
+    *reinterpret_cast<uint2 *>(pc + t0) = make_uint2(p8[0] | (p8[1] << 8) | (p8[2] << 16) | (p8[3] << 24),
+                                                     p8[4] | (p8[5] << 8) | (p8[6] << 16) | (p8[7] << 24));
+  } else {
+    for (int k = 0; k < nk; k++) { cnt[t0 + k] = c8[k]; pc[t0 + k] = (uint8_t)p8[k]; }
+  }
+  if (ist) {
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (k < nk) ist[t0 + k] = p8[k] ? wistart[sizeof(REC) == 2 ? pos_word[idx[k]] : w8[k]] : 0u;
   }
 }
 
@@ -195,13 +209,18 @@ __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank,
 struct MergeArgs {
   uint64_t N, n_out; uint32_t d; int w; int want_sa; int dbg_mode;
   uint64_t out_lo, out_hi;   // this call emits BWT positions [out_lo,out_hi) only (multi-GPU slices); bwt/out_sa are indexed by global position
-  const uint32_t *sa, *endpos, *grp, *ist;
+  const uint32_t *sa, *endpos, *grp, *ist, *pos_word, *wistart;
   const uint8_t *pc, *hard; const uint64_t *off;
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
   uint8_t *bwt; uint64_t *out_sa;
 };
 
 __device__ __forceinline__ uint8_t fix_char(uint8_t ch) { return ch == kDollar ? 0 : ch; }  // pfbwt.cpp:126
+// start of slot t's word in ilist: stored per slot when SA values are wanted, looked up otherwise
+// (BWT only needs it for whole words and hard groups)
+__device__ __forceinline__ uint32_t slot_ist(const MergeArgs &a, uint64_t t) {
+  return a.ist ? a.ist[t] : a.wistart[a.pos_word[a.sa[t]]];
+}
 
 // Expansion.  One workgroup owns kSlots consecutive SA(D) slots, i.e. one contiguous range of
 // the output; slot offsets, classes and chars are staged in LDS and every thread then produces 16
@@ -253,11 +272,11 @@ __device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L
         ch = fix_char(L.lpc[s]);
         if (a.want_sa && in_slice) {
           const uint32_t i = a.sa[t0 + s];
-          const uint64_t pos = a.ilist[a.ist[t0 + s] + (uint32_t)(x - L.loff[s])];
+          const uint64_t pos = a.ilist[slot_ist(a, t0 + s) + (uint32_t)(x - L.loff[s])];
           a.out_sa[base + x] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
         }
       } else if (cl == CLS_FULL) {
-        const uint64_t pos = a.ilist[a.ist[t0 + s] + (uint32_t)(x - L.loff[s])];
+        const uint64_t pos = a.ilist[slot_ist(a, t0 + s) + (uint32_t)(x - L.loff[s])];
         ch = a.bwlast[pos];
         if (a.want_sa && in_slice) {
           const uint32_t i = a.sa[t0 + s];
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, unsigned 
       for (uint32_t m = lane; m < k; m += 64) {
         const uint64_t t = g + m;
         lmoff[wv][m] = (uint32_t)(a.off[t] - base);
-        lmist[wv][m] = a.ist[t];
+        lmist[wv][m] = slot_ist(a, t);
         uint32_t sl = 0;
         if (a.want_sa) { const uint32_t i = a.sa[t]; sl = a.endpos[i] - i; }
         lmsl[wv][m] = sl;
@@ -407,11 +426,11 @@ __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgs a, const BigGro
     while (mh - ml > 1) { uint32_t mid = (ml + mh) >> 1; if (a.off[g + mid] - base <= e) ml = mid; else mh = mid; }
     const uint64_t t = g + ml;
     const uint32_t j = (uint32_t)(e - (a.off[t] - base));
-    const uint32_t pos = a.ilist[a.ist[t] + j];
+    const uint32_t pos = a.ilist[slot_ist(a, t) + j];
     uint64_t r = j;
     for (uint64_t t2 = g; t2 < g + k; t2++) {
       if (t2 == t) continue;
-      const uint32_t *lst = a.ilist + a.ist[t2];
+      const uint32_t *lst = a.ilist + slot_ist(a, t2);
       uint32_t l2 = 0, h2 = (uint32_t)(a.off[t2 + 1] - a.off[t2]);      // # entries < pos
       while (l2 < h2) { uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
       r += l2;
@@ -433,21 +452,28 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   DBuf<uint32_t> istart_lex(c, d), wistart(c, d);
   exclusive_sum_u32(c, occ_lex, istart_lex.p, d);
   hipLaunchKernelGGL(wistart_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, wistart.p);
-  DBuf<uint4> posrec(c, N);
-  DBuf<uint32_t> cnt(c, N + 8), grp(c, N + 8), ist(c, N + 8);
+  DBuf<uint16_t> pp16;
+  DBuf<uint64_t> pp64;
+  DBuf<uint32_t> cnt(c, N + 8), ist;
+  if (flags) { ist.alloc(c, N + 8); pp64.alloc(c, N); } else pp16.alloc(c, N);
   DBuf<uint8_t> pc(c, N + 8), hard(c, N);
   DBuf<uint64_t> off(c, N + 1);
   PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream));
   hard.zero();
-  { KScope ks(c, "pfp::posrec_kernel", N * (1 + 4 + 4 + 4 + 16));
-  hipLaunchKernelGGL(posrec_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, d, w, ix.pos_word.p,
-                     ix.endpos.p, so.rank.p, D.wocc.p, posrec.p); }
-  { KScope ks(c, "pfp::slot_gather_kernel", N * (4 + 16 + 13));
-  hipLaunchKernelGGL(slot_gather_kernel, dim3(cdiv(cdiv64(N, 8), 256)), dim3(256), 0, c->stream, N, so.sa.p, posrec.p,
-                     wistart.p, cnt.p, pc.p, grp.p, ist.p); }
+  { KScope ks(c, "pfp::pprec_kernel", N * (1 + 4 + 4 + (flags ? 8 : 2)));
+    if (flags) hipLaunchKernelGGL(pprec_kernel<uint64_t>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, d, w,
+                                  ix.pos_word.p, ix.endpos.p, D.wocc.p, pp64.p);
+    else hipLaunchKernelGGL(pprec_kernel<uint16_t>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, d, w,
+                            ix.pos_word.p, ix.endpos.p, D.wocc.p, pp16.p); }
+  { KScope ks(c, "pfp::slot_gather_kernel", N * (4 + 5 + (flags ? 12 : 2)));
+    const dim3 grid(cdiv(cdiv64(N, 8), 256));
+    if (flags) hipLaunchKernelGGL(slot_gather_kernel<uint64_t>, grid, dim3(256), 0, c->stream, N, so.sa.p, pp64.p,
+                                  ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, ist.p);
+    else hipLaunchKernelGGL(slot_gather_kernel<uint16_t>, grid, dim3(256), 0, c->stream, N, so.sa.p, pp16.p,
+                            ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, (uint32_t *)nullptr); }
   exclusive_sum_u32_u64(c, cnt.p, off.p, N + 1);
   { KScope ks(c, "pfp::group_flags_kernel", N * 5);
-  hipLaunchKernelGGL(group_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, grp.p, pc.p, flags ? 1 : 0, hard.p); }
+  hipLaunchKernelGGL(group_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.grp.p, pc.p, flags ? 1 : 0, hard.p); }
   const uint64_t n_out = read_scalar(c, off.p + N);
   PFP_REQUIRE(expect_n_out == 0 || n_out == expect_n_out, PFP_EFORMAT,
               "merge: sum of occurrence counts (" + std::to_string(n_out) + ") != text length + 1 (" +
@@ -456,7 +482,8 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   MergeArgs a{};
   a.N = N; a.n_out = n_out; a.d = d; a.w = w; a.want_sa = flags ? 1 : 0;
   { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
-  a.sa = so.sa.p; a.endpos = ix.endpos.p; a.grp = grp.p; a.ist = ist.p;
+  a.sa = so.sa.p; a.endpos = ix.endpos.p; a.grp = so.grp.p; a.ist = flags ? ist.p : nullptr;
+  a.pos_word = ix.pos_word.p; a.wistart = wistart.p;
   a.pc = pc.p; a.hard = hard.p; a.off = off.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p;
   // the caller's buffers hold positions [out_lo, out_hi): rebase so that kernels index by global position

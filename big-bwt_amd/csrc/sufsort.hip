@@ -126,6 +126,29 @@ __global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const uint3
   val[a] = i;
 }
 
+// Sparse rank materialisation (helpers).  Measured and NOT used inside the doubling loop: marking the
+// needed positions i+h in a bitmap and filling rank[] for them with one pass over all slots costs N
+// cache-resident random bit reads per round (4 ms at N = 260 M), no cheaper than the dense
+// scatter of write_back it was meant to replace (profiles/r01_notes.md).
+__global__ void mark_needed_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ act_i,
+                                   uint32_t *__restrict__ bits) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  const uint64_t j = (uint64_t)act_i[a] + h;
+  if (j < g.N) atomicOr(&bits[j >> 5], 1u << (j & 31));
+}
+__global__ void mark_positions_kernel(uint64_t cnt, const uint64_t *__restrict__ pos, uint32_t *__restrict__ bits) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < cnt) { const uint64_t j = pos[a]; atomicOr(&bits[j >> 5], 1u << (j & 31)); }
+}
+__global__ void provide_ranks_kernel(uint64_t N, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ grp,
+                                     const uint32_t *__restrict__ bits, uint32_t *__restrict__ rank) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const uint32_t j = sa[t];
+  if ((bits[j >> 5] >> (j & 31)) & 1u) rank[j] = grp[t];
+}
+
 // stream compaction of the active list: (slot, suffix, group) of every suffix that stays unresolved
 __global__ void compact3_kernel(uint64_t m, const uint8_t *__restrict__ keep, const uint32_t *__restrict__ inc,
                                 const uint32_t *__restrict__ aslot, const uint32_t *__restrict__ val,
@@ -154,11 +177,13 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
                                   const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead,
                                   const uint8_t *__restrict__ hd, const uint64_t *__restrict__ key0, uint64_t ones,
                                   uint64_t highs, uint32_t *__restrict__ sa, uint32_t *__restrict__ rank,
-                                  uint8_t *__restrict__ keep) {
+                                  uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   uint32_t i = val[a];
-  sa[aslot[a]] = i;
+  const uint32_t slot = aslot[a];
+  sa[slot] = i;
+  grp[slot] = newhead[a];       // slot-side copy of the group head: the merge never gathers rank[]
   rank[i] = newhead[a];
   bool single = hd[a] && (a + 1 == m || hd[a + 1]);
   bool fin = false;
@@ -175,7 +200,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   const uint64_t N = g.N;
   const int TB = 256;
   out.N = N;
-  out.sa.alloc(c, N); out.rank.alloc(c, N);
+  out.sa.alloc(c, N); out.rank.alloc(c, N); out.grp.alloc(c, N + 8);
   DBuf<uint64_t> keyo(c, N);
   DBuf<uint32_t> valo(c, N), aslot(c, N), aslot2(c, N), hv(c, N), newhead(c, N), inc(c, N), act_i(c, N), act_grp(c, N);
   DBuf<uint8_t> hd(c, N + 1), keep(c, N);
@@ -191,10 +216,10 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     inclusive_max_u32(c, hv.p, newhead.p, m);
     const bool round0 = first && ones != 0;
     first = false;
-    { KScope ks(c, "pfp::write_back_kernel", m * (13 + (round0 ? 8 : 4) + 9));
+    { KScope ks(c, "pfp::write_back_kernel", m * (13 + (round0 ? 8 : 4) + 13));
     hipLaunchKernelGGL(write_back_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p,
                        newhead.p, hd.p, round0 ? keyo.p : (const uint64_t *)nullptr, ones, highs, out.sa.p,
-                       out.rank.p, keep.p); }
+                       out.rank.p, out.grp.p, keep.p); }
     inclusive_count_eq_u8(c, keep.p, 1, inc.p, m);
     { KScope ks(c, "pfp::compact3_kernel", m * 17);
       hipLaunchKernelGGL(compact3_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keep.p, inc.p, aslot.p, valo.p,
@@ -212,6 +237,24 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     h *= 2;
     out.rounds++;
   }
+}
+
+// rank[] of a finished SuffixOrder is only defined where a doubling round needed it; these fill it
+// for a list of positions / for every position (debug validation, pfp tests)
+void materialize_ranks(pfp_ctx *c, SuffixOrder &so, const uint64_t *d_positions, uint64_t count) {
+  DBuf<uint32_t> bits(c, so.N / 32 + 2);
+  bits.zero();
+  hipLaunchKernelGGL(mark_positions_kernel, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, count, d_positions, bits.p);
+  hipLaunchKernelGGL(provide_ranks_kernel, dim3(cdiv(so.N, 256)), dim3(256), 0, c->stream, so.N, so.sa.p, so.grp.p, bits.p,
+                     so.rank.p);
+  PFP_HIP(hipGetLastError());
+}
+void materialize_all_ranks(pfp_ctx *c, SuffixOrder &so) {
+  DBuf<uint32_t> bits(c, so.N / 32 + 2);
+  PFP_HIP(hipMemsetAsync(bits.p, 0xff, (so.N / 32 + 2) * 4, c->stream));
+  hipLaunchKernelGGL(provide_ranks_kernel, dim3(cdiv(so.N, 256)), dim3(256), 0, c->stream, so.N, so.sa.p, so.grp.p, bits.p,
+                     so.rank.p);
+  PFP_HIP(hipGetLastError());
 }
 
 void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out) {

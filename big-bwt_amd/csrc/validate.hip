@@ -69,7 +69,7 @@ static int cmp_suffix(const std::vector<uint8_t> &b, uint32_t x, uint32_t y) {
   }
 }
 
-void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, const SuffixOrder &so, bool dict_mode, const char *what) {
+void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, SuffixOrder &so, bool dict_mode, const char *what) {
   const uint64_t N = so.N;
   auto sa = fetch(c, so.sa.p, N);
   auto rk = fetch(c, so.rank.p, N);
