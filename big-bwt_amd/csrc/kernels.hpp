@@ -31,6 +31,8 @@ void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p,
                 uint32_t *block_counts, unsigned long long *first_bad, const KRParams *kp_override = nullptr);
 uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, DBuf<uint64_t> &d_ends,
                    uint64_t *n_used, const KRParams *kp_override = nullptr);
+uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_used, int w, uint64_t max_phrase,
+                                const DBuf<uint64_t> &d_ends, uint64_t ne, KRParams &kp);
 // fused chain: reference triggers plus a few extra window hashes that split phrases longer than max_phrase
 uint64_t scan_text_adaptive(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, uint64_t max_phrase,
                             DBuf<uint64_t> &d_ends, uint64_t *n_used, uint32_t *n_extra);

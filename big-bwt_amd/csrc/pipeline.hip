@@ -637,12 +637,37 @@ __global__ void dist_sym_kernel(uint64_t P, const uint32_t *__restrict__ lpid, u
 
 extern "C" {
 
-int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p, int is_first,
-                         int is_last, uint64_t global_offset, int want_sai, uint64_t out_sizes[4]) {
-  if (!c || (!d_text && n) || !out_sizes) return PFP_EINVAL;
+// Extra trigger hashes this rank would add to split its giant phrases (<= 8, see scan.hip).  The
+// caller allgathers the proposals and hands the union to every rank's pfp_dist_local_parse, so that
+// all ranks scan with ONE trigger set.
+int pfp_dist_propose_triggers(pfp_ctx *c, const void *d_text, uint64_t n, int w, uint64_t p, uint32_t out_hashes[8],
+                              uint32_t *n_hashes) {
+  if (!c || (!d_text && n) || !out_hashes || !n_hashes) return PFP_EINVAL;
+  *n_hashes = 0;
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
   check_args(w, p, 0);
+  if (!c->max_phrase) return PFP_OK;
+  StagedText tx;
+  tx.stage(c, d_text, true, n, w);
+  DBuf<uint64_t> ends;
+  uint64_t used = 0;
+  KRParams kp = make_kr_params(w, p);
+  uint64_t ne = scan_text(c, tx, n, w, p, ends, &used, &kp);
+  propose_extra_triggers(c, tx, used, w, c->max_phrase, ends, ne, kp);
+  for (uint32_t q = 0; q < kp.nextra && q < 8; q++) out_hashes[(*n_hashes)++] = kp.extra[q];
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p, int is_first,
+                         int is_last, uint64_t global_offset, int want_sai, const uint32_t *extra_hashes,
+                         uint32_t n_extra, uint64_t out_sizes[4]) {
+  if (!c || (!d_text && n) || !out_sizes || (n_extra && !extra_hashes)) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  check_args(w, p, 0);
+  PFP_REQUIRE(n_extra <= KRParams::kMaxExtra, PFP_EINVAL, "too many extra trigger hashes");
   PFP_REQUIRE(is_first ? halo_len == 0 : halo_len >= (uint64_t)w, PFP_EINVAL, "halo must hold at least one window");
   PFP_REQUIRE(halo_len <= n, PFP_EINVAL, "halo longer than the local text");
   DistState *ds = dist_of(c);
@@ -650,7 +675,9 @@ int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t ha
   ds->w = w; ds->n_local = n;
   ds->tx.stage(c, d_text, true, n, w);
   uint64_t used = 0;
-  ds->n_ends = scan_text(c, ds->tx, n, w, p, ds->ends, &used);    // reference trigger set: identical on all ranks
+  KRParams kp = make_kr_params(w, p);                              // one trigger set on all ranks
+  for (uint32_t q = 0; q < n_extra; q++) { kp.extra[kp.nextra++] = extra_hashes[q]; kp.bloom |= 1ull << (extra_hashes[q] & 63); }
+  ds->n_ends = scan_text(c, ds->tx, n, w, p, ds->ends, &used, &kp);
   PFP_REQUIRE(used == n, PFP_EFORMAT, "bytes <= 2 inside a text shard are not supported in the multi-GPU chain");
   DBuf<uint64_t> tmp(c, 2);
   hipLaunchKernelGGL(count_below_kernel, dim3(1), dim3(1), 0, c->stream, ds->ends.p, ds->n_ends, halo_len, tmp.p);

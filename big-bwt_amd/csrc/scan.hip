@@ -316,44 +316,51 @@ __global__ void window_hash_kernel(const uint8_t *__restrict__ tbase, int w, con
   out[blockIdx.x * kCand + threadIdx.x] = h;
 }
 
+// one proposal round: window hashes (at most 8) that would split the phrases of this scan result
+// that are longer than max_phrase; appended to kp when new.  Returns how many were added.
+uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_used, int w, uint64_t max_phrase,
+                                const DBuf<uint64_t> &d_ends, uint64_t ne, KRParams &kp) {
+  const uint32_t cap = 8;
+  if (!max_phrase || max_phrase < 4 * (uint64_t)w + 2 * kCand + 64 || kp.nextra + cap > KRParams::kMaxExtra) return 0;
+  DBuf<uint32_t> cnt(c, 1), hashes(c, cap * kCand);
+  DBuf<uint64_t> picks(c, cap);
+  std::vector<uint32_t> hv(cap * kCand);
+  cnt.zero();
+  hipLaunchKernelGGL(giant_phrases_kernel, dim3(cdiv(ne + 1, 256)), dim3(256), 0, c->stream, d_ends.p, ne, n_used, w,
+                     max_phrase, cnt.p, picks.p, cap);
+  uint32_t ng = read_scalar(c, cnt.p);
+  if (!ng) return 0;
+  uint32_t take = ng < cap ? ng : cap;
+  hipLaunchKernelGGL(window_hash_kernel, dim3(take), dim3(kCand), 0, c->stream, tx.tbase(), w, picks.p, hashes.p);
+  PFP_HIP(hipMemcpyAsync(hv.data(), hashes.p, (size_t)take * kCand * 4, hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  // per giant phrase: the candidate window that is rarest among kCand consecutive ones.  A
+  // window seen more than 4 times there recurs every < 64 bytes (a run of one repeated char,
+  // a short period): adding it would only trade the giant phrase for millions of tiny ones.
+  uint32_t added = 0;
+  for (uint32_t q = 0; q < take; q++) {
+    const uint32_t *cand = hv.data() + (size_t)q * kCand;
+    uint32_t best = 0, best_mult = kCand + 1;
+    for (uint32_t x = 0; x < kCand; x++) {
+      uint32_t mult = 0;
+      for (uint32_t y = 0; y < kCand; y++) mult += cand[y] == cand[x];
+      if (mult < best_mult) { best_mult = mult; best = cand[x]; }
+    }
+    if (best_mult > 4) continue;
+    bool dup = false;
+    for (uint32_t z = 0; z < kp.nextra; z++) dup |= kp.extra[z] == best;
+    if (!dup) { kp.extra[kp.nextra++] = best; kp.bloom |= 1ull << (best & 63); added++; }
+  }
+  return added;
+}
+
 uint64_t scan_text_adaptive(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, uint64_t max_phrase,
                             DBuf<uint64_t> &d_ends, uint64_t *n_used, uint32_t *n_extra) {
   KRParams kp = make_kr_params(w, p);
   *n_extra = 0;
   uint64_t ne = scan_text(c, tx, n, w, p, d_ends, n_used, &kp);
-  if (!max_phrase || max_phrase < 4 * (uint64_t)w + 2 * kCand + 64) return ne;
-  const uint32_t cap = 8;
-  DBuf<uint32_t> cnt(c, 1), hashes(c, cap * kCand);
-  DBuf<uint64_t> picks(c, cap);
-  std::vector<uint32_t> hv(cap * kCand);
-  for (int iter = 0; iter < 4 && kp.nextra + cap <= KRParams::kMaxExtra; iter++) {
-    cnt.zero();
-    hipLaunchKernelGGL(giant_phrases_kernel, dim3(cdiv(ne + 1, 256)), dim3(256), 0, c->stream, d_ends.p, ne, *n_used, w,
-                       max_phrase, cnt.p, picks.p, cap);
-    uint32_t ng = read_scalar(c, cnt.p);
-    if (!ng) break;
-    uint32_t take = ng < cap ? ng : cap;
-    hipLaunchKernelGGL(window_hash_kernel, dim3(take), dim3(kCand), 0, c->stream, tx.tbase(), w, picks.p, hashes.p);
-    PFP_HIP(hipMemcpyAsync(hv.data(), hashes.p, (size_t)take * kCand * 4, hipMemcpyDeviceToHost, c->stream));
-    sync(c);
-    // per giant phrase: the candidate window that is rarest among kCand consecutive ones.  A
-    // window seen more than 4 times there recurs every < 64 bytes (a run of one repeated char,
-    // a short period): adding it would only trade the giant phrase for millions of tiny ones.
-    uint32_t added = 0;
-    for (uint32_t q = 0; q < take; q++) {
-      const uint32_t *cand = hv.data() + (size_t)q * kCand;
-      uint32_t best = 0, best_mult = kCand + 1;
-      for (uint32_t x = 0; x < kCand; x++) {
-        uint32_t mult = 0;
-        for (uint32_t y = 0; y < kCand; y++) mult += cand[y] == cand[x];
-        if (mult < best_mult) { best_mult = mult; best = cand[x]; }
-      }
-      if (best_mult > 4) continue;
-      bool dup = false;
-      for (uint32_t z = 0; z < kp.nextra; z++) dup |= kp.extra[z] == best;
-      if (!dup) { kp.extra[kp.nextra++] = best; kp.bloom |= 1ull << (best & 63); added++; }
-    }
-    if (!added) break;
+  for (int iter = 0; iter < 4; iter++) {
+    if (!propose_extra_triggers(c, tx, *n_used, w, max_phrase, d_ends, ne, kp)) break;
     ne = scan_text(c, tx, *n_used, w, p, d_ends, n_used, &kp);
   }
   *n_extra = kp.nextra;

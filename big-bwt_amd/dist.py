@@ -66,7 +66,16 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO):
     left = tails[rank - 1] if rank > 0 else shard[:0]
     local = torch.cat([left, shard]).contiguous() if rank > 0 else shard.contiguous()
     torch.cuda.synchronize(dev)
-    info = ctx.dist_local_parse(local.data_ptr(), local.numel(), left.numel(), w, p, rank == 0, rank == size - 1, goff, want_sai)
+    # --- one trigger set for all ranks: the reference's plus the union of every rank's proposals for
+    #     splitting giant phrases (N runs); the outputs do not depend on the parse
+    mine = ctx.dist_propose_triggers(local.data_ptr(), local.numel(), w, p)
+    prop = torch.full((8,), -1, dtype=torch.int64, device=dev)
+    if mine:
+        prop[: len(mine)] = torch.tensor(mine, dtype=torch.int64, device=dev)
+    props = yield ("allgather", prop)
+    extra = sorted({int(v) for t in props for v in t.tolist() if v >= 0})[:32]
+    info = ctx.dist_local_parse(local.data_ptr(), local.numel(), left.numel(), w, p, rank == 0, rank == size - 1, goff, want_sai,
+                                extra)
     if rank < size - 1:
         # the next rank re-derives my last phrase boundary from the last tail.numel() bytes of my shard
         if info["last_trigger"] - (w - 1) < local.numel() - tail.numel():
@@ -103,7 +112,7 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO):
     torch.cuda.synchronize(dev)
     ctx.dist_merge(sym_all.data_ptr(), sym_all.numel(), last_all.data_ptr(), sai_all.data_ptr() if want_sai else None, flags,
                    n_total, lo, hi, bwt.data_ptr(), sa.data_ptr() if flags else None)
-    stats = dict(local=info, glob=ginfo, phrases_total=int(sym_all.numel()), shard_bytes=n_shard)
+    stats = dict(local=info, glob=ginfo, phrases_total=int(sym_all.numel()), shard_bytes=n_shard, extra_triggers=len(extra))
     return dict(bwt=bwt[: hi - lo], sa=sa[: hi - lo] if flags else None, lo=lo, hi=hi, n_total=n_total, stats=stats)
 
 

@@ -31,7 +31,7 @@ SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror"
            "pfp_free", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak",
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_dev", "pfp_get_stats",
            "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
-           "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_merge", "pfp_dist_release"]
+           "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_merge", "pfp_dist_release"]
 
 
 class PfpError(RuntimeError):
@@ -293,11 +293,20 @@ class Context:
         return used.value
 
     # -- multi-GPU chain, one rank's share (device pointers; collectives are the caller's: dist.py)
-    def dist_local_parse(self, d_text_ptr, n, halo_len, w, p, is_first, is_last, global_offset, want_sai):
+    def dist_propose_triggers(self, d_text_ptr, n, w, p):
+        hashes = (C.c_uint32 * 8)()
+        cnt = C.c_uint32()
+        self._check(self.lib.pfp_dist_propose_triggers(self._h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_int(w),
+                                                       C.c_uint64(p), hashes, C.byref(cnt)))
+        return [int(hashes[i]) for i in range(cnt.value)]
+
+    def dist_local_parse(self, d_text_ptr, n, halo_len, w, p, is_first, is_last, global_offset, want_sai, extra=()):
         sizes = (C.c_uint64 * 4)()
+        ex = (C.c_uint32 * max(1, len(extra)))(*extra)
         self._check(self.lib.pfp_dist_local_parse(self._h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_uint64(halo_len),
                                                   C.c_int(w), C.c_uint64(p), C.c_int(int(is_first)), C.c_int(int(is_last)),
-                                                  C.c_uint64(global_offset), C.c_int(int(want_sai)), sizes))
+                                                  C.c_uint64(global_offset), C.c_int(int(want_sai)), ex,
+                                                  C.c_uint32(len(extra)), sizes))
         return dict(dict_bytes=int(sizes[0]), words=int(sizes[1]), phrases=int(sizes[2]), last_trigger=int(sizes[3]))
 
     def dist_export_local(self, d_dict=None, d_occ=None, d_last=None, d_sai=None):

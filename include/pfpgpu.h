@@ -166,6 +166,9 @@ void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
  * threading of pscan.hpp:114-165 and the output-range threading of pfthreads.hpp:456-493).
  * The caller (big-bwt_amd/dist.py, torch.distributed over RCCL) shards the text, moves the
  * halos and runs the allgathers between the steps; all pointers are device pointers.
+ *   pfp_dist_propose_triggers: window hashes (<= 8) that would split this shard's giant phrases
+ *       (pfp_set_max_phrase); the caller allgathers them, every rank passes the union as
+ *       extra_hashes so that all ranks parse with one trigger set (outputs do not depend on it)
  *   pfp_dist_local_parse : d_text = halo (the last halo_len bytes of the previous shard; 0 for the
  *       first rank) followed by this rank's shard, n bytes in all; global_offset = position of the
  *       shard's first byte in the whole text.  Owns the phrases that end inside the shard.
@@ -180,8 +183,11 @@ void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
  *       n_total = text length; emits BWT positions [out_lo,out_hi) into d_bwt_slice (u8) and, with
  *       flags, SA values into d_sa_slice (u64).
  * ------------------------------------------------------------------------------------ */
+int pfp_dist_propose_triggers(pfp_ctx *ctx, const void *d_text, uint64_t n, int w, uint64_t p,
+                              uint32_t out_hashes[8], uint32_t *n_hashes);
 int pfp_dist_local_parse(pfp_ctx *ctx, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p,
-                         int is_first, int is_last, uint64_t global_offset, int want_sai, uint64_t out_sizes[4]);
+                         int is_first, int is_last, uint64_t global_offset, int want_sai,
+                         const uint32_t *extra_hashes, uint32_t n_extra, uint64_t out_sizes[4]);
 int pfp_dist_export_local(pfp_ctx *ctx, void *d_dict, void *d_occ, void *d_last, void *d_sai);
 int pfp_dist_global(pfp_ctx *ctx, const void *d_union, uint64_t union_bytes, const void *d_union_occ,
                     uint64_t n_union, uint64_t my_word_base, void *d_sym_out, uint64_t out_info[3]);

@@ -88,14 +88,17 @@ def test_distributed_chain_matches_oracle(O, pkg, R):
     import importlib
     d = importlib.import_module("bigbwt_amd.dist")
     dev = torch.device("cuda:0")
-    text = O.gen_fasta(150000, 6, 0.002, 41)
+    text = O.gen_fasta(150000, 6, 0.002, 41, n_blocks=[(40000, 60000)])     # N block: giant phrase -> shared extra triggers
     n = len(text)
     cuts = [0] + [n * (r + 1) // R + (7 * r - 3) for r in range(R - 1)] + [n]     # uneven, unaligned shards
     ctxs = [pkg.Context(0) for _ in range(R)]
     try:
         for flags in (0, pkg.FLAG_SA):
             shards = [torch.from_numpy(text[cuts[r]:cuts[r + 1]].copy()).to(dev) for r in range(R)]
+            for c in ctxs:
+                c.set_max_phrase(2000)
             res = d.simulate(ctxs, shards, 10, 100, flags, halo=4096)
+            assert res[0]["stats"]["extra_triggers"] >= 1
             bwt = torch.cat([r["bwt"] for r in res]).cpu().numpy()
             want = O.bigbwt(text, 10, 100, flags)
             assert res[0]["lo"] == 0 and res[-1]["hi"] == n + 1
