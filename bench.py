@@ -239,6 +239,14 @@ def main():
                         frac=dom["frac"], traffic=None, us_per_launch=dom["us_per_launch"],
                         launches_per_step=dom["launches_per_step"], algo_bytes_per_launch=dom["algo_bytes_per_launch"],
                         share_of_step=round(dom["ms_per_step"] / ms_per_step, 3))
+        # HBM traffic of that kernel from the committed PMC passes (same workload), per launch like `achieved`
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_pmc_traffic.json")))
+            if args.workload == "c2" and world == 1 and dom["kernel"] in pmc["kernels"]:
+                roofline["traffic"] = int(pmc["kernels"][dom["kernel"]]["hbm_bytes_per_chain_corrected"] / dom["launches_per_step"])
+                roofline["traffic_source"] = "profiles/r01_c2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; 2*FETCH+WRITE)"
+        except Exception:
+            pass
         scan_row = next((x for x in rows if x["kernel"] == "pfp::kr_flag_kernel"), None)
         # the host-buffer entry point (pageable H2D of the text + D2H of the .bwt included): reported, never `value`
         host_boundary, host_ok = None, None
