@@ -40,6 +40,8 @@ WORKLOADS = {
                w=10, p=100, flags=0, desc="BASELINE configs[1]: 1x human-chr1-shaped FASTA (~253 MB), -w 10 -p 100, BWT only"),
     "c3": dict(G=12_100_020, C=64, r=1e-3, nblocks=[], w=10, p=100, flags=6,
                desc="BASELINE configs[2]: 64x mutated yeast-shaped FASTA (~0.79 GB), -w 10 -p 100, BWT + -s -e"),
+    "big": dict(G=12_100_020, C=512, r=1e-3, nblocks=[], w=10, p=100, flags=0,
+                desc="512x mutated yeast-shaped FASTA (~6.3 GB > 2^32 bytes), -w 10 -p 100, BWT only (robustness / scaling probe)"),
     "small": dict(G=6_000_000, C=4, r=1e-3, nblocks=[(1_000_000, 300_000)], w=10, p=100, flags=0,
                   desc="reduced smoke workload (not a reportable number)"),
 }
@@ -207,17 +209,22 @@ def main():
     ctx.set_profiling(False)
 
     # ---- correctness of what was just measured (outside the timed region)
-    hist_t = torch.bincount(text.to(torch.int64), minlength=256)
+    def hist(t):
+        h = torch.zeros(256, dtype=torch.int64, device=dev)
+        for s in range(0, t.numel(), 1 << 28):
+            h += torch.bincount(t[s:s + (1 << 28)].to(torch.int64), minlength=256)
+        return h
+    hist_t = hist(text)
     if collection:
         res = last_result["r"]
-        hist_b = torch.bincount(res["bwt"].to(torch.int64), minlength=256)
+        hist_b = hist(res["bwt"])
         dist.all_reduce(hist_t); dist.all_reduce(hist_b)
         hist_t[0] += 1
         dstats = res["stats"]
         st["n_phrases"], st["n_words"], st["dict_size"] = dstats["phrases_total"], dstats["glob"]["words"], dstats["glob"]["dict_bytes"]
     else:
         hist_t[0] += 1
-        hist_b = torch.bincount(bwt[: n + 1].to(torch.int64), minlength=256)
+        hist_b = hist(bwt[: n + 1])
     verified = bool(torch.equal(hist_t, hist_b))
 
     out = None

@@ -392,10 +392,25 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, unsigned 
       }
       __builtin_amdgcn_wave_barrier();
       __threadfence_block();
+      // rank of every occurrence among all E: either count the smaller ones directly (E broadcast LDS
+      // reads) or, when the group is a few long sorted lists (k members, E/k each), own index +
+      // lower_bound in each other member's LDS segment (k * log2(E/k) dependent reads)
+      uint32_t lg = 1;
+      while ((k << lg) < (uint32_t)E) lg++;
+      const bool by_search = (uint64_t)k * (lg + 1) * 3 < E;
       for (uint32_t e = lane; e < (uint32_t)E; e += 64) {
         const uint32_t pos = lpos[wv][e];
         uint32_t r = 0;
-        for (uint32_t q = 0; q < (uint32_t)E; q++) r += lpos[wv][q] < pos;
+        if (!by_search) {
+          for (uint32_t q = 0; q < (uint32_t)E; q++) r += lpos[wv][q] < pos;
+        } else {
+          for (uint32_t m2 = 0; m2 < k; m2++) {
+            uint32_t l2 = lmoff[wv][m2], h2 = lmoff[wv][m2 + 1];       // # entries < pos in member m2's segment
+            const uint32_t s0 = l2;
+            while (l2 < h2) { uint32_t mid = (l2 + h2) >> 1; if (lpos[wv][mid] < pos) l2 = mid + 1; else h2 = mid; }
+            r += l2 - s0;
+          }
+        }
         if (base + r >= a.out_lo && base + r < a.out_hi) {
           a.bwt[base + r] = lch[wv][e];
           if (a.want_sa) a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)lsl[wv][e];
