@@ -84,18 +84,6 @@ def first_window_triggers(text, w, p, O):
     return O.kr_window(bytes(text[:w].cpu().numpy().tobytes())) % p == 0
 
 
-def time_events_ms(ext_stream, fn, reps):
-    """average device time of fn() (which only enqueues on ext_stream) over reps launches"""
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in evs:
-        a.record(ext_stream)
-        fn()
-        b.record(ext_stream)
-    ext_stream.synchronize()
-    ts = [a.elapsed_time(b) for a, b in evs]
-    return float(np.mean(ts)), float(np.min(ts))
-
-
 def cpu_baseline(text_host, w, p, flags, O, sample_bytes):
     """the real reference (newscanNT.x -> bwtparse -> pfbwtNT.x, 1 thread) on a prefix of the text"""
     sample = text_host[:sample_bytes]
