@@ -27,6 +27,13 @@ void sort_pairs_u32_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, const u
   KScope ks(c, "rocprim::radix_sort_pairs<u32,u32>", n * 4 + passes * n * 16);
   PRIM2(rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, (unsigned)bb, (unsigned)eb, c->stream));
 }
+void segsort_pairs_u32_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                           size_t nseg, const uint32_t *seg_begin, const uint32_t *seg_end, int bb, int eb) {
+  if (!n || !nseg) return;
+  KScope ks(c, "rocprim::segmented_radix_sort_pairs<u32,u32>", n * 16 + nseg * 8);
+  PRIM2(rocprim::segmented_radix_sort_pairs(tmp, tb, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, seg_begin, seg_end,
+                                            (unsigned)bb, (unsigned)eb, c->stream));
+}
 void exclusive_sum_u32(pfp_ctx *c, const uint32_t *in, uint32_t *out, size_t n) {
   if (!n) return;
   KScope ks(c, "rocprim::scan<u32>", n * 8);

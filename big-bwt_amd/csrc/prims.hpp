@@ -9,6 +9,9 @@ void sort_pairs_u64_u32(pfp_ctx *c, const uint64_t *kin, uint64_t *kout, const u
                         size_t n, int begin_bit, int end_bit);
 void sort_pairs_u32_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
                         size_t n, int begin_bit, int end_bit);
+// stable radix sort inside each segment [begin[k], end[k]) (one already-grouped array)
+void segsort_pairs_u32_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                           size_t nseg, const uint32_t *seg_begin, const uint32_t *seg_end, int begin_bit, int end_bit);
 // out[i] = sum_{j<i} in[j]
 void exclusive_sum_u32(pfp_ctx *c, const uint32_t *in, uint32_t *out, size_t n);
 void exclusive_sum_u32_u64(pfp_ctx *c, const uint32_t *in, uint64_t *out, size_t n);

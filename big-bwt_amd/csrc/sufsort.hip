@@ -18,6 +18,7 @@
 #include "prims.hpp"
 #include "devutil.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace pfp {
 
@@ -149,6 +150,38 @@ __global__ void provide_ranks_kernel(uint64_t N, const uint32_t *__restrict__ sa
   if ((bits[j >> 5] >> (j & 31)) & 1u) rank[j] = grp[t];
 }
 
+// segmented variant of a doubling round: the unresolved suffixes are already grouped (the active
+// list is in slot order), so only the 32-bit "next" key has to be sorted, inside every group
+__global__ void group_starts_kernel(uint64_t m, const uint32_t *__restrict__ act_grp, uint8_t *__restrict__ gs) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < m) gs[a] = (a == 0 || act_grp[a] != act_grp[a - 1]) ? 1 : 0;
+}
+__global__ void build_keys32_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ act_i,
+                                    const uint32_t *__restrict__ rank, uint32_t *__restrict__ key,
+                                    uint32_t *__restrict__ val) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  const uint32_t i = act_i[a];
+  key[a] = (g.mode == MODE_DICT || (uint64_t)i + h < g.N) ? rank[i + h] + 1u : 0u;
+  val[a] = i;
+}
+__global__ void seg_end_kernel(uint32_t ng, uint32_t m, const uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
+                               uint32_t *__restrict__ maxlen) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t len = 0;
+  if (k < ng) { uint32_t e = (k + 1 < ng) ? seg_begin[k + 1] : m; seg_end[k] = e; len = e - seg_begin[k]; }
+  for (int o = 32; o > 0; o >>= 1) { uint32_t v = __shfl_down(len, o, 64); len = v > len ? v : len; }
+  if ((threadIdx.x & 63) == 0 && len) atomicMax(maxlen, len);
+}
+__global__ void heads32_kernel(uint64_t m, const uint8_t *__restrict__ gs, const uint32_t *__restrict__ key,
+                               const uint32_t *__restrict__ aslot, uint8_t *__restrict__ hd, uint32_t *__restrict__ hv) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  bool h = gs[a] || key[a] != key[a - 1];
+  hd[a] = h ? 1 : 0;
+  hv[a] = h ? aslot[a] : 0u;
+}
+
 // stream compaction of the active list: (slot, suffix, group) of every suffix that stays unresolved
 __global__ void compact3_kernel(uint64_t m, const uint8_t *__restrict__ keep, const uint32_t *__restrict__ inc,
                                 const uint32_t *__restrict__ aslot, const uint32_t *__restrict__ val,
@@ -158,6 +191,20 @@ __global__ void compact3_kernel(uint64_t m, const uint8_t *__restrict__ keep, co
   if (a >= m || !keep[a]) return;
   const uint32_t o = inc[a] - 1;
   aslot2[o] = aslot[a]; act_i[o] = val[a]; act_grp[o] = newhead[a];
+}
+
+// number of unresolved groups after a round (their heads stay unresolved with them).  A fixed grid
+// of grid-stride workgroups, one atomic per workgroup: a per-wave atomic on one word serialises
+// (4 M atomics = 24 ms at N = 260 M).
+__global__ __launch_bounds__(256) void count_groups_kernel(uint64_t m, const uint8_t *__restrict__ keep,
+                                                           const uint8_t *__restrict__ hd, uint32_t *__restrict__ n_groups) {
+  uint32_t cnt = 0;
+  for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < m; a += (uint64_t)gridDim.x * 256) cnt += (keep[a] && hd[a]) ? 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  __shared__ uint32_t ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t t = ws[0] + ws[1] + ws[2] + ws[3]; if (t) atomicAdd(n_groups, t); }
 }
 
 __global__ void heads_kernel(uint64_t m, const uint64_t *__restrict__ key, const uint32_t *__restrict__ aslot,
@@ -210,9 +257,18 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   out.rounds = 0;
   bool first = true;
   const int keybits = 32 + bits_for(N);
+  static const bool use_segsort = []() { const char *e = getenv("PFP_SEGSORT"); return !(e && e[0] == '0'); }();
+  DBuf<uint8_t> gs;
+  DBuf<uint32_t> k32, k32o, segb, sege, nseg_d, ngrp_d(c, 1);
+  bool seg_round = false;       // the keys of this round live in k32o (segmented path) instead of keyo
   for (;;) {
-    { KScope ks(c, "pfp::heads_kernel", m * 17);
-    hipLaunchKernelGGL(heads_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p); }
+    if (seg_round) {
+      KScope ks(c, "pfp::heads_kernel", m * 14);
+      hipLaunchKernelGGL(heads32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, gs.p, k32o.p, aslot.p, hd.p, hv.p);
+    } else {
+      KScope ks(c, "pfp::heads_kernel", m * 17);
+      hipLaunchKernelGGL(heads_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p);
+    }
     inclusive_max_u32(c, hv.p, newhead.p, m);
     const bool round0 = first && ones != 0;
     first = false;
@@ -221,19 +277,53 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
                        newhead.p, hd.p, round0 ? keyo.p : (const uint64_t *)nullptr, ones, highs, out.sa.p,
                        out.rank.p, out.grp.p, keep.p); }
     inclusive_count_eq_u8(c, keep.p, 1, inc.p, m);
+    PFP_HIP(hipMemsetAsync(ngrp_d.p, 0, 4, c->stream));
     { KScope ks(c, "pfp::compact3_kernel", m * 17);
-      hipLaunchKernelGGL(compact3_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keep.p, inc.p, aslot.p, valo.p,
-                         newhead.p, aslot2.p, act_i.p, act_grp.p); }
+      hipLaunchKernelGGL(compact3_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keep.p, inc.p, aslot.p,
+                         valo.p, newhead.p, aslot2.p, act_i.p, act_grp.p); }
+    if (use_segsort)
+      hipLaunchKernelGGL(count_groups_kernel, dim3((int)std::min<uint64_t>(cdiv64(m, 256), 2048)), dim3(256), 0, c->stream, m,
+                         keep.p, hd.p, ngrp_d.p);
     PFP_HIP(hipGetLastError());
-    uint32_t m2 = read_scalar(c, inc.p + (m - 1));
+    PFP_HIP(hipMemcpyAsync(c->h_scalars, inc.p + (m - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, ngrp_d.p, 4, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    uint32_t m2, ngrp;
+    memcpy(&m2, c->h_scalars, 4); memcpy(&ngrp, c->h_scalars + 1, 4);
     std::swap(aslot.p, aslot2.p);
     m = m2;
     if (m == 0) break;
     PFP_REQUIRE(h < 2 * N, PFP_EHIP, "suffix sort failed to converge");
-    { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 4 + 12));
-    hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p,
-                       out.rank.p, key.p, val.p); }
-    sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, keybits);
+    // Rounds after the first: the unresolved suffixes are already grouped, only the 32-bit "next"
+    // key has to be ordered inside every group.  When the groups are many and of moderate size (a
+    // dictionary of near-identical variants) a segmented sort moves 16 B per suffix instead of the
+    // 7 x 24 B of a global 53-bit radix sort (big: 240 -> 126 ms of sorting).  rocPRIM's segmented
+    // sort serialises a giant segment on one workgroup (the 300 k run of one symbol in a parse cost
+    // 68 ms), and for tiny groups its bookkeeping eats the gain, so the choice is per round.
+    seg_round = false;
+    if (use_segsort && m >= (1u << 20) && ngrp && m / ngrp >= 24) {
+      if (!gs.p) { gs.alloc(c, N); k32.alloc(c, N); k32o.alloc(c, N); segb.alloc(c, N + 1); sege.alloc(c, N + 1); nseg_d.alloc(c, 2); }
+      hipLaunchKernelGGL(group_starts_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, act_grp.p, gs.p);
+      select_index_u32(c, gs.p, segb.p, nseg_d.p, m);
+      PFP_HIP(hipMemsetAsync(nseg_d.p + 1, 0, 4, c->stream));
+      const uint32_t ng = read_scalar(c, nseg_d.p);
+      hipLaunchKernelGGL(seg_end_kernel, dim3(cdiv(ng, TB)), dim3(TB), 0, c->stream, ng, (uint32_t)m, segb.p, sege.p,
+                         nseg_d.p + 1);
+      const uint32_t maxlen = read_scalar(c, nseg_d.p + 1);
+      if (maxlen <= (1u << 15) && m / ng >= 24) {
+        { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
+          hipLaunchKernelGGL(build_keys32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, out.rank.p,
+                             k32.p, val.p); }
+        segsort_pairs_u32_u32(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, bits_for(N));
+        seg_round = true;
+      }
+    }
+    if (!seg_round) {
+      { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 4 + 12));
+      hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p,
+                         out.rank.p, key.p, val.p); }
+      sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, keybits);
+    }
     h *= 2;
     out.rounds++;
   }
