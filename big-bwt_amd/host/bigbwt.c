@@ -10,7 +10,10 @@
  *
  * Outputs next to the input, byte formats as the reference: .bwt always; .sa | .ssa | .esa;
  * .log (appended).  -t is accepted and ignored (the GPU is the helper); -P is accepted and
- * unnecessary (phrase deduplication is exact).  -f and --compress are not implemented yet.
+ * unnecessary (phrase deduplication is exact).  -f reads FASTA/FASTQ (plain or gzip) exactly as the
+ * reference's kseq reader does (fasta.c); with -f the -c check runs on that filtered text (the
+ * reference compares against the raw file, bigbwt:183-184, which can never match).
+ * --compress is not implemented.
  */
 #define _GNU_SOURCE
 #include <errno.h>
@@ -25,6 +28,7 @@
 #include <time.h>
 #include <unistd.h>
 #include "pfpgpu.h"
+#include "fasta.h"
 
 static double now_s(void) {
   struct timespec ts;
@@ -68,7 +72,7 @@ static void usage(const char *argv0) {
          "  -k               keep temporary files (.dict .occ .parse .last .sai .ilist .bwlast .bwsai)\n"
          "  -v               verbose\n"
          "  -c               check BWT against the whole-text suffix array (reference: SACA-K)\n"
-         "  -f               read fasta (not implemented in this build)\n"
+         "  -f               read fasta/fastq, plain or gzip (headers and newlines dropped, upper-cased)\n"
          "  --sum            compute output files sha256sum\n"
          "  --parsing        stop after the parsing phase (debug only)\n"
          "  --compress       compress output of the parsing phase (not implemented in this build)\n"
@@ -114,8 +118,8 @@ int main(int argc, char **argv) {
     printf("You can either compute the full SA or a sample of it, not both. Exiting...\n");
     return 0;
   }
-  if (fasta || compress) {
-    printf("%s is not supported by this build. Exiting...\n", fasta ? "-f (fasta mode)" : "--compress");
+  if (compress) {
+    printf("--compress is not supported by this build. Exiting...\n");
     return 1;
   }
   char logname[4096];
@@ -124,12 +128,25 @@ int main(int argc, char **argv) {
   FILE *logf = fopen(logname, "a");
   if (!logf) { perror(logname); return 1; }
 
-  int fd = open(input, O_RDONLY);
-  struct stat sb;
-  if (fd < 0 || fstat(fd, &sb) != 0) { perror(input); return 1; }
-  uint64_t n = (uint64_t)sb.st_size;
-  const uint8_t *text = n ? mmap(NULL, n, PROT_READ, MAP_PRIVATE, fd, 0) : (const uint8_t *)"";
-  if (text == MAP_FAILED) { perror("mmap"); return 1; }
+  uint64_t n = 0;
+  const uint8_t *text = NULL;
+  if (fasta) {      /* newscan.cpp:332-352: gzopen + kseq, sequences only */
+    size_t raw_n = 0;
+    uint8_t *raw = pfp_read_maybe_gz(input, &raw_n);
+    if (!raw) { perror(input); return 1; }
+    uint8_t *seq = malloc(raw_n ? raw_n : 1);
+    if (!seq) { fprintf(stderr, "out of memory\n"); return 1; }
+    n = pfp_fasta_text(raw, raw_n, seq);
+    free(raw);
+    text = seq;
+  } else {
+    int fd = open(input, O_RDONLY);
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0) { perror(input); return 1; }
+    n = (uint64_t)sb.st_size;
+    text = n ? mmap(NULL, n, PROT_READ, MAP_PRIVATE, fd, 0) : (const uint8_t *)"";
+    if (text == MAP_FAILED) { perror("mmap"); return 1; }
+  }
 
   pfp_ctx *ctx = NULL;
   int rc = pfp_ctx_create(&ctx, device);

@@ -290,6 +290,16 @@ def run_ref(text: bytes, w=10, p=100, flags=0, threads=0, keep_dir=None, want_in
 _M64 = (1 << 64) - 1
 
 
+def fasta_text(raw):
+    """the text `bigbwt -f` parses: sequences of a FASTA/FASTQ buffer, upper-cased (orc_fasta_text)"""
+    raw = np.ascontiguousarray(np.frombuffer(bytes(raw), dtype=np.uint8))
+    out = np.zeros(max(raw.size, 1), dtype=np.uint8)
+    lib().orc_fasta_text.restype = C.c_uint64
+    got = lib().orc_fasta_text(raw.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint64(raw.size),
+                               out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out[:got].copy()
+
+
 def gen_fasta(G, C_, r, seed, n_blocks=()):
     """GEN(G,C,r,seed) of SURVEY.md section 4, scalar xorshift64 spec (run in C: orc_gen_fasta).
     n_blocks: optional [(start,len),...] ranges of the base genome overwritten by 'N' (config 2)."""

@@ -12,6 +12,7 @@
  */
 #define _GNU_SOURCE
 #include "pfp_oracle.h"
+#include <ctype.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
@@ -531,5 +532,72 @@ uint64_t orc_gen_fasta(uint64_t G, uint32_t C, double r, uint64_t seed, const ui
   }
 #undef RND
   free(base);
+  return o;
+}
+
+/* ---- FASTA/FASTQ input (bigbwt -f) -------------------------------------------------------------
+ * Restates kseq.h's reader as newscan.cpp:332-352 drives it.  rd_getc = ks_getc (kseq.h:77-91),
+ * rd_line = ks_getuntil2(KS_SEP_LINE, append=1) (kseq.h:94-146): appends the rest of the line,
+ * removes a trailing '\r' when the string is longer than one char, returns -1 only when no byte
+ * was available.  rd_word = ks_getuntil2(KS_SEP_SPACE) and reports the delimiter. */
+typedef struct { const uint8_t *b; uint64_t n, i; } rd_t;
+typedef struct { uint8_t *s; uint64_t l; } str_t;
+static int rd_getc(rd_t *r) { return r->i < r->n ? r->b[r->i++] : -1; }
+static int rd_line(rd_t *r, str_t *s, int keep) {
+  if (r->i >= r->n) return -1;
+  while (r->i < r->n && r->b[r->i] != '\n') { if (keep) s->s[s->l] = r->b[r->i]; s->l++; r->i++; }
+  if (r->i < r->n) r->i++;
+  if (keep) { if (s->l > 1 && s->s[s->l - 1] == '\r') s->l--; }
+  return 0;
+}
+static int rd_word(rd_t *r, int *delim) {
+  *delim = 0;
+  if (r->i >= r->n) return -1;
+  while (r->i < r->n && !isspace(r->b[r->i])) r->i++;
+  if (r->i < r->n) *delim = r->b[r->i++];
+  return 0;
+}
+/* one kseq_read (kseq.h:178-222): >=0 sequence length in seq, -1 end of file, -2 truncated quality */
+static int64_t fasta_next(rd_t *r, int *last_char, str_t *seq, uint8_t *scratch) {
+  int c;
+  if (*last_char == 0) {
+    while ((c = rd_getc(r)) >= 0 && c != '>' && c != '@') {}
+    if (c < 0) return -1;
+    *last_char = c;
+  }
+  seq->l = 0;
+  if (rd_word(r, &c) < 0) return -1;
+  if (c != '\n') { str_t dump = {NULL, 0}; rd_line(r, &dump, 0); }
+  while ((c = rd_getc(r)) >= 0 && c != '>' && c != '+' && c != '@') {
+    if (c == '\n') continue;
+    seq->s[seq->l++] = (uint8_t)c;
+    rd_line(r, seq, 1);
+  }
+  if (c == '>' || c == '@') *last_char = c;
+  if (c != '+') return (int64_t)seq->l;
+  while ((c = rd_getc(r)) >= 0 && c != '\n') {}
+  if (c < 0) return -2;
+  str_t q = {scratch, 0};
+  while (rd_line(r, &q, 1) >= 0 && q.l < seq->l) {}
+  *last_char = 0;
+  if (seq->l != q.l) return -2;
+  return (int64_t)seq->l;
+}
+uint64_t orc_fasta_text(const uint8_t *in, uint64_t n, uint8_t *out) {
+  rd_t r = {in, n, 0};
+  uint8_t *buf = malloc(n ? n : 1), *scratch = malloc(n ? n : 1);
+  str_t seq = {buf, 0};
+  int last_char = 0;
+  uint64_t o = 0;
+  int64_t l;
+  int stop = 0;
+  while (!stop && (l = fasta_next(&r, &last_char, &seq, scratch)) >= 0) {
+    for (int64_t i = 0; i < l; i++) {
+      int ch = toupper(seq.s[i]);
+      if (ch <= 2) { stop = 1; break; }      /* newscan.cpp:340-343, 349 */
+      out[o++] = (uint8_t)ch;
+    }
+  }
+  free(buf); free(scratch);
   return o;
 }

@@ -86,6 +86,10 @@ void orc_unpack5(const uint8_t *in, uint64_t cnt, uint64_t *v);
 uint64_t orc_gen_fasta(uint64_t G, uint32_t C, double r, uint64_t seed, const uint64_t *nblk, uint32_t nnblk,
                        uint8_t *out, uint64_t cap);
 
+/* newscan.cpp:332-352 (-f) over kseq.h:178-222: the text the parser sees for a FASTA/FASTQ file.
+ * out must hold n bytes; returns the bytes written. */
+uint64_t orc_fasta_text(const uint8_t *in, uint64_t n, uint8_t *out);
+
 void orc_free(void *p);
 
 #ifdef __cplusplus
