@@ -13,7 +13,8 @@
  * unnecessary (phrase deduplication is exact).  -f reads FASTA/FASTQ (plain or gzip) exactly as the
  * reference's kseq reader does (fasta.c); with -f the -c check runs on that filtered text (the
  * reference compares against the raw file, bigbwt:183-184, which can never match).
- * --compress is not implemented.
+ * --parsing and --compress write the overlap-free dictionary (.dicz) as the reference does
+ * (bigbwt:81); --compress then shells out to tar/xz exactly as bigbwt:98 does.
  */
 #define _GNU_SOURCE
 #include <errno.h>
@@ -75,7 +76,7 @@ static void usage(const char *argv0) {
          "  -f               read fasta/fastq, plain or gzip (headers and newlines dropped, upper-cased)\n"
          "  --sum            compute output files sha256sum\n"
          "  --parsing        stop after the parsing phase (debug only)\n"
-         "  --compress       compress output of the parsing phase (not implemented in this build)\n"
+         "  --compress       compress output of the parsing phase (.parse.txz of .parse and .dicz)\n"
          "  -P, --probing    accepted for compatibility (deduplication here is exact)\n",
          argv0);
 }
@@ -118,10 +119,6 @@ int main(int argc, char **argv) {
     printf("You can either compute the full SA or a sample of it, not both. Exiting...\n");
     return 0;
   }
-  if (compress) {
-    printf("--compress is not supported by this build. Exiting...\n");
-    return 1;
-  }
   char logname[4096];
   snprintf(logname, sizeof logname, "%s.log", input);
   printf("Sending logging messages to file: %s\n", logname);
@@ -161,7 +158,7 @@ int main(int argc, char **argv) {
   double start0 = now_s(), start = start0;
   int status = 0;
 
-  if (keep || parsing) {
+  if (keep || parsing || compress) {
     /* staged run: materialise the reference's temp files (bigbwt -k / --parsing) */
     pfp_parse_result pr;
     printf("==== Parsing. Command: pfp_parse(%s, -w %d -p %llu%s)\n", input, w, p, flags ? " -s" : "");
@@ -169,19 +166,43 @@ int main(int argc, char **argv) {
     if (rc) goto fail;
     fprintf(logf, "Found %llu distinct words\nTotal number of words: %llu\n", (unsigned long long)pr.n_words,
             (unsigned long long)pr.n_phrases);
-    status |= write_file(input, "dict", pr.dict, pr.dict_size);
     status |= write_file(input, "parse", pr.parse, pr.n_phrases * 4);
-    if (!parsing) {   /* bigbwt:88-94 removes .last/.occ after --parsing */
-      status |= write_file(input, "occ", pr.occ, pr.n_words * 4);
-      status |= write_file(input, "last", pr.last, pr.n_phrases);
-      if (flags) status |= write_file(input, "sai", pr.sai, pr.n_phrases * 5);
-    }
-    printf("Elapsed time: %.4f\n", now_s() - start);
-    if (parsing) {
-      printf("==== Stopping after the parsing phase as requested\n");
+    if (flags) status |= write_file(input, "sai", pr.sai, pr.n_phrases * 5);
+    if (parsing || compress) {
+      /* bigbwt:81 passes -c to the parser for both: the dictionary is written without the overlaps
+       * (.dicz, what unparse reads); bigbwt:88-94 then removes .last/.occ, which are not written here */
+      uint8_t *z = malloc(pr.dict_size + 1);
+      if (!z) { fprintf(stderr, "out of memory\n"); return 1; }
+      status |= write_file(input, "dicz", z, pfp_dicz_from_dict(pr.dict, pr.dict_size, w, z));
+      free(z);
+      printf("Elapsed time: %.4f\n", now_s() - start);
       pfp_parse_result_free(&pr);
-      goto done;
+      if (parsing) {
+        printf("==== Stopping after the parsing phase as requested\n");
+        goto done;
+      }
+      /* bigbwt:95-105 */
+      start = now_s();
+      char cmd[3 * 4096 + 64];
+      snprintf(cmd, sizeof cmd, "XZ_OPT=-9 tar -cJf '%s.parse.txz' '%s.parse' '%s.dicz'", input, input, input);
+      printf("==== Compressing. Command: %s\n", cmd);
+      if (system(cmd) != 0) { printf("Error executing command line:\n\t%s\nCheck log file: %s\n", cmd, logname); status = 1; goto done; }
+      printf("Elapsed time: %.4f\n", now_s() - start);
+      if (!keep) {   /* delete_temp_files, bigbwt:201-217: .dicz stays */
+        char nm[4096 + 16];
+        printf("==== Deleting temporary files.\n");
+        snprintf(nm, sizeof nm, "%s.parse", input); unlink(nm);
+        if (s || S) { snprintf(nm, sizeof nm, "%s.sai", input); unlink(nm); }   /* bigbwt:210: not for -e alone */
+      }
+      printf("==== Done: Parsing output xz-compressed as requested\n");
+      fclose(logf);
+      pfp_ctx_destroy(ctx);
+      return status ? 1 : 0;
     }
+    status |= write_file(input, "dict", pr.dict, pr.dict_size);
+    status |= write_file(input, "occ", pr.occ, pr.n_words * 4);
+    status |= write_file(input, "last", pr.last, pr.n_phrases);
+    printf("Elapsed time: %.4f\n", now_s() - start);
     start = now_s();
     uint64_t P = pr.n_phrases;
     uint32_t *ilist = malloc((P + 1) * 4);

@@ -83,3 +83,18 @@ uint8_t *pfp_read_maybe_gz(const char *path, size_t *n) {
   *n = len;
   return buf;
 }
+
+size_t pfp_dicz_from_dict(const uint8_t *dict, size_t dict_size, int w, uint8_t *out) {
+  size_t o = 0, s = 0;
+  for (size_t i = 0; i + 1 < dict_size; i++) {
+    if (dict[i] != 1) continue;
+    size_t b = s, e = i - (size_t)w;
+    if (dict[b] == 2) b++;
+    memcpy(out + o, dict + b, e - b);
+    o += e - b;
+    out[o++] = 1;
+    s = i + 1;
+  }
+  out[o++] = 0;
+  return o;
+}

@@ -98,7 +98,31 @@ def main():
         soups.append([raw.hex(), text.hex()])
     subprocess.call(["rm", "-rf", tmp])
     print("soups:", len(soups), "non-empty texts:", sum(1 for s in soups if s[1]))
-    json.dump(dict(cases=res, soups=soups), open(os.path.join(HERE, "golden_fasta.json"), "w"), indent=1)
+    # newscanNT.x -c: the compressed dictionary (.dicz) and the parse unparse rebuilds the text from
+    dicz = []
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as entry
+    from textgen import make_text
+    O = entry.load_oracle()
+    spec = dict(kind="gen", G=20000, C=3, r=0.002, seed=11)
+    inputs = [("gen_small", make_text(spec, O).tobytes(), False, spec)] + [(n, r, True, None) for n, r in cases() if n in ("gzip_three_copies", "two_records")]
+    for name, raw, fasta, spec in inputs:
+        tmp = tempfile.mkdtemp(prefix="pfpfa_", dir="/dev/shm")
+        f = os.path.join(tmp, "t")
+        open(f, "wb").write(raw)
+        subprocess.check_call([os.path.join(REF, "newscanNT.x"), f, "-w", "10", "-p", "100", "-c"] + (["-f"] if fasta else []),
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.check_call([os.path.join(REF, "unparse"), f], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        z = open(f + ".dicz", "rb").read()
+        out = open(f + ".out", "rb").read()
+        dicz.append(dict(name=name, fasta=fasta, spec=spec, raw_hex=None if spec else raw.hex(), w=10, p=100,
+                         dicz_sha256=hashlib.sha256(z).hexdigest(), dicz_len=len(z),
+                         parse_sha256=hashlib.sha256(open(f + ".parse", "rb").read()).hexdigest(),
+                         unparse_sha256=hashlib.sha256(out).hexdigest(), unparse_len=len(out)))
+        print("dicz", name, len(z), "unparse", len(out))
+        subprocess.call(["rm", "-rf", tmp])
+    json.dump(dict(cases=res, soups=soups, dicz=dicz), open(os.path.join(HERE, "golden_fasta.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
