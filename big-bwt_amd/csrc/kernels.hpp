@@ -68,9 +68,28 @@ struct SuffixOrder {
   uint64_t N = 0;
   DBuf<uint32_t> sa;     // [N] suffix start positions in sorted order (ties: position order)
   DBuf<uint32_t> grp;    // [N] grp[t] = first sa slot of slot t's group (equal strings share it)
-  DBuf<uint32_t> rank;   // [N] rank[i] = grp[slot of i]; defined only where materialised (see below)
+  DBuf<uint32_t> rank;   // [N] rank[i] = grp[slot of i]; kNoRank where the sorter never needed it (see RankView)
   uint64_t rounds = 0;
+  // Dictionary mode keeps the sorted first-round keys: the rank of a suffix that the first round
+  // already settled is the lower bound of its packed key among them, found on demand instead of
+  // being scattered to rank[] for all N positions (the scatter was 9 ms of 56 at N = 260 M).
+  DBuf<uint64_t> skeys;  // [N] packed keys of the first round in sorted order
+  DBuf<uint32_t> tab;    // [T] 0xFFFFFFFF - (first slot whose key has top bits >= T-1-r), r reversed bucket
+  DBuf<uint8_t> lut;     // [256] byte -> dense code
+  const uint8_t *bytes = nullptr;
+  int kbits = 0, cpk = 0, shift = 0;
+  uint32_t T = 0;
+  uint32_t finbit = 0;   // dictionary mode, N < 2^31: rank[] values carry this bit once their suffix is settled
 };
+constexpr uint32_t kNoRank = 0xFFFFFFFFu;
+// device-side view for rank lookups (sufsort.hip: rank_at)
+struct RankView {
+  const uint32_t *rank; const uint64_t *skeys; const uint32_t *tab; const uint8_t *lut; const uint8_t *bytes;
+  uint64_t N; int kbits, cpk, shift; uint32_t T, finbit;
+};
+RankView rank_view(const SuffixOrder &so);
+// out[k] = rank of the suffix starting at pos[k]
+void gather_ranks(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint64_t count, uint32_t *d_out);
 // Suffixes of the dictionary as 0x01-terminated strings (gsacak semantics):
 // endpos[i] = position of the terminator of the word containing i (the final 0x00 is its own word).
 void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out);

@@ -55,10 +55,9 @@ void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix) {
 // Lexicographic rank of every word.  A whole word is a singleton group in SA(D) (the parse is
 // prefix free), so rank[start of word] is its slot: sorting the d words by that slot gives the
 // order std::sort produces in the reference (newscan.cpp:622-636) without touching all N slots.
-__global__ void word_slot_kernel(uint32_t d, const uint64_t *__restrict__ woff, const uint32_t *__restrict__ rank,
-                                 uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+__global__ void iota_u32_kernel(uint32_t d, uint32_t *__restrict__ val) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < d) { key[j] = rank[woff[j]]; val[j] = j; }
+  if (j < d) val[j] = j;
 }
 __global__ void lexrank_from_order_kernel(uint32_t d, const uint32_t *__restrict__ word_sorted, uint32_t *__restrict__ lexrank) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,7 +68,8 @@ void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrder &so, DictIndex
   const uint32_t d = (uint32_t)D.d;
   ix.lexrank.alloc(c, d);
   DBuf<uint32_t> key(c, d), val(c, d), keyo(c, d), valo(c, d);
-  hipLaunchKernelGGL(word_slot_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, D.woff.p, so.rank.p, key.p, val.p);
+  gather_ranks(c, so, D.woff.p, d, key.p);
+  hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, val.p);
   sort_pairs_u32_u32(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
   hipLaunchKernelGGL(lexrank_from_order_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
   PFP_HIP(hipGetLastError());

@@ -18,6 +18,7 @@
 #include "prims.hpp"
 #include "devutil.hpp"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace pfp {
@@ -69,6 +70,49 @@ __global__ __launch_bounds__(256) void byte_presence_kernel(const uint8_t *__res
   if (threadIdx.x < 8 && m[threadIdx.x]) atomicOr(&present[threadIdx.x], m[threadIdx.x]);
 }
 
+// packed key of the suffix at i, code table in `lut` (LDS in the bulk kernel, global in lookups)
+__device__ __forceinline__ uint64_t packed_key_at(const uint8_t *__restrict__ s, uint64_t i, int bits, int cpk,
+                                                  const uint8_t *lut) {
+  uint4 a = ld16u(s + i), b = ld16u(s + i + 16);
+  const uint32_t w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint64_t k = 0;
+  bool live = true;
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    if (j < cpk) {
+      uint32_t c = (w8[j >> 2] >> (8 * (j & 3))) & 0xff;
+      uint32_t code = live ? lut[c] : 0u;
+      k = (k << bits) | code;
+      if (c <= kEndOfWord) live = false;
+    }
+  }
+  return k;
+}
+
+// Rank of the suffix at j.  rank[j] holds it when some round after the first refined j's group;
+// otherwise the first round settled j and its rank is the first slot holding j's packed key: the
+// bucket table narrows the range to the slots that share the key's top bits, a binary search
+// over the sorted keys finishes (a handful of sectors instead of one scattered write per suffix).
+//
+// `settled` (dictionary mode, finbit != 0): j's group will never be refined again - it is a
+// singleton or a set of identical strings.  An unresolved tie whose continuations are settled is
+// itself a set of identical strings (their sorted prefixes reach the terminator), which is how
+// write_back retires groups without gathering the suffix length of every member every round.
+__device__ __forceinline__ uint32_t rank_at(const RankView &L, uint64_t j, bool &settled) {
+  const uint32_t r = L.rank[j];
+  if (L.skeys == nullptr || r != kNoRank) { settled = (r & L.finbit) != 0; return r & ~L.finbit; }
+  settled = true;
+  const uint64_t k = packed_key_at(L.bytes, j, L.kbits, L.cpk, L.lut);
+  const uint32_t b = (uint32_t)(k >> L.shift);
+  uint32_t lo = 0xFFFFFFFFu - L.tab[L.T - 1 - b];
+  uint32_t hi = (b + 1 < L.T) ? 0xFFFFFFFFu - L.tab[L.T - 2 - b] : (uint32_t)L.N;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (L.skeys[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 __global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyPack kp,
                                                                uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
   __shared__ uint8_t lut[256];
@@ -76,20 +120,7 @@ __global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__
   __syncthreads();
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  uint4 a = ld16u(s + i), b = ld16u(s + i + 16);
-  const uint32_t w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  uint64_t k = 0;
-  bool live = true;
-#pragma unroll
-  for (int j = 0; j < 32; j++) {
-    if (j < kp.cpk) {
-      uint32_t c = (w8[j >> 2] >> (8 * (j & 3))) & 0xff;
-      uint32_t code = live ? lut[c] : 0u;
-      k = (k << kp.bits) | code;
-      if (c <= kEndOfWord) live = false;
-    }
-  }
-  key[i] = k; val[i] = (uint32_t)i;
+  key[i] = packed_key_at(s, i, kp.bits, kp.cpk, lut); val[i] = (uint32_t)i;
 }
 
 __global__ void init_keys_bytes_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
@@ -116,15 +147,16 @@ __global__ void iota32_kernel(uint32_t *p, uint64_t n) {
 // random access is rank[i+h].  In dictionary mode an unresolved suffix is always longer than the
 // sorted prefix h (otherwise write_back would have retired it), so i+h stays inside its word.
 __global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ act_i,
-                                  const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ rank,
+                                  const uint32_t *__restrict__ act_grp, RankView L, int nb,
                                   uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const uint32_t i = act_i[a];
   const uint64_t grp = act_grp[a];
-  const uint64_t nxt = (g.mode == MODE_DICT || (uint64_t)i + h < g.N) ? (uint64_t)rank[i + h] + 1 : 0;
-  key[a] = (grp << 32) | nxt;
-  val[a] = i;
+  bool settled = false;
+  const uint64_t nxt = (g.mode == MODE_DICT || (uint64_t)i + h < g.N) ? (uint64_t)rank_at(L, (uint64_t)i + h, settled) + 1 : 0;
+  key[a] = (grp << nb) | nxt;
+  val[a] = i | (settled ? L.finbit : 0u);
 }
 
 // Sparse rank materialisation (helpers).  Measured and NOT used inside the doubling loop: marking the
@@ -157,13 +189,13 @@ __global__ void group_starts_kernel(uint64_t m, const uint32_t *__restrict__ act
   if (a < m) gs[a] = (a == 0 || act_grp[a] != act_grp[a - 1]) ? 1 : 0;
 }
 __global__ void build_keys32_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ act_i,
-                                    const uint32_t *__restrict__ rank, uint32_t *__restrict__ key,
-                                    uint32_t *__restrict__ val) {
+                                    RankView L, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const uint32_t i = act_i[a];
-  key[a] = (g.mode == MODE_DICT || (uint64_t)i + h < g.N) ? rank[i + h] + 1u : 0u;
-  val[a] = i;
+  bool settled = false;
+  key[a] = (g.mode == MODE_DICT || (uint64_t)i + h < g.N) ? rank_at(L, (uint64_t)i + h, settled) + 1u : 0u;
+  val[a] = i | (settled ? L.finbit : 0u);
 }
 __global__ void seg_end_kernel(uint32_t ng, uint32_t m, const uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
                                uint32_t *__restrict__ maxlen) {
@@ -185,12 +217,12 @@ __global__ void heads32_kernel(uint64_t m, const uint8_t *__restrict__ gs, const
 // stream compaction of the active list: (slot, suffix, group) of every suffix that stays unresolved
 __global__ void compact3_kernel(uint64_t m, const uint8_t *__restrict__ keep, const uint32_t *__restrict__ inc,
                                 const uint32_t *__restrict__ aslot, const uint32_t *__restrict__ val,
-                                const uint32_t *__restrict__ newhead, uint32_t *__restrict__ aslot2,
+                                const uint32_t *__restrict__ newhead, uint32_t finbit, uint32_t *__restrict__ aslot2,
                                 uint32_t *__restrict__ act_i, uint32_t *__restrict__ act_grp) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m || !keep[a]) return;
   const uint32_t o = inc[a] - 1;
-  aslot2[o] = aslot[a]; act_i[o] = val[a]; act_grp[o] = newhead[a];
+  aslot2[o] = aslot[a]; act_i[o] = val[a] & ~finbit; act_grp[o] = newhead[a];
 }
 
 // number of unresolved groups after a round (their heads stay unresolved with them).  A fixed grid
@@ -216,29 +248,79 @@ __global__ void heads_kernel(uint64_t m, const uint64_t *__restrict__ key, const
   hv[a] = h ? aslot[a] : 0u;
 }
 
+// First round of dictionary mode (slot == index): group heads, and the bucket table of the sorted
+// keys for rank_at: the first slot of every occupied top-bits bucket marks its reversed entry.
+__global__ void heads0_kernel(uint64_t m, const uint64_t *__restrict__ key, int shift, uint32_t T,
+                              uint8_t *__restrict__ hd, uint32_t *__restrict__ hv, uint32_t *__restrict__ tab) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  const uint64_t k = key[a], kprev = a ? key[a - 1] : ~k;
+  const bool h = k != kprev;
+  hd[a] = h ? 1 : 0;
+  hv[a] = h ? (uint32_t)a : 0u;
+  if (a == 0 || (k >> shift) != (kprev >> shift)) tab[T - 1 - (uint32_t)(k >> shift)] = 0xFFFFFFFFu - (uint32_t)a;
+}
+__global__ void fill_u32_kernel(uint32_t *p, uint64_t n, uint32_t v) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+// First round of dictionary mode: sa and grp are the sorted values / scanned heads themselves
+// (streaming copies); rank[] is written only for the suffixes that stay unresolved.
+__global__ void write_back0_kernel(uint64_t m, const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead,
+                                   const uint8_t *__restrict__ hd, const uint64_t *__restrict__ key0, uint64_t ones,
+                                   uint64_t highs, uint32_t *__restrict__ sa, uint32_t *__restrict__ rank,
+                                   uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  const uint32_t i = val[a], head = newhead[a];
+  sa[a] = i;
+  grp[a] = head;
+  const bool single = hd[a] && (a + 1 == m || hd[a + 1]);
+  bool fin = false;
+  if (!single) { uint64_t v = key0[a] ^ ones; fin = ((v - ones) & ~v & highs) != 0; }
+  const bool k = !single && !fin;
+  if (k) rank[i] = head;
+  keep[a] = k ? 1 : 0;
+}
+
+// dense fallback after the first round: many suffixes stay unresolved, so most lookups would need
+// the search; scatter the settled ranks once instead (the pre-lazy behaviour)
+__global__ void scatter_settled_kernel(uint64_t N, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ grp,
+                                       const uint8_t *__restrict__ keep, uint32_t finbit, uint32_t *__restrict__ rank) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < N && !keep[t]) rank[sa[t]] = grp[t] | finbit;
+}
+
 // write the refined order back and decide which suffixes stay unresolved.
 // sorted_len = prefix length that is sorted after this round.
 // Round 0 (key0 != nullptr) decides "whole string inside the sorted prefix" from the packed key
 // itself (some field holds the terminator code 1): no gather.
 __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, const uint32_t *__restrict__ aslot,
                                   const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead,
-                                  const uint8_t *__restrict__ hd, const uint64_t *__restrict__ key0, uint64_t ones,
-                                  uint64_t highs, uint32_t *__restrict__ sa, uint32_t *__restrict__ rank,
-                                  uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
+                                  const uint8_t *__restrict__ hd, uint32_t finbit, uint32_t *__restrict__ sa,
+                                  uint32_t *__restrict__ rank, uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
-  uint32_t i = val[a];
+  const uint32_t iv = val[a], i = iv & ~finbit;
   const uint32_t slot = aslot[a];
   sa[slot] = i;
   grp[slot] = newhead[a];       // slot-side copy of the group head: the merge never gathers rank[]
-  rank[i] = newhead[a];
   bool single = hd[a] && (a + 1 == m || hd[a + 1]);
   bool fin = false;
   if (!single && g.mode == MODE_DICT) {
-    if (key0) { uint64_t v = key0[a] ^ ones; fin = ((v - ones) & ~v & highs) != 0; }
-    else fin = suf_len(g, i) <= sorted_len;
+    if (finbit) fin = (iv & finbit) != 0;              // the continuation is settled (see rank_at)
+    else fin = suf_len(g, i) <= sorted_len;            // N >= 2^31: no spare bit, gather the length
   }
-  keep[a] = (!single && !fin) ? 1 : 0;
+  const bool k = !single && !fin;
+  rank[i] = newhead[a] | (k ? 0u : finbit);
+  keep[a] = k ? 1 : 0;
+}
+
+// the first round leaves more than N/kLazyRatio suffixes unresolved -> scatter all ranks after all
+static const uint64_t kLazyRatio = []() { const char *e = getenv("PFP_LAZY_RATIO"); return e ? (uint64_t)atoll(e) : 8ull; }();
+
+RankView rank_view(const SuffixOrder &so) {
+  return RankView{so.rank.p, so.skeys.p, so.tab.p, so.lut.p, so.bytes, so.N, so.kbits, so.cpk, so.shift, so.T, so.finbit};
 }
 
 static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> &val, uint64_t h0, SuffixOrder &out,
@@ -256,13 +338,31 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   uint64_t m = N, h = h0;
   out.rounds = 0;
   bool first = true;
-  const int keybits = 32 + bits_for(N);
+  const bool lazy = ones != 0;      // dictionary mode: out.lut/bytes/kbits/cpk are set by the caller
+  if (lazy) {
+    const int tb = std::min(key0_bits, std::max(8, std::min(24, bits_for(N) - 5)));
+    out.shift = key0_bits - tb;
+    out.T = 1u << tb;
+    out.tab.alloc(c, out.T);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(cdiv(out.T, TB)), dim3(TB), 0, c->stream, out.tab.p, (uint64_t)out.T,
+                       0xFFFFFFFFu - (uint32_t)N);
+    PFP_HIP(hipMemsetAsync(out.rank.p, 0xff, N * 4, c->stream));
+  }
+  const int nb = bits_for(N);           // key of a later round = (group head << nb) | (1 + rank of the continuation)
+  const int keybits = 2 * nb;
+  static const bool no_finflag = getenv("PFP_NO_FINFLAG") != nullptr;      // tests: force the length-gather path
+  out.finbit = (g.mode == MODE_DICT && N < (1ull << 31) && !no_finflag) ? 0x80000000u : 0u;
   static const bool use_segsort = []() { const char *e = getenv("PFP_SEGSORT"); return !(e && e[0] == '0'); }();
   DBuf<uint8_t> gs;
   DBuf<uint32_t> k32, k32o, segb, sege, nseg_d, ngrp_d(c, 1);
   bool seg_round = false;       // the keys of this round live in k32o (segmented path) instead of keyo
   for (;;) {
-    if (seg_round) {
+    if (first && lazy) {
+      { KScope ks(c, "pfp::heads_kernel", m * 13);
+        hipLaunchKernelGGL(heads0_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, out.shift, out.T, hd.p, hv.p,
+                           out.tab.p); }
+      inclusive_max_u32(c, out.tab.p, out.tab.p, out.T);
+    } else if (seg_round) {
       KScope ks(c, "pfp::heads_kernel", m * 14);
       hipLaunchKernelGGL(heads32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, gs.p, k32o.p, aslot.p, hd.p, hv.p);
     } else {
@@ -270,17 +370,24 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       hipLaunchKernelGGL(heads_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p);
     }
     inclusive_max_u32(c, hv.p, newhead.p, m);
-    const bool round0 = first && ones != 0;
+    const bool round0 = first && lazy;
     first = false;
-    { KScope ks(c, "pfp::write_back_kernel", m * (13 + (round0 ? 8 : 4) + 13));
-    hipLaunchKernelGGL(write_back_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p,
-                       newhead.p, hd.p, round0 ? keyo.p : (const uint64_t *)nullptr, ones, highs, out.sa.p,
-                       out.rank.p, out.grp.p, keep.p); }
+    if (round0) {
+      { KScope ks(c, "pfp::write_back_kernel", m * (4 + 4 + 1 + 8 + 4 + 4 + 1));
+        hipLaunchKernelGGL(write_back0_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, valo.p, newhead.p, hd.p, keyo.p,
+                           ones, highs, out.sa.p, out.rank.p, out.grp.p, keep.p); }
+      // the sorted keys stay with the result; later rounds sort the (smaller) active set elsewhere
+      out.skeys = std::move(keyo);
+    } else {
+      KScope ks(c, "pfp::write_back_kernel", m * (13 + 4 + 13));
+      hipLaunchKernelGGL(write_back_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p,
+                         newhead.p, hd.p, out.finbit, out.sa.p, out.rank.p, out.grp.p, keep.p);
+    }
     inclusive_count_eq_u8(c, keep.p, 1, inc.p, m);
     PFP_HIP(hipMemsetAsync(ngrp_d.p, 0, 4, c->stream));
     { KScope ks(c, "pfp::compact3_kernel", m * 17);
       hipLaunchKernelGGL(compact3_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keep.p, inc.p, aslot.p,
-                         valo.p, newhead.p, aslot2.p, act_i.p, act_grp.p); }
+                         valo.p, newhead.p, out.finbit, aslot2.p, act_i.p, act_grp.p); }
     if (use_segsort)
       hipLaunchKernelGGL(count_groups_kernel, dim3((int)std::min<uint64_t>(cdiv64(m, 256), 2048)), dim3(256), 0, c->stream, m,
                          keep.p, hd.p, ngrp_d.p);
@@ -290,10 +397,23 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     sync(c);
     uint32_t m2, ngrp;
     memcpy(&m2, c->h_scalars, 4); memcpy(&ngrp, c->h_scalars + 1, 4);
+    if (round0 && m2 && (uint64_t)m2 * kLazyRatio > N) {
+      KScope ks(c, "pfp::write_back_kernel", N * (4 + 4 + 1 + 4));
+      hipLaunchKernelGGL(scatter_settled_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, out.sa.p, out.grp.p, keep.p,
+                         out.finbit, out.rank.p);
+      keyo = std::move(out.skeys);       // no lookups: the buffer serves the later sorts again
+      out.tab.release();
+    }
+    static const bool trace_rounds = getenv("PFP_TRACE_ROUNDS") != nullptr;
+    if (trace_rounds)
+      fprintf(stderr, "[pfp] doubling N=%llu round=%llu h=%llu m=%llu -> %u unresolved in %u groups%s\n", (unsigned long long)N,
+              (unsigned long long)out.rounds, (unsigned long long)h, (unsigned long long)m, m2, ngrp, seg_round ? " (seg)" : "");
     std::swap(aslot.p, aslot2.p);
     m = m2;
     if (m == 0) break;
     PFP_REQUIRE(h < 2 * N, PFP_EHIP, "suffix sort failed to converge");
+    if (!keyo.p) keyo.alloc(c, m);
+    const RankView L = rank_view(out);
     // Rounds after the first: the unresolved suffixes are already grouped, only the 32-bit "next"
     // key has to be ordered inside every group.  When the groups are many and of moderate size (a
     // dictionary of near-identical variants) a segmented sort moves 16 B per suffix instead of the
@@ -312,7 +432,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       const uint32_t maxlen = read_scalar(c, nseg_d.p + 1);
       if (maxlen <= (1u << 15) && m / ng >= 24) {
         { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
-          hipLaunchKernelGGL(build_keys32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, out.rank.p,
+          hipLaunchKernelGGL(build_keys32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, L,
                              k32.p, val.p); }
         segsort_pairs_u32_u32(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, bits_for(N));
         seg_round = true;
@@ -321,7 +441,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     if (!seg_round) {
       { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 4 + 12));
       hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p,
-                         out.rank.p, key.p, val.p); }
+                         L, nb, key.p, val.p); }
       sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, keybits);
     }
     h *= 2;
@@ -344,6 +464,17 @@ void materialize_all_ranks(pfp_ctx *c, SuffixOrder &so) {
   PFP_HIP(hipMemsetAsync(bits.p, 0xff, (so.N / 32 + 2) * 4, c->stream));
   hipLaunchKernelGGL(provide_ranks_kernel, dim3(cdiv(so.N, 256)), dim3(256), 0, c->stream, so.N, so.sa.p, so.grp.p, bits.p,
                      so.rank.p);
+  PFP_HIP(hipGetLastError());
+}
+
+__global__ void gather_ranks_kernel(RankView L, uint64_t count, const uint64_t *__restrict__ pos, uint32_t *__restrict__ out) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool settled;
+  if (a < count) out[a] = rank_at(L, pos[a], settled);
+}
+void gather_ranks(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint64_t count, uint32_t *d_out) {
+  if (!count) return;
+  hipLaunchKernelGGL(gather_ranks_kernel, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, rank_view(so), count, d_pos, d_out);
   PFP_HIP(hipGetLastError());
 }
 
@@ -373,6 +504,10 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   DBuf<uint32_t> val(c, N);
   { KScope ks(c, "pfp::init_keys_packed_kernel", N * 13);
     hipLaunchKernelGGL(init_keys_packed_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kp, key.p, val.p); }
+  out.lut.alloc(c, 256);
+  PFP_HIP(hipMemcpyAsync(out.lut.p, kp.lut, 256, hipMemcpyHostToDevice, c->stream));
+  sync(c);      // kp.lut is a stack array
+  out.bytes = bytes; out.kbits = kp.bits; out.cpk = kp.cpk;
   doubling(c, g, key, val, (uint64_t)kp.cpk, out, kp.bits * kp.cpk, kp.ones, kp.highs);
 }
 

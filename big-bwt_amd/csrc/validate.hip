@@ -72,12 +72,24 @@ static int cmp_suffix(const std::vector<uint8_t> &b, uint32_t x, uint32_t y) {
 void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, SuffixOrder &so, bool dict_mode, const char *what) {
   const uint64_t N = so.N;
   auto sa = fetch(c, so.sa.p, N);
-  auto rk = fetch(c, so.rank.p, N);
+  // ranks through the sorter's own lookup (rank[] is sparse in dictionary mode), checked against grp[]
+  std::vector<uint32_t> rk(N);
+  {
+    std::vector<uint64_t> pos(N);
+    for (uint64_t i = 0; i < N; i++) pos[i] = i;
+    DBuf<uint64_t> dpos(c, N);
+    DBuf<uint32_t> dr(c, N);
+    h2d(c, dpos.p, pos.data(), N);
+    gather_ranks(c, so, dpos.p, N, dr.p);
+    rk = fetch(c, dr.p, N);
+  }
+  auto gr = fetch(c, so.grp.p, N);
   std::vector<uint8_t> seen(N, 0);
   for (uint64_t t = 0; t < N; t++) {
     if (sa[t] >= N || seen[sa[t]]) VFAIL(std::string(what) + ": sa is not a permutation at slot " + std::to_string(t));
     seen[sa[t]] = 1;
     if (rk[sa[t]] > t) VFAIL(std::string(what) + ": rank above slot");
+    if (rk[sa[t]] != gr[t]) VFAIL(std::string(what) + ": rank lookup differs from the slot's group head at slot " + std::to_string(t));
   }
   if (dict_mode && N < (64u << 20)) {
     auto b = fetch(c, bytes, N);
