@@ -327,103 +327,142 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgs a, const ui
   }
 }
 
-// Hard groups.  One wave scans 64 consecutive slots for hard group heads and processes each such
-// group cooperatively.  Every occurrence (member, j) must land at the rank of its BWT(P) position
-// among all occurrences of the group - the reference pops a heap (pfbwt.cpp:537-556):
-//   * groups of up to kHardLds occurrences: positions staged in LDS, each lane counts the smaller
-//     ones with broadcast LDS reads (all-pairs, no dependent global loads);
-//   * larger groups (few members with long inverted lists): own index + lower_bound in every other
-//     member's inverted list.
-constexpr int kHardLds = 1024;   // occurrences of a group ranked in LDS
-constexpr int kHardMem = 256;    // members of such a group
+// Hard groups.  hard[] is 1 exactly at the head slot of every hard group; the heads are compacted
+// into a list and every wave takes 64 of them at a time, one per lane.  A single group is a chain
+// of dependent loads (members, offsets, inverted-list starts, positions), so the work of a batch
+// is laid out flat and every phase runs with all lanes busy on independent loads:
+//   A  lane = group      : member count, output base, number of occurrences E
+//   B  lane = member     : offset of its occurrences, inverted-list start, char, suffix length
+//   C  lane = occurrence : its BWT(P) position from the inverted list  -> LDS
+//   D  lane = occurrence : rank among the E positions of its own group -> output slot
+// Every occurrence (member, j) must land at the rank of its BWT(P) position among all occurrences
+// of the group - the reference pops a heap (pfbwt.cpp:537-556).  Ranking is all-pairs over the
+// group's LDS segment, or, when the group is a few long sorted lists, own index + lower_bound in
+// each other member's segment.  Groups that do not fit the LDS tables are queued for
+// hard_big_kernel.  (One group at a time per wave took 7.7 us per group, 22 ms at 8.8 M groups.)
+constexpr int kHardLds = 1024;   // occurrences of one batch ranked in LDS
+constexpr int kHardMem = 256;    // members of one batch
 struct BigGroup { uint64_t g; uint64_t E; uint32_t k; uint32_t pad; };
-__global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, unsigned long long *__restrict__ stats,
+struct HardLds {
+  uint32_t lpos[kHardLds];
+  uint8_t lq[kHardLds];
+  uint32_t lmoff[kHardMem + 1], lmist[kHardMem], lmsl[kHardMem];
+  uint8_t lmch[kHardMem], lmg[kHardMem];
+  uint64_t gbase[64];
+  uint32_t ghead[64], geoff[65], gk0[65];
+};
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+}
+__global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, const uint32_t *__restrict__ heads,
+                                                          const uint32_t *__restrict__ nheads_p,
+                                                          unsigned long long *__restrict__ stats,
                                                           BigGroup *__restrict__ big, uint32_t big_cap) {
-  __shared__ uint32_t lpos[4][kHardLds];
-  __shared__ uint32_t lsl[4][kHardLds];
-  __shared__ uint8_t lch[4][kHardLds];
-  __shared__ uint32_t lmoff[4][kHardMem + 1], lmist[4][kHardMem], lmsl[4][kHardMem];
-  __shared__ uint8_t lmch[4][kHardMem];
+  __shared__ HardLds S[4];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  HardLds &L = S[wv];
+  const uint32_t nH = *nheads_p;
+  const uint32_t nbatch = (nH + 63) / 64;
   unsigned long long my_chars = 0, my_groups = 0;
-  for (uint64_t tbase = ((uint64_t)blockIdx.x * 4 + wv) * 64; tbase < a.N; tbase += (uint64_t)gridDim.x * 256) {
-  const uint64_t tme = tbase + lane;
-  const bool head = tme < a.N && a.hard[tme] && a.grp[tme] == (uint32_t)tme;
-  unsigned long long heads = __ballot(head);
-  while (heads) {
-    const int hl = __ffsll((long long)heads) - 1;
-    heads &= heads - 1;
-    const uint64_t g = tbase + hl;
-    // members: consecutive slots with this group id
-    uint32_t k = 0;
-    for (;;) {
-      const uint64_t t = g + k + lane;
-      const bool in = t < a.N && a.grp[t] == (uint32_t)g && a.pc[t] != 0;
-      const unsigned long long mm = __ballot(in);
-      if (mm == ~0ULL) { k += 64; continue; }
-      k += __ffsll((long long)~mm) - 1;
-      break;
+  for (uint32_t b = blockIdx.x * 4 + wv; b < nbatch; b += gridDim.x * 4) {
+    // ---- A: one group per lane
+    const uint32_t hidx = b * 64 + lane;
+    uint64_t g = 0, base = 0;
+    uint32_t k = 0, E = 0;
+    bool live = false;
+    if (hidx < nH) {
+      g = heads[hidx];
+      uint32_t kk = 0;
+      while (g + kk < a.N && a.grp[g + kk] == (uint32_t)g && a.pc[g + kk] != 0) kk++;
+      base = a.off[g];
+      const uint64_t Eg = a.off[g + kk] - base;
+      if (kk && !(base + Eg <= a.out_lo || base >= a.out_hi)) {      // inside this rank's slice
+        my_chars += Eg; my_groups += 1;
+        if (Eg <= (uint64_t)kHardLds && kk <= (uint32_t)kHardMem) { live = true; k = kk; E = (uint32_t)Eg; }
+        else {       // too large for the LDS tables: hard_big_kernel (whole grid, one thread per occurrence)
+          const unsigned long long idx = atomicAdd(&stats[2], 1ull);
+          if (idx < big_cap) big[idx] = BigGroup{g, Eg, kk, 0};
+        }
+      }
     }
-    const uint64_t base = a.off[g];
-    const uint64_t E = a.off[g + k] - base;
-    if (base + E <= a.out_lo || base >= a.out_hi) continue;     // group lies outside this rank's slice
-    if (lane == 0) { my_chars += E; my_groups += 1; }
-    if (E <= (uint64_t)kHardLds && k <= (uint32_t)kHardMem) {
-      // stage 1: member table (k <= E <= kHardLds): offset, inverted-list start, char, suffix length
-      for (uint32_t m = lane; m < k; m += 64) {
-        const uint64_t t = g + m;
-        lmoff[wv][m] = (uint32_t)(a.off[t] - base);
-        lmist[wv][m] = slot_ist(a, t);
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+      // the longest prefix of the remaining groups whose members and occurrences fit the tables
+      const bool mine = (todo >> lane) & 1ull;
+      uint32_t pk = mine ? k : 0u, pE = mine ? E : 0u;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t vk = __shfl_up(pk, o, 64), vE = __shfl_up(pE, o, 64);
+        if (lane >= o) { pk += vk; pE += vE; }
+      }
+      const bool fit = mine && pk <= (uint32_t)kHardMem && pE <= (uint32_t)kHardLds;
+      const unsigned long long take = __ballot(fit);       // never empty: a single live group fits
+      todo &= ~take;
+      const int nG = __popcll(take);
+      const int lastl = 63 - __clzll((long long)take);
+      const uint32_t M = __shfl(pk, lastl, 64), Eb = __shfl(pE, lastl, 64);
+      if (fit) {
+        const int gi = __popcll(take & ((1ull << lane) - 1ull));
+        L.ghead[gi] = (uint32_t)g; L.gbase[gi] = base; L.geoff[gi] = pE - E; L.gk0[gi] = pk - k;
+      }
+      if (lane == 0) { L.geoff[nG] = Eb; L.gk0[nG] = M; }
+      wave_lds_sync();
+      // ---- B: one member per lane
+      for (uint32_t q = lane; q < M; q += 64) {
+        int lo = 0, hi = nG;                       // gk0[lo] <= q < gk0[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.gk0[mid] <= q) lo = mid; else hi = mid; }
+        const uint64_t t = (uint64_t)L.ghead[lo] + (q - L.gk0[lo]);
+        L.lmoff[q] = L.geoff[lo] + (uint32_t)(a.off[t] - L.gbase[lo]);
+        L.lmist[q] = slot_ist(a, t);
         uint32_t sl = 0;
         if (a.want_sa) { const uint32_t i = a.sa[t]; sl = a.endpos[i] - i; }
-        lmsl[wv][m] = sl;
-        lmch[wv][m] = fix_char(a.pc[t]);
+        L.lmsl[q] = sl;
+        L.lmch[q] = fix_char(a.pc[t]);
+        L.lmg[q] = (uint8_t)lo;
       }
-      if (lane == 0) lmoff[wv][k] = (uint32_t)E;
-      __builtin_amdgcn_wave_barrier();
-      __threadfence_block();
-      // stage 2: one lane per occurrence - all 64 lanes issue independent ilist gathers
-      for (uint32_t e = lane; e < (uint32_t)E; e += 64) {
-        uint32_t lo = 0, hi = k;                 // lmoff[lo] <= e < lmoff[hi]
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lmoff[wv][mid] <= e) lo = mid; else hi = mid; }
-        lpos[wv][e] = a.ilist[lmist[wv][lo] + (e - lmoff[wv][lo])];
-        lch[wv][e] = lmch[wv][lo];
-        lsl[wv][e] = lmsl[wv][lo];
+      if (lane == 0) L.lmoff[M] = Eb;
+      wave_lds_sync();
+      // ---- C: one occurrence per lane, independent inverted-list gathers
+      for (uint32_t e = lane; e < Eb; e += 64) {
+        uint32_t lo = 0, hi = M;                   // lmoff[lo] <= e < lmoff[hi]
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.lmoff[mid] <= e) lo = mid; else hi = mid; }
+        L.lpos[e] = a.ilist[L.lmist[lo] + (e - L.lmoff[lo])];
+        L.lq[e] = (uint8_t)lo;
       }
-      __builtin_amdgcn_wave_barrier();
-      __threadfence_block();
-      // rank of every occurrence among all E: either count the smaller ones directly (E broadcast LDS
-      // reads) or, when the group is a few long sorted lists (k members, E/k each), own index +
-      // lower_bound in each other member's LDS segment (k * log2(E/k) dependent reads)
-      uint32_t lg = 1;
-      while ((k << lg) < (uint32_t)E) lg++;
-      const bool by_search = (uint64_t)k * (lg + 1) * 3 < E;
-      for (uint32_t e = lane; e < (uint32_t)E; e += 64) {
-        const uint32_t pos = lpos[wv][e];
+      wave_lds_sync();
+      // ---- D: rank inside the own group's segment
+      for (uint32_t e = lane; e < Eb; e += 64) {
+        const uint32_t q = L.lq[e], gi = L.lmg[q];
+        const uint32_t s0 = L.geoff[gi], s1 = L.geoff[gi + 1], k0 = L.gk0[gi], k1 = L.gk0[gi + 1];
+        const uint32_t Eg = s1 - s0, kg = k1 - k0;
+        const uint32_t pos = L.lpos[e];
+        uint32_t lg = 1;
+        while ((kg << lg) < Eg) lg++;
+        const bool by_search = a.dbg_mode ? a.dbg_mode == 2 : (uint64_t)kg * (lg + 1) * 3 < Eg;
         uint32_t r = 0;
         if (!by_search) {
-          for (uint32_t q = 0; q < (uint32_t)E; q++) r += lpos[wv][q] < pos;
+          for (uint32_t x = s0; x < s1; x++) r += L.lpos[x] < pos;
         } else {
-          for (uint32_t m2 = 0; m2 < k; m2++) {
-            uint32_t l2 = lmoff[wv][m2], h2 = lmoff[wv][m2 + 1];       // # entries < pos in member m2's segment
-            const uint32_t s0 = l2;
-            while (l2 < h2) { uint32_t mid = (l2 + h2) >> 1; if (lpos[wv][mid] < pos) l2 = mid + 1; else h2 = mid; }
-            r += l2 - s0;
+          for (uint32_t m2 = k0; m2 < k1; m2++) {
+            uint32_t l2 = L.lmoff[m2], h2 = L.lmoff[m2 + 1];       // # entries < pos in member m2's segment
+            const uint32_t b2 = l2;
+            while (l2 < h2) { const uint32_t mid = (l2 + h2) >> 1; if (L.lpos[mid] < pos) l2 = mid + 1; else h2 = mid; }
+            r += l2 - b2;
           }
         }
-        if (base + r >= a.out_lo && base + r < a.out_hi) {
-          a.bwt[base + r] = lch[wv][e];
-          if (a.want_sa) a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)lsl[wv][e];
+        const uint64_t o = L.gbase[gi] + r;
+        if (o >= a.out_lo && o < a.out_hi) {
+          a.bwt[o] = L.lmch[q];
+          if (a.want_sa) a.out_sa[o] = a.bwsai[pos] - (uint64_t)L.lmsl[q];
         }
       }
-      __builtin_amdgcn_wave_barrier();
-    } else if (lane == 0) {     // too large for LDS: queued for hard_big_kernel (whole-grid, one thread per occurrence)
-      const unsigned long long idx = atomicAdd(&stats[2], 1ull);
-      if (idx < big_cap) big[idx] = BigGroup{g, E, k, 0};
+      wave_lds_sync();
     }
   }
-  }
-  // statistics (pfbwt.cpp:231-233 "Hard bwt chars"): lane 0 of every wave holds its totals
+  // statistics (pfbwt.cpp:231-233 "Hard bwt chars")
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { my_chars += __shfl_down(my_chars, o, 64); my_groups += __shfl_down(my_groups, o, 64); }
   if (lane == 0 && (my_chars | my_groups)) { atomicAdd(&stats[0], my_chars); atomicAdd(&stats[1], my_groups); }
 }
 
@@ -518,10 +557,13 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     KScope ks2(c, "pfp::expand_heavy_kernel", 0);   // bytes are accounted in expand_kernel's n_out term
     if (nh) hipLaunchKernelGGL(expand_heavy_kernel, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, heavy.p, nh);
   }
+  // hard[] marks exactly the heads of the hard groups (group_flags_kernel): compact them once
+  DBuf<uint32_t> heads(c, N / 2 + 2), nheads(c, 1);
+  select_index_u32(c, hard.p, heads.p, nheads.p, N);
   for (;;) {
     { KScope ks(c, "pfp::hard_groups_kernel", N * 5);
-      hipLaunchKernelGGL(hard_groups_kernel, dim3((int)std::min<uint64_t>(cdiv64(N, 256), (uint64_t)c->n_cu * 8)), dim3(256), 0,
-                         c->stream, a, hstats.p, big.p, big_cap); }
+      hipLaunchKernelGGL(hard_groups_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, a, heads.p, nheads.p, hstats.p, big.p,
+                         big_cap); }
     PFP_HIP(hipGetLastError());
     PFP_HIP(hipMemcpyAsync(c->h_scalars, hstats.p, 40, hipMemcpyDeviceToHost, c->stream));
     sync(c);
