@@ -291,14 +291,78 @@ __global__ void scatter_settled_kernel(uint64_t N, const uint32_t *__restrict__ 
   if (t < N && !keep[t]) rank[sa[t]] = grp[t] | finbit;
 }
 
+// Pivot rounds.  The unresolved groups of a dictionary of near-identical phrases (a collection of
+// variants) are families: most members are identical to each other up to the terminator or differ
+// from each other at one position a few dozen bytes on.  Doubling needs log2(lcp) more rounds for
+// them - each a device-wide sort plus a scattered rank update.  A pivot round instead compares
+// every member directly with its group's first member P (= sa[head slot]), from the offset already
+// known equal, 16 bytes per step, for at most `cap` bytes, and sorts by what it found:
+//     smaller than P : (first difference at lcp, own byte there)   ascending lcp, then byte
+//     identical to P up to the terminator
+//     greater than P : descending lcp, then ascending byte
+// Two members that differ from P at different offsets are thereby ordered against each other, two
+// that differ at the same offset by their bytes; the same (side, lcp, byte) is a still unresolved
+// tie.  A member still equal to P after cap bytes joins P's class unresolved (no settled bit) and
+// vetoes the settling of that whole class (pivot_veto_kernel).  Order-key layout (kPivBits bits):
+constexpr int kPivBits = 23;
+constexpr uint32_t kPivEq = 1u << 21;
+constexpr uint32_t kPivCapMax = 8192;
+__global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t m, uint64_t from, uint32_t cap,
+                                        const uint32_t *__restrict__ act_i, const uint32_t *__restrict__ act_grp,
+                                        const uint32_t *__restrict__ sa, uint32_t finbit, uint64_t *__restrict__ key,
+                                        uint32_t *__restrict__ val) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  const uint32_t i = act_i[a], grp = act_grp[a];
+  const uint32_t piv = sa[grp];
+  uint32_t ok = kPivEq;
+  uint32_t settled = finbit;
+  if (i != piv) {
+    settled = 0;
+    const uint8_t *pa = s + i + from, *pp = s + piv + from;
+    bool done = false;
+    for (uint32_t off = 0; off < cap && !done; off += 16) {
+      const uint4 xa = ld16u(pa + off), xp = ld16u(pp + off);
+      const uint64_t x[2] = {(uint64_t)xa.x | ((uint64_t)xa.y << 32), (uint64_t)xa.z | ((uint64_t)xa.w << 32)};
+      const uint64_t y[2] = {(uint64_t)xp.x | ((uint64_t)xp.y << 32), (uint64_t)xp.z | ((uint64_t)xp.w << 32)};
+#pragma unroll
+      for (int q = 0; q < 2 && !done; q++) {
+        const uint64_t tb = (x[q] - 0x0202020202020202ull) & ~x[q] & 0x8080808080808080ull;   // bytes < 2; lowest flag exact
+        if (x[q] == y[q]) { if (tb) { settled = finbit; done = true; } continue; }
+        const int fd = __builtin_ctzll(x[q] ^ y[q]) >> 3;
+        const int ft = tb ? (__builtin_ctzll(tb) >> 3) : 8;
+        if (ft < fd) { settled = finbit; done = true; continue; }        // both end before they differ: identical
+        const uint32_t bx = (uint32_t)(x[q] >> (8 * fd)) & 0xffu, by = (uint32_t)(y[q] >> (8 * fd)) & 0xffu;
+        const uint32_t lcp = off + 8 * q + fd;
+        ok = bx < by ? ((lcp << 8) | bx) : ((2u << 21) | ((kPivCapMax - 1 - lcp) << 8) | bx);
+        if (bx <= kEndOfWord) settled = finbit;      // the member ends here: whoever shares this key is the same string
+        done = true;
+      }
+    }
+    // not done: still equal to P after cap bytes -> P's class, without the settled bit
+  }
+  key[a] = ((uint64_t)grp << kPivBits) | ok;
+  val[a] = i | settled;
+}
+// a member of P's class without the settled bit (equal to P for cap bytes, unknown beyond): nobody in
+// that class may settle this round
+__global__ void pivot_veto_kernel(uint64_t m, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val,
+                                  const uint32_t *__restrict__ newhead, uint32_t finbit, uint8_t *__restrict__ veto) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  if (((uint32_t)key[a] & ((1u << kPivBits) - 1)) == kPivEq && !(val[a] & finbit)) veto[newhead[a]] = 1;
+}
+
 // write the refined order back and decide which suffixes stay unresolved.
 // sorted_len = prefix length that is sorted after this round.
 // Round 0 (key0 != nullptr) decides "whole string inside the sorted prefix" from the packed key
 // itself (some field holds the terminator code 1): no gather.
 __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, const uint32_t *__restrict__ aslot,
                                   const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead,
-                                  const uint8_t *__restrict__ hd, uint32_t finbit, uint32_t *__restrict__ sa,
-                                  uint32_t *__restrict__ rank, uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
+                                  const uint8_t *__restrict__ hd, uint32_t finbit, const uint64_t *__restrict__ prevkey,
+                                  int prevshift, const uint32_t *__restrict__ prevgrp, const uint8_t *__restrict__ veto,
+                                  uint32_t *__restrict__ sa, uint32_t *__restrict__ rank, uint32_t *__restrict__ grp,
+                                  uint8_t *__restrict__ keep) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const uint32_t iv = val[a], i = iv & ~finbit;
@@ -308,13 +372,21 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
   bool single = hd[a] && (a + 1 == m || hd[a + 1]);
   bool fin = false;
   if (!single && g.mode == MODE_DICT) {
-    if (finbit) fin = (iv & finbit) != 0;              // the continuation is settled (see rank_at)
+    if (finbit) fin = (iv & finbit) != 0 && !(veto && veto[newhead[a]]);   // continuation settled / identical to the pivot
     else fin = suf_len(g, i) <= sorted_len;            // N >= 2^31: no spare bit, gather the length
   }
   const bool k = !single && !fin;
-  rank[i] = newhead[a] | (k ? 0u : finbit);
+  // rank[i] already holds the old group head: a suffix that stays unresolved in a group that kept
+  // its head needs no write - the scattered 4-byte store is the expensive access of this kernel
+  const uint32_t old = prevkey ? (uint32_t)(prevkey[a] >> prevshift) : (prevgrp ? prevgrp[a] : ~newhead[a]);
+  if (!k || old != newhead[a]) rank[i] = newhead[a] | (k ? 0u : finbit);
   keep[a] = k ? 1 : 0;
 }
+
+// after the first round, pivot rounds are tried while the groups are families (average size up to
+// kPivotAvg) and each one at least halves the unresolved set; at most kPivotCap bytes per comparison
+static const uint32_t kPivotAvg = []() { const char *e = getenv("PFP_PIVOT_AVG"); return e ? (uint32_t)atoll(e) : 1024u; }();
+static const uint32_t kPivotCap = []() { const char *e = getenv("PFP_PIVOT_CAP"); uint32_t v = e ? (uint32_t)atoll(e) : 512u; return v > kPivCapMax ? kPivCapMax : v; }();
 
 // the first round leaves more than N/kLazyRatio suffixes unresolved -> scatter all ranks after all
 static const uint64_t kLazyRatio = []() { const char *e = getenv("PFP_LAZY_RATIO"); return e ? (uint64_t)atoll(e) : 8ull; }();
@@ -356,6 +428,12 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   DBuf<uint8_t> gs;
   DBuf<uint32_t> k32, k32o, segb, sege, nseg_d, ngrp_d(c, 1);
   bool seg_round = false;       // the keys of this round live in k32o (segmented path) instead of keyo
+  bool pivot_round = false;     // the keys of this round are pivot order keys (build_keys_pivot_kernel)
+  bool pivot_ok = true;
+  bool lazy_pending = false;    // dictionary mode: rank[] of the suffixes settled by the first round not scattered (yet)
+  DBuf<uint8_t> veto, keep0;
+  uint32_t piv_cap = kPivotCap;  // bytes compared per member in the next pivot round
+  bool long_cap_tried = false;
   for (;;) {
     if (first && lazy) {
       { KScope ks(c, "pfp::heads_kernel", m * 13);
@@ -379,41 +457,61 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       // the sorted keys stay with the result; later rounds sort the (smaller) active set elsewhere
       out.skeys = std::move(keyo);
     } else {
+      if (pivot_round) {
+        if (!veto.p) veto.alloc(c, N);
+        veto.zero();
+        hipLaunchKernelGGL(pivot_veto_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, valo.p, newhead.p, out.finbit,
+                           veto.p);
+      }
+      // previous group head of the element now at a: the high part of its sort key, or (segmented
+      // rounds keep every element inside its segment) the group of list position a.  The first round
+      // of plain mode has neither: everything is written.
+      const bool have_prev = out.rounds > 0;
       KScope ks(c, "pfp::write_back_kernel", m * (13 + 4 + 13));
       hipLaunchKernelGGL(write_back_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p,
-                         newhead.p, hd.p, out.finbit, out.sa.p, out.rank.p, out.grp.p, keep.p);
+                         newhead.p, hd.p, out.finbit, (have_prev && !seg_round) ? keyo.p : (const uint64_t *)nullptr,
+                         pivot_round ? kPivBits : nb, (have_prev && seg_round) ? act_grp.p : (const uint32_t *)nullptr,
+                         pivot_round ? veto.p : (const uint8_t *)nullptr, out.sa.p, out.rank.p, out.grp.p, keep.p);
     }
     inclusive_count_eq_u8(c, keep.p, 1, inc.p, m);
     PFP_HIP(hipMemsetAsync(ngrp_d.p, 0, 4, c->stream));
     { KScope ks(c, "pfp::compact3_kernel", m * 17);
       hipLaunchKernelGGL(compact3_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keep.p, inc.p, aslot.p,
                          valo.p, newhead.p, out.finbit, aslot2.p, act_i.p, act_grp.p); }
-    if (use_segsort)
-      hipLaunchKernelGGL(count_groups_kernel, dim3((int)std::min<uint64_t>(cdiv64(m, 256), 2048)), dim3(256), 0, c->stream, m,
-                         keep.p, hd.p, ngrp_d.p);
+    hipLaunchKernelGGL(count_groups_kernel, dim3((int)std::min<uint64_t>(cdiv64(m, 256), 2048)), dim3(256), 0, c->stream, m,
+                       keep.p, hd.p, ngrp_d.p);
     PFP_HIP(hipGetLastError());
     PFP_HIP(hipMemcpyAsync(c->h_scalars, inc.p + (m - 1), 4, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, ngrp_d.p, 4, hipMemcpyDeviceToHost, c->stream));
     sync(c);
     uint32_t m2, ngrp;
     memcpy(&m2, c->h_scalars, 4); memcpy(&ngrp, c->h_scalars + 1, 4);
-    if (round0 && m2 && (uint64_t)m2 * kLazyRatio > N) {
-      KScope ks(c, "pfp::write_back_kernel", N * (4 + 4 + 1 + 4));
-      hipLaunchKernelGGL(scatter_settled_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, out.sa.p, out.grp.p, keep.p,
-                         out.finbit, out.rank.p);
-      keyo = std::move(out.skeys);       // no lookups: the buffer serves the later sorts again
-      out.tab.release();
+    if (round0 && m2) {
+      // whether the settled ranks get scattered after all is decided when (if) a doubling round
+      // first needs them: pivot rounds read the strings, not rank[]
+      lazy_pending = true;
+      keep0.alloc(c, N);
+      PFP_HIP(hipMemcpyAsync(keep0.p, keep.p, N, hipMemcpyDeviceToDevice, c->stream));
     }
+
     static const bool trace_rounds = getenv("PFP_TRACE_ROUNDS") != nullptr;
     if (trace_rounds)
       fprintf(stderr, "[pfp] doubling N=%llu round=%llu h=%llu m=%llu -> %u unresolved in %u groups%s\n", (unsigned long long)N,
-              (unsigned long long)out.rounds, (unsigned long long)h, (unsigned long long)m, m2, ngrp, seg_round ? " (seg)" : "");
+              (unsigned long long)out.rounds, (unsigned long long)h, (unsigned long long)m, m2, ngrp,
+              seg_round ? " (seg)" : (pivot_round ? " (pivot)" : ""));
+    // a pivot round that did not at least halve the unresolved set: what is left are members equal to
+    // their pivot for the whole comparison window.  While they are few, one more round with the longest
+    // window settles the long phrases' variants; after that the rest is doubling's business.
+    if (pivot_round && (uint64_t)m2 * 2 > m) {
+      if (!long_cap_tried && (uint64_t)m2 * 64 < N) { long_cap_tried = true; piv_cap = kPivCapMax - 16; }
+      else pivot_ok = false;
+    }
+    const bool was_pivot = pivot_round;
     std::swap(aslot.p, aslot2.p);
     m = m2;
     if (m == 0) break;
     PFP_REQUIRE(h < 2 * N, PFP_EHIP, "suffix sort failed to converge");
     if (!keyo.p) keyo.alloc(c, m);
-    const RankView L = rank_view(out);
     // Rounds after the first: the unresolved suffixes are already grouped, only the 32-bit "next"
     // key has to be ordered inside every group.  When the groups are many and of moderate size (a
     // dictionary of near-identical variants) a segmented sort moves 16 B per suffix instead of the
@@ -421,6 +519,28 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     // sort serialises a giant segment on one workgroup (the 300 k run of one symbol in a parse cost
     // 68 ms), and for tiny groups its bookkeeping eats the gain, so the choice is per round.
     seg_round = false;
+    pivot_round = pivot_ok && g.mode == MODE_DICT && out.finbit && kPivotCap >= 16 && ngrp && m / ngrp <= kPivotAvg;
+    if (pivot_round) {
+      { KScope ks(c, "pfp::build_keys_pivot_kernel", m * (4 + 4 + 4 + 12 + 64));
+        hipLaunchKernelGGL(build_keys_pivot_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, out.bytes, m, h, piv_cap, act_i.p,
+                           act_grp.p, out.sa.p, out.finbit, key.p, val.p); }
+      sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, nb + kPivBits);
+      out.rounds++;
+      (void)was_pivot;
+      continue;                 // the sorted prefix common to all groups is still h: no doubling of h
+    }
+    if (lazy_pending) {
+      lazy_pending = false;
+      if ((uint64_t)m * kLazyRatio > N) {      // most lookups would need the search: scatter the settled ranks once
+        KScope ks(c, "pfp::write_back_kernel", N * (4 + 4 + 1 + 4));
+        hipLaunchKernelGGL(scatter_settled_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, out.sa.p, out.grp.p, keep0.p,
+                           out.finbit, out.rank.p);
+        out.skeys.release();
+        out.tab.release();
+      }
+      keep0.release();
+    }
+    const RankView L = rank_view(out);
     if (use_segsort && m >= (1u << 20) && ngrp && m / ngrp >= 24) {
       if (!gs.p) { gs.alloc(c, N); k32.alloc(c, N); k32o.alloc(c, N); segb.alloc(c, N + 1); sege.alloc(c, N + 1); nseg_d.alloc(c, 2); }
       hipLaunchKernelGGL(group_starts_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, act_grp.p, gs.p);
