@@ -75,17 +75,17 @@ struct SuffixOrder {
   // being scattered to rank[] for all N positions (the scatter was 9 ms of 56 at N = 260 M).
   DBuf<uint64_t> skeys;  // [N] packed keys of the first round in sorted order
   DBuf<uint32_t> tab;    // [T] 0xFFFFFFFF - (first slot whose key has top bits >= T-1-r), r reversed bucket
-  DBuf<uint8_t> lut;     // [256] byte -> dense code
+  DBuf<uint32_t> lut;    // [256] byte -> (alphabetic code << 6) | code length
   const uint8_t *bytes = nullptr;
-  int kbits = 0, cpk = 0, shift = 0;
+  int kbits = 0, shift = 0;   // kbits code bits per key (+ 1 flag bit)
   uint32_t T = 0;
   uint32_t finbit = 0;   // dictionary mode, N < 2^31: rank[] values carry this bit once their suffix is settled
 };
 constexpr uint32_t kNoRank = 0xFFFFFFFFu;
 // device-side view for rank lookups (sufsort.hip: rank_at)
 struct RankView {
-  const uint32_t *rank; const uint64_t *skeys; const uint32_t *tab; const uint8_t *lut; const uint8_t *bytes;
-  uint64_t N; int kbits, cpk, shift; uint32_t T, finbit;
+  const uint32_t *rank; const uint64_t *skeys; const uint32_t *tab; const uint32_t *lut; const uint8_t *bytes;
+  uint64_t N; int kbits, shift; uint32_t T, finbit;
 };
 RankView rank_view(const SuffixOrder &so);
 // out[k] = rank of the suffix starting at pos[k]

@@ -18,6 +18,7 @@
 #include "prims.hpp"
 #include "devutil.hpp"
 #include <algorithm>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 
@@ -34,59 +35,113 @@ __device__ __forceinline__ uint64_t suf_len(const SufGeom &g, uint32_t i) {
   return g.N - i;
 }
 
-// Alphabet-packed initial keys.  The bytes that occur in the dictionary are renumbered densely
-// (0 = past-the-terminator pad, 1 = the 0x01 terminator, 2.. = the other bytes in byte order) and
-// the first `cpk` = 64/bits characters of every suffix are packed into one 64-bit key, first
-// character in the most significant field.  For FASTA-like alphabets (<= 14 distinct bytes) that
-// is 16 characters per key, so the first device-wide sort already orders 16-character prefixes
-// and one whole doubling round over all N suffixes disappears.
-struct KeyPack {
-  int bits, cpk;
-  uint64_t ones, highs;     // 1 in the lowest / highest bit of each of the cpk fields
-  uint8_t lut[256];
+// First-round keys.  The bytes that occur in the dictionary get an order-preserving prefix-free
+// (alphabetic) code whose lengths follow their frequencies - A,C,G,T of a FASTA text cost 2-3 bits,
+// header characters and other rare bytes a dozen - and the codes of the first characters of every
+// suffix are concatenated into kbits (<= 63) bits, cut off where the bits run out; the last bit
+// of the key tells whether the suffix's terminator lies inside.  Concatenated alphabetic codes
+// compare like the strings they encode, so the first device-wide sort orders the suffixes by a
+// prefix of 20-odd characters for DNA text with any number of rare symbols mixed in (a fixed
+// width code gave 16 characters for <= 14 distinct bytes and 12 beyond that), and no suffix is
+// covered by fewer than hmin = kbits / (longest code) characters.
+// lut[b] = (code << 6) | length.
+struct KeyCode {
+  uint32_t lut[256];
+  int kbits, hmin;
 };
 
-__global__ __launch_bounds__(256) void byte_presence_kernel(const uint8_t *__restrict__ s, uint64_t N,
-                                                            uint32_t *__restrict__ present /*[8]*/) {
-  __shared__ uint32_t m[8];
-  if (threadIdx.x < 8) m[threadIdx.x] = 0;
+__global__ __launch_bounds__(256) void byte_histogram_kernel(const uint8_t *__restrict__ s, uint64_t N,
+                                                             uint32_t *__restrict__ hist /*[256]*/) {
+  __shared__ uint32_t h[4][256];
+  for (int q = threadIdx.x; q < 1024; q += 256) (&h[0][0])[q] = 0;
   __syncthreads();
-  uint32_t loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t *mine = h[threadIdx.x >> 6];
   for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; i < N; i += (uint64_t)gridDim.x * 256 * 16) {
     uint4 v = *reinterpret_cast<const uint4 *>(s + i);     // buffer is zero padded past N
     uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+    const int nb = (N - i) >= 16 ? 16 : (int)(N - i);
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        uint32_t c = (w4[q] >> (8 * b)) & 0xff;
-#pragma unroll
-        for (int k = 0; k < 8; k++) loc[k] |= ((c >> 5) == (uint32_t)k) ? (1u << (c & 31)) : 0u;
-      }
+    for (int q = 0; q < 16; q++)
+      if (q < nb) atomicAdd(&mine[(w4[q >> 2] >> (8 * (q & 3))) & 0xff], 1u);
   }
-#pragma unroll
-  for (int k = 0; k < 8; k++) if (loc[k]) atomicOr(&m[k], loc[k]);
   __syncthreads();
-  if (threadIdx.x < 8 && m[threadIdx.x]) atomicOr(&present[threadIdx.x], m[threadIdx.x]);
+  const uint32_t t = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+  if (t) atomicAdd(&hist[threadIdx.x], t);
 }
 
-// packed key of the suffix at i, code table in `lut` (LDS in the bulk kernel, global in lookups)
-__device__ __forceinline__ uint64_t packed_key_at(const uint8_t *__restrict__ s, uint64_t i, int bits, int cpk,
-                                                  const uint8_t *lut) {
+// Alphabetic code by recursive weight-balanced splitting of the symbols in byte order (every split
+// point minimises |left weight - right weight|): within 2 bits of the entropy bound, always a
+// complete prefix-free order-preserving code.  Rare symbols are floored at 1/4096 of the total so
+// that no code grows beyond ~14 bits.
+static void balanced_code(const std::vector<uint64_t> &w, int lo, int hi, uint32_t code, int len, std::vector<uint32_t> &codes,
+                          std::vector<int> &lens) {
+  if (hi - lo == 1) { codes[lo] = code; lens[lo] = len; return; }
+  uint64_t tot = 0;
+  for (int k = lo; k < hi; k++) tot += w[k];
+  uint64_t acc = 0, best = ~0ull;
+  int cut = lo + 1;
+  for (int k = lo; k + 1 < hi; k++) {
+    acc += w[k];
+    const uint64_t l = acc, r = tot - acc, diff = l > r ? l - r : r - l;
+    if (diff < best) { best = diff; cut = k + 1; }
+  }
+  balanced_code(w, lo, cut, code << 1, len + 1, codes, lens);
+  balanced_code(w, cut, hi, (code << 1) | 1u, len + 1, codes, lens);
+}
+static KeyCode make_key_code(const uint32_t hist[256]) {
+  KeyCode kc{};
+  std::vector<int> sym;
+  for (int b2 = 0; b2 < 256; b2++) if (hist[b2] || b2 <= 1) sym.push_back(b2);       // 0x00 / 0x01 always coded
+  uint64_t total = 0;
+  for (int b2 : sym) total += hist[b2];
+  const uint64_t floor_w = total / 4096 + 1;
+  std::vector<uint64_t> w(sym.size());
+  for (size_t k = 0; k < sym.size(); k++) w[k] = std::max<uint64_t>(hist[sym[k]], floor_w);
+  std::vector<uint32_t> codes(sym.size());
+  std::vector<int> lens(sym.size());
+  if (sym.size() == 1) { codes[0] = 0; lens[0] = 1; }
+  else balanced_code(w, 0, (int)sym.size(), 0u, 0, codes, lens);
+  int maxlen = 1;
+  for (int l : lens) maxlen = std::max(maxlen, l);
+  if (maxlen > 24) {        // cannot happen with the weight floor; fixed width keeps the table format valid regardless
+    const int bits = bits_for((uint64_t)sym.size() - 1);
+    for (size_t k = 0; k < sym.size(); k++) { codes[k] = (uint32_t)k; lens[k] = bits; }
+    maxlen = bits;
+  }
+  for (size_t k = 0; k < sym.size(); k++) kc.lut[sym[k]] = (codes[k] << 6) | (uint32_t)lens[k];
+  // bytes that do not occur still need a valid entry (reads past the terminator are masked, not skipped)
+  for (int b2 = 0; b2 < 256; b2++) if (!kc.lut[b2]) kc.lut[b2] = (uint32_t)maxlen;
+  kc.kbits = 63;
+  kc.hmin = std::max(1, std::min(32, kc.kbits / maxlen));
+  return kc;
+}
+
+// key of the suffix at i: codes of its first characters, most significant first, in kbits bits; then
+// one bit "the terminator's code is inside".  `lut` may live in LDS (bulk kernel) or global memory.
+__device__ __forceinline__ uint64_t packed_key_at(const uint8_t *__restrict__ s, uint64_t i, int kbits, const uint32_t *lut) {
   uint4 a = ld16u(s + i), b = ld16u(s + i + 16);
   const uint32_t w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   uint64_t k = 0;
-  bool live = true;
+  int pos = kbits;
+  uint32_t term = 0;
 #pragma unroll
   for (int j = 0; j < 32; j++) {
-    if (j < cpk) {
-      uint32_t c = (w8[j >> 2] >> (8 * (j & 3))) & 0xff;
-      uint32_t code = live ? lut[c] : 0u;
-      k = (k << bits) | code;
-      if (c <= kEndOfWord) live = false;
+    if (pos > 0) {
+      const uint32_t c = (w8[j >> 2] >> (8 * (j & 3))) & 0xff;
+      const uint32_t e = lut[c];
+      const int l = (int)(e & 63u);
+      const uint64_t cd = e >> 6;
+      if (pos >= l) {
+        pos -= l;
+        k |= cd << pos;
+        if (c <= kEndOfWord) { term = 1; pos = 0; }
+      } else {
+        k |= cd >> (l - pos);
+        pos = 0;
+      }
     }
   }
-  return k;
+  return (k << 1) | term;
 }
 
 // Rank of the suffix at j.  rank[j] holds it when some round after the first refined j's group;
@@ -102,7 +157,7 @@ __device__ __forceinline__ uint32_t rank_at(const RankView &L, uint64_t j, bool 
   const uint32_t r = L.rank[j];
   if (L.skeys == nullptr || r != kNoRank) { settled = (r & L.finbit) != 0; return r & ~L.finbit; }
   settled = true;
-  const uint64_t k = packed_key_at(L.bytes, j, L.kbits, L.cpk, L.lut);
+  const uint64_t k = packed_key_at(L.bytes, j, L.kbits, L.lut);
   const uint32_t b = (uint32_t)(k >> L.shift);
   uint32_t lo = 0xFFFFFFFFu - L.tab[L.T - 1 - b];
   uint32_t hi = (b + 1 < L.T) ? 0xFFFFFFFFu - L.tab[L.T - 2 - b] : (uint32_t)L.N;
@@ -113,14 +168,14 @@ __device__ __forceinline__ uint32_t rank_at(const RankView &L, uint64_t j, bool 
   return lo;
 }
 
-__global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyPack kp,
+__global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
                                                                uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
-  __shared__ uint8_t lut[256];
+  __shared__ uint32_t lut[256];
   lut[threadIdx.x] = kp.lut[threadIdx.x];
   __syncthreads();
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  key[i] = packed_key_at(s, i, kp.bits, kp.cpk, lut); val[i] = (uint32_t)i;
+  key[i] = packed_key_at(s, i, kp.kbits, lut); val[i] = (uint32_t)i;
 }
 
 __global__ void init_keys_bytes_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
@@ -267,8 +322,8 @@ __global__ void fill_u32_kernel(uint32_t *p, uint64_t n, uint32_t v) {
 // First round of dictionary mode: sa and grp are the sorted values / scanned heads themselves
 // (streaming copies); rank[] is written only for the suffixes that stay unresolved.
 __global__ void write_back0_kernel(uint64_t m, const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead,
-                                   const uint8_t *__restrict__ hd, const uint64_t *__restrict__ key0, uint64_t ones,
-                                   uint64_t highs, uint32_t *__restrict__ sa, uint32_t *__restrict__ rank,
+                                   const uint8_t *__restrict__ hd, const uint64_t *__restrict__ key0,
+                                   uint32_t *__restrict__ sa, uint32_t *__restrict__ rank,
                                    uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
@@ -277,7 +332,7 @@ __global__ void write_back0_kernel(uint64_t m, const uint32_t *__restrict__ val,
   grp[a] = head;
   const bool single = hd[a] && (a + 1 == m || hd[a + 1]);
   bool fin = false;
-  if (!single) { uint64_t v = key0[a] ^ ones; fin = ((v - ones) & ~v & highs) != 0; }
+  if (!single) fin = (key0[a] & 1ull) != 0;       // the terminator is inside the key: the tied strings are identical
   const bool k = !single && !fin;
   if (k) rank[i] = head;
   keep[a] = k ? 1 : 0;
@@ -392,11 +447,11 @@ static const uint32_t kPivotCap = []() { const char *e = getenv("PFP_PIVOT_CAP")
 static const uint64_t kLazyRatio = []() { const char *e = getenv("PFP_LAZY_RATIO"); return e ? (uint64_t)atoll(e) : 8ull; }();
 
 RankView rank_view(const SuffixOrder &so) {
-  return RankView{so.rank.p, so.skeys.p, so.tab.p, so.lut.p, so.bytes, so.N, so.kbits, so.cpk, so.shift, so.T, so.finbit};
+  return RankView{so.rank.p, so.skeys.p, so.tab.p, so.lut.p, so.bytes, so.N, so.kbits, so.shift, so.T, so.finbit};
 }
 
 static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> &val, uint64_t h0, SuffixOrder &out,
-                     int key0_bits = 64, uint64_t ones = 0, uint64_t highs = 0) {
+                     int key0_bits = 64, bool dict_keys = false) {
   // precondition: key/val hold the initial (prefix key, position) pairs for all N positions
   const uint64_t N = g.N;
   const int TB = 256;
@@ -410,7 +465,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   uint64_t m = N, h = h0;
   out.rounds = 0;
   bool first = true;
-  const bool lazy = ones != 0;      // dictionary mode: out.lut/bytes/kbits/cpk are set by the caller
+  const bool lazy = dict_keys;      // dictionary mode: out.lut/bytes/kbits are set by the caller
   if (lazy) {
     const int tb = std::min(key0_bits, std::max(8, std::min(24, bits_for(N) - 5)));
     out.shift = key0_bits - tb;
@@ -453,7 +508,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     if (round0) {
       { KScope ks(c, "pfp::write_back_kernel", m * (4 + 4 + 1 + 8 + 4 + 4 + 1));
         hipLaunchKernelGGL(write_back0_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, valo.p, newhead.p, hd.p, keyo.p,
-                           ones, highs, out.sa.p, out.rank.p, out.grp.p, keep.p); }
+                           out.sa.p, out.rank.p, out.grp.p, keep.p); }
       // the sorted keys stay with the result; later rounds sort the (smaller) active set elsewhere
       out.skeys = std::move(keyo);
     } else {
@@ -601,34 +656,24 @@ void gather_ranks(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint
 void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out) {
   PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
   SufGeom g{MODE_DICT, N, endpos};
-  // which byte values occur -> dense codes
-  DBuf<uint32_t> present(c, 8);
-  present.zero();
-  hipLaunchKernelGGL(byte_presence_kernel, dim3(std::min<uint64_t>(cdiv64(N, 4096), (uint64_t)c->n_cu * 8)), dim3(256), 0,
-                     c->stream, bytes, N, present.p);
-  uint32_t hp[8];
-  PFP_HIP(hipMemcpyAsync(c->h_scalars, present.p, 32, hipMemcpyDeviceToHost, c->stream));
+  // byte frequencies -> alphabetic code
+  DBuf<uint32_t> hist(c, 256);
+  hist.zero();
+  hipLaunchKernelGGL(byte_histogram_kernel, dim3(std::min<uint64_t>(cdiv64(N, 4096), (uint64_t)c->n_cu * 8)), dim3(256), 0,
+                     c->stream, bytes, N, hist.p);
+  std::vector<uint32_t> hh(256);
+  PFP_HIP(hipMemcpyAsync(hh.data(), hist.p, 1024, hipMemcpyDeviceToHost, c->stream));
   sync(c);
-  memcpy(hp, c->h_scalars, 32);
-  KeyPack kp{};
-  int code = 2;
-  for (int b = 0; b < 256; b++) {
-    bool on = (hp[b >> 5] >> (b & 31)) & 1u;
-    kp.lut[b] = b == 0 ? 0 : (b == 1 ? 1 : (on ? (uint8_t)code++ : 0));
-  }
-  PFP_REQUIRE(code <= 256, PFP_EFORMAT, "alphabet overflow");
-  kp.bits = bits_for((uint64_t)(code - 1));
-  kp.cpk = std::min(64 / kp.bits, 32);
-  for (int f = 0; f < kp.cpk; f++) { kp.ones |= 1ull << (f * kp.bits); kp.highs |= 1ull << (f * kp.bits + kp.bits - 1); }
+  const KeyCode kc = make_key_code(hh.data());
   DBuf<uint64_t> key(c, N);
   DBuf<uint32_t> val(c, N);
   { KScope ks(c, "pfp::init_keys_packed_kernel", N * 13);
-    hipLaunchKernelGGL(init_keys_packed_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kp, key.p, val.p); }
+    hipLaunchKernelGGL(init_keys_packed_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kc, key.p, val.p); }
   out.lut.alloc(c, 256);
-  PFP_HIP(hipMemcpyAsync(out.lut.p, kp.lut, 256, hipMemcpyHostToDevice, c->stream));
-  sync(c);      // kp.lut is a stack array
-  out.bytes = bytes; out.kbits = kp.bits; out.cpk = kp.cpk;
-  doubling(c, g, key, val, (uint64_t)kp.cpk, out, kp.bits * kp.cpk, kp.ones, kp.highs);
+  PFP_HIP(hipMemcpyAsync(out.lut.p, kc.lut, 1024, hipMemcpyHostToDevice, c->stream));
+  sync(c);      // kc is a stack object
+  out.bytes = bytes; out.kbits = kc.kbits;
+  doubling(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true);
 }
 
 void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrder &out) {
