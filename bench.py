@@ -271,7 +271,8 @@ def main():
                        "phrases": st["n_phrases"], "words": st["n_words"], "dict_bytes": st["dict_size"],
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{world} shards of one collection: halo + allgatherv of dictionaries and parse over RCCL, "
-                                        f"replicated dictionary/parse sorts, output-sliced merge") if collection else
+                                        f"suffix array of the global dictionary sharded by key range, every rank emits the BWT "
+                                        f"range its share of SA(D) produces; SA of the parse replicated") if collection else
                                        f"{world} independent texts (one per GPU), no collective")},
             "roofline": roofline,
             "kernels": rows[:12],

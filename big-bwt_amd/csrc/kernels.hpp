@@ -65,7 +65,11 @@ void dictionary_from_bytes(pfp_ctx *c, Dictionary &D);
 
 // ---------------------------------------------------------------- suffix sorting (sufsort.hip)
 struct SuffixOrder {
-  uint64_t N = 0;
+  uint64_t N = 0;        // slots held here: all NP suffixes, or (key-range sharded sort) one contiguous range of SA(D)
+  uint64_t NP = 0;       // positions of the sorted string
+  uint64_t slot_base = 0;        // range mode: SA(D) slot of local slot 0
+  uint64_t klo = 0, khi = ~0ull; // range mode: first-round keys in [klo, khi) (khi == ~0: no upper bound)
+  bool range = false, complete = true;   // range mode stops (complete = false) where it would need other ranks' ranks
   DBuf<uint32_t> sa;     // [N] suffix start positions in sorted order (ties: position order)
   DBuf<uint32_t> grp;    // [N] grp[t] = first sa slot of slot t's group (equal strings share it)
   DBuf<uint32_t> rank;   // [N] rank[i] = grp[slot of i]; kNoRank where the sorter never needed it (see RankView)
@@ -93,6 +97,14 @@ void gather_ranks(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint
 // Suffixes of the dictionary as 0x01-terminated strings (gsacak semantics):
 // endpos[i] = position of the terminator of the word containing i (the final 0x00 is its own word).
 void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out);
+// multi-GPU: rank `part` of `parts` sorts the suffixes whose first-round key lies in its share of the key
+// space (splitters from a deterministic key sample: every rank derives the same ones, no exchange);
+// groups never straddle shares, and pivot rounds compare strings, not ranks, so a share is finished
+// without its neighbours.  out.complete == false: a group was left that only doubling could settle.
+void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, uint32_t part,
+                              uint32_t parts, SuffixOrder &out);
+// range mode: out[j] = 1 + SA(D) slot of the suffix starting at pos[j] if it belongs to this share, else 0
+void gather_slots_range(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint64_t count, uint32_t *d_out);
 // rank[] is written sparsely by the sorter; fill it for given positions (device array) / everywhere
 void materialize_ranks(pfp_ctx *c, SuffixOrder &so, const uint64_t *d_positions, uint64_t count);
 void materialize_all_ranks(pfp_ctx *c, SuffixOrder &so);
@@ -110,6 +122,8 @@ struct DictIndex {        // per-position / per-word helper arrays over the dict
 };
 void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix);
 void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrder &so, DictIndex &ix);
+void compute_lexrank_from_slots(pfp_ctx *c, const Dictionary &D, const uint32_t *d_wslot_all, uint32_t parts, DictIndex &ix);
+uint64_t count_slot_outputs(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, int w);
 
 struct ParseBWT {         // outputs of bwtparse.c in HBM
   uint64_t P = 0;
@@ -131,7 +145,7 @@ struct BwtOutputs {
 // emits BWT positions [out_lo,out_hi) into out.d_bwt[0..) / out.d_sa[0..) (default: everything)
 void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, const ParseBWT &pb,
                const uint32_t *occ_lex, int w, int flags, uint64_t expect_n_out, BwtOutputs &out, uint64_t out_lo = 0,
-               uint64_t out_hi = ~0ull);
+               uint64_t out_hi = ~0ull, uint64_t pos_base = 0, uint64_t n_out_global = 0);
 
 // 5-byte packing and run sampling of finished device outputs
 void pack5_dev(pfp_ctx *c, const uint64_t *vals, uint64_t cnt, uint8_t *out5);

@@ -64,6 +64,58 @@ __global__ void lexrank_from_order_kernel(uint32_t d, const uint32_t *__restrict
   if (r < d) lexrank[word_sorted[r]] = r;
 }
 
+// multi-GPU: every share of the suffix array reported 1 + slot for the words it holds, 0 for the others
+__global__ void combine_word_slots_kernel(uint32_t d, uint32_t parts, const uint32_t *__restrict__ wslot_all,
+                                          uint32_t *__restrict__ key, uint32_t *__restrict__ missing) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= d) return;
+  uint32_t v = 0;
+  for (uint32_t r = 0; r < parts; r++) { const uint32_t x = wslot_all[(uint64_t)r * d + j]; v = x > v ? x : v; }
+  if (v == 0) atomicAdd(missing, 1u);
+  key[j] = v - 1;
+}
+void compute_lexrank_from_slots(pfp_ctx *c, const Dictionary &D, const uint32_t *d_wslot_all, uint32_t parts, DictIndex &ix) {
+  const uint32_t d = (uint32_t)D.d;
+  ix.lexrank.alloc(c, d);
+  DBuf<uint32_t> key(c, d), val(c, d), keyo(c, d), valo(c, d), missing(c, 1);
+  missing.zero();
+  hipLaunchKernelGGL(combine_word_slots_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, parts, d_wslot_all, key.p, missing.p);
+  PFP_REQUIRE(read_scalar(c, missing.p) == 0, PFP_EFORMAT, "a dictionary word was claimed by no share of the suffix array");
+  hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, val.p);
+  sort_pairs_u32_u32(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
+  hipLaunchKernelGGL(lexrank_from_order_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
+  PFP_HIP(hipGetLastError());
+}
+
+// number of BWT positions the slots of `so` emit (sum of the occurrence counts of their words)
+__global__ __launch_bounds__(256) void slot_output_count_kernel(uint64_t n, const uint32_t *__restrict__ sa,
+                                                                const uint32_t *__restrict__ pos_word,
+                                                                const uint32_t *__restrict__ endpos,
+                                                                const uint32_t *__restrict__ wocc, uint32_t d, int w,
+                                                                unsigned long long *__restrict__ total) {
+  __shared__ unsigned long long ws[4];
+  unsigned long long cnt = 0;
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (uint64_t)gridDim.x * 256) {
+    const uint32_t i = sa[t], wd = pos_word[i];
+    if (wd < d && (endpos[i] - i) > (uint32_t)w) cnt += wocc[wd];
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) { const unsigned long long t2 = ws[0] + ws[1] + ws[2] + ws[3]; if (t2) atomicAdd(total, t2); }
+}
+uint64_t count_slot_outputs(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, int w) {
+  DBuf<unsigned long long> total(c, 1);
+  total.zero();
+  if (so.N)
+    hipLaunchKernelGGL(slot_output_count_kernel, dim3((int)std::min<uint64_t>(cdiv64(so.N, 256), (uint64_t)c->n_cu * 16)), dim3(256),
+                       0, c->stream, so.N, so.sa.p, ix.pos_word.p, ix.endpos.p, D.wocc.p, (uint32_t)D.d, w, total.p);
+  PFP_HIP(hipGetLastError());
+  PFP_HIP(hipMemcpyAsync(c->h_scalars, total.p, 8, hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  return c->h_scalars[0];
+}
+
 void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrder &so, DictIndex &ix) {
   const uint32_t d = (uint32_t)D.d;
   ix.lexrank.alloc(c, d);
@@ -208,6 +260,7 @@ __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank,
 
 struct MergeArgs {
   uint64_t N, n_out; uint32_t d; int w; int want_sa; int dbg_mode;
+  uint64_t pos_base, n_out_global;   // global BWT position of local position 0; global n+1 (== n_out unless the slots are one rank's range)
   uint64_t out_lo, out_hi;   // this call emits BWT positions [out_lo,out_hi) only (multi-GPU slices); bwt/out_sa are indexed by global position
   const uint32_t *sa, *endpos, *grp, *ist, *pos_word, *wistart;
   const uint8_t *pc, *hard; const uint64_t *off;
@@ -280,7 +333,7 @@ __device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L
         ch = a.bwlast[pos];
         if (a.want_sa && in_slice) {
           const uint32_t i = a.sa[t0 + s];
-          a.out_sa[base + x] = (base + x == 0) ? a.n_out - 1 : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
+          a.out_sa[base + x] = (a.pos_base + base + x == 0) ? a.n_out_global - 1 : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
         }
       }   // CLS_HARD: left 0 here, written by the hard-group kernels that run after this one
       const uint32_t sh = (uint32_t)ch << (8 * (k & 3));
@@ -498,8 +551,11 @@ __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgs a, const BigGro
 
 void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, const ParseBWT &pb,
                const uint32_t *occ_lex, int w, int flags, uint64_t expect_n_out, BwtOutputs &out, uint64_t out_lo,
-               uint64_t out_hi) {
-  const uint64_t N = D.dsize;
+               uint64_t out_hi, uint64_t pos_base, uint64_t n_out_global) {
+  // NP dictionary positions; N suffix-array slots held by `so` (all of them, or - multi-GPU, key-range
+  // sharded sort - one contiguous range of SA(D) whose first output position is pos_base)
+  const uint64_t NP = D.dsize;
+  const uint64_t N = so.N;
   const uint32_t d = (uint32_t)D.d;
   PFP_REQUIRE(!flags || pb.bwsai.p, PFP_EINVAL, "SA output requested without sa info");
   // istart in lexicographic order (pfbwt.cpp:388-396), looked up per word
@@ -509,15 +565,15 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   DBuf<uint16_t> pp16;
   DBuf<uint64_t> pp64;
   DBuf<uint32_t> cnt(c, N + 8), ist;
-  if (flags) { ist.alloc(c, N + 8); pp64.alloc(c, N); } else pp16.alloc(c, N);
+  if (flags) { ist.alloc(c, N + 8); pp64.alloc(c, NP); } else pp16.alloc(c, NP);
   DBuf<uint8_t> pc(c, N + 8), hard(c, N);
   DBuf<uint64_t> off(c, N + 1);
   PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream));
   hard.zero();
-  { KScope ks(c, "pfp::pprec_kernel", N * (1 + 4 + 4 + (flags ? 8 : 2)));
-    if (flags) hipLaunchKernelGGL(pprec_kernel<uint64_t>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, d, w,
+  { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + (flags ? 8 : 2)));
+    if (flags) hipLaunchKernelGGL(pprec_kernel<uint64_t>, dim3(cdiv(NP, TB)), dim3(TB), 0, c->stream, D.bytes.p, NP, d, w,
                                   ix.pos_word.p, ix.endpos.p, D.wocc.p, pp64.p);
-    else hipLaunchKernelGGL(pprec_kernel<uint16_t>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, d, w,
+    else hipLaunchKernelGGL(pprec_kernel<uint16_t>, dim3(cdiv(NP, TB)), dim3(TB), 0, c->stream, D.bytes.p, NP, d, w,
                             ix.pos_word.p, ix.endpos.p, D.wocc.p, pp16.p); }
   { KScope ks(c, "pfp::slot_gather_kernel", N * (4 + 5 + (flags ? 12 : 2)));
     const dim3 grid(cdiv(cdiv64(N, 8), 256));
@@ -535,6 +591,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   out.n_out = n_out;
   MergeArgs a{};
   a.N = N; a.n_out = n_out; a.d = d; a.w = w; a.want_sa = flags ? 1 : 0;
+  a.pos_base = pos_base; a.n_out_global = n_out_global ? n_out_global : n_out;
   { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
   a.sa = so.sa.p; a.endpos = ix.endpos.p; a.grp = so.grp.p; a.ist = flags ? ist.p : nullptr;
   a.pos_word = ix.pos_word.p; a.wistart = wistart.p;

@@ -616,6 +616,7 @@ struct DistState {
   DictIndex ix;
   SuffixOrder so;
   DBuf<uint32_t> occ_lex;
+  uint64_t local_total = 0;     // BWT positions the held slots emit
 };
 static DistState *dist_of(pfp_ctx *c) {
   if (!c->dist) c->dist = new DistState();
@@ -633,6 +634,11 @@ __global__ void dist_sym_kernel(uint64_t P, const uint32_t *__restrict__ lpid, u
                                 uint32_t *__restrict__ sym) {
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < P) sym[k] = lexrank[gid_of_union[word_base + lpid[k]]] + 1;
+}
+
+__global__ void add_one_kernel(uint32_t n, const uint32_t *__restrict__ in, uint32_t *__restrict__ out) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) out[j] = in[j] + 1;
 }
 
 extern "C" {
@@ -717,13 +723,13 @@ int pfp_dist_export_local(pfp_ctx *c, void *d_dict, void *d_occ, void *d_last, v
   PFP_CATCH(c)
 }
 
-int pfp_dist_global(pfp_ctx *c, const void *d_union, uint64_t union_bytes, const void *d_union_occ, uint64_t n_union,
-                    uint64_t my_word_base, void *d_sym_out, uint64_t out_info[3]) {
-  if (!c || !c->dist || !d_union || !d_union_occ || !d_sym_out || !out_info) return PFP_EINVAL;
+int pfp_dist_global_sort(pfp_ctx *c, const void *d_union, uint64_t union_bytes, const void *d_union_occ, uint64_t n_union,
+                         uint32_t part, uint32_t parts, void *d_wslot_out, uint64_t out_info[8]) {
+  if (!c || !c->dist || !d_union || !d_union_occ || !d_wslot_out || !out_info || parts < 1 || part >= parts) return PFP_EINVAL;
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
   DistState *ds = dist_of(c);
-  PFP_REQUIRE(n_union >= 1 && my_word_base + ds->L.d <= n_union, PFP_EINVAL, "inconsistent union layout");
+  PFP_REQUIRE(n_union >= 1, PFP_EINVAL, "empty union");
   // the union is itself a (not sorted, not duplicate-free) dictionary: words + 0x01, closed by one 0x00
   Dictionary U; DictIndex uix;
   U.dsize = union_bytes + 1; U.d = n_union;
@@ -735,13 +741,40 @@ int pfp_dist_global(pfp_ctx *c, const void *d_union, uint64_t union_bytes, const
   hipLaunchKernelGGL(words_from_wend_kernel, dim3(cdiv(n_union, TB)), dim3(TB), 0, c->stream, (uint32_t)n_union, uix.wend.p,
                      U.woff.p, U.wlen.p);
   ds->G = Dictionary();
+  ds->ix = DictIndex();
+  ds->so = SuffixOrder();
   build_dictionary_words(c, U.bytes.p, U.woff.p, U.wlen.p, n_union, (const uint32_t *)d_union_occ, union_bytes, ds->G);
-  if (c->debug) { Dictionary &G = ds->G; (void)G; }
   build_dict_index(c, ds->G, ds->ix);
-  sort_dict_suffixes(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, ds->so);
-  if (c->debug) validate_suffix_order(c, ds->G.bytes.p, ds->so, true, "global dict SA");
-  compute_lexrank(c, ds->G, ds->so, ds->ix);
   const uint32_t d = (uint32_t)ds->G.d;
+  if (parts == 1) {
+    sort_dict_suffixes(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, ds->so);
+    if (c->debug) validate_suffix_order(c, ds->G.bytes.p, ds->so, true, "global dict SA");
+    DBuf<uint32_t> slots(c, d);
+    gather_ranks(c, ds->so, ds->G.woff.p, d, slots.p);
+    hipLaunchKernelGGL(add_one_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, slots.p, (uint32_t *)d_wslot_out);
+    ds->local_total = 0;
+  } else {
+    sort_dict_suffixes_range(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, part, parts, ds->so);
+    gather_slots_range(c, ds->so, ds->G.woff.p, d, (uint32_t *)d_wslot_out);
+    ds->local_total = ds->so.complete ? count_slot_outputs(c, ds->G, ds->ix, ds->so, ds->w) : 0;
+  }
+  PFP_HIP(hipGetLastError());
+  sync(c);
+  out_info[0] = ds->G.d; out_info[1] = ds->G.dsize; out_info[2] = ds->so.rounds; out_info[3] = ds->so.complete ? 1 : 0;
+  out_info[4] = ds->so.N; out_info[5] = ds->so.slot_base; out_info[6] = ds->local_total; out_info[7] = 0;
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_dist_global_finish(pfp_ctx *c, const void *d_wslot_all, uint32_t parts, uint64_t my_word_base, void *d_sym_out) {
+  if (!c || !c->dist || !d_wslot_all || !d_sym_out || parts < 1) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  const uint32_t d = (uint32_t)ds->G.d;
+  PFP_REQUIRE(d >= 1, PFP_EINVAL, "pfp_dist_global_sort has not run");
+  compute_lexrank_from_slots(c, ds->G, (const uint32_t *)d_wslot_all, parts, ds->ix);
+  if (c->debug) validate_lexrank(c, ds->G, ds->ix);
   ds->occ_lex.alloc(c, d);
   hipLaunchKernelGGL(occ_lex_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ds->ix.lexrank.p, ds->G.wocc.p,
                      ds->occ_lex.p, (uint32_t *)nullptr);
@@ -749,9 +782,22 @@ int pfp_dist_global(pfp_ctx *c, const void *d_union, uint64_t union_bytes, const
                      my_word_base, ds->G.pid.p, ds->ix.lexrank.p, (uint32_t *)d_sym_out);
   PFP_HIP(hipGetLastError());
   sync(c);
-  out_info[0] = ds->G.d; out_info[1] = ds->G.dsize; out_info[2] = ds->so.rounds;
   return PFP_OK;
   PFP_CATCH(c)
+}
+
+// the two steps above on one rank holding the whole suffix array (no exchange in between)
+int pfp_dist_global(pfp_ctx *c, const void *d_union, uint64_t union_bytes, const void *d_union_occ, uint64_t n_union,
+                    uint64_t my_word_base, void *d_sym_out, uint64_t out_info[3]) {
+  if (!c || !c->dist || !d_union || !d_union_occ || !d_sym_out || !out_info) return PFP_EINVAL;
+  uint64_t info[8];
+  uint32_t *wslot = nullptr;
+  if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void **)&wslot, (n_union ? n_union : 1) * 4) != hipSuccess) return PFP_ENOMEM;
+  int rc = pfp_dist_global_sort(c, d_union, union_bytes, d_union_occ, n_union, 0, 1, wslot, info);
+  if (rc == PFP_OK) rc = pfp_dist_global_finish(c, wslot, 1, my_word_base, d_sym_out);
+  (void)hipFree(wslot);
+  if (rc == PFP_OK) { out_info[0] = info[0]; out_info[1] = info[1]; out_info[2] = info[2]; }
+  return rc;
 }
 
 int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last, const void *d_sai, int flags,
@@ -768,7 +814,14 @@ int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last
   if (c->debug) validate_parse_bwt(c, pb);
   BwtOutputs bo;
   bo.d_bwt = (uint8_t *)d_bwt_slice; bo.d_sa = (uint64_t *)d_sa_slice;
-  merge_bwt(c, ds->G, ds->ix, ds->so, pb, ds->occ_lex.p, ds->w, flags, n_total + 1, bo, out_lo, out_hi);
+  if (ds->so.range) {
+    // the held slots are one contiguous range of SA(D): they emit exactly [out_lo, out_hi)
+    PFP_REQUIRE(ds->so.complete, PFP_EINVAL, "this share of the suffix array is incomplete: redo pfp_dist_global_sort with parts = 1");
+    PFP_REQUIRE(out_hi - out_lo == ds->local_total, PFP_EINVAL, "output range does not match this share's occurrence count");
+    merge_bwt(c, ds->G, ds->ix, ds->so, pb, ds->occ_lex.p, ds->w, flags, ds->local_total, bo, 0, ~0ull, out_lo, n_total + 1);
+  } else {
+    merge_bwt(c, ds->G, ds->ix, ds->so, pb, ds->occ_lex.p, ds->w, flags, n_total + 1, bo, out_lo, out_hi);
+  }
   sync(c);
   return PFP_OK;
   PFP_CATCH(c)

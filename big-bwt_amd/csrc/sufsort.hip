@@ -466,12 +466,17 @@ RankView rank_view(const SuffixOrder &so) {
 }
 
 static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> &val, uint64_t h0, SuffixOrder &out,
-                     int key0_bits = 64, bool dict_keys = false) {
-  // precondition: key/val hold the initial (prefix key, position) pairs for all N positions
-  const uint64_t N = g.N;
+                     int key0_bits = 64, bool dict_keys = false, uint64_t n_elems = ~0ull) {
+  // precondition: key/val hold the initial (prefix key, position) pairs of the N suffixes to sort: all
+  // NP positions, or (range mode, n_elems given) the ones of this rank's key range
+  const uint64_t NP = g.N;
+  const bool range_mode = n_elems != ~0ull;
+  const uint64_t N = range_mode ? n_elems : NP;
   const int TB = 256;
-  out.N = N;
-  out.sa.alloc(c, N); out.rank.alloc(c, N); out.grp.alloc(c, N + 8);
+  out.N = N; out.NP = NP; out.range = range_mode; out.complete = true;
+  out.rounds = 0;
+  out.sa.alloc(c, N); out.rank.alloc(c, NP); out.grp.alloc(c, N + 8);
+  if (N == 0) return;
   DBuf<uint64_t> keyo(c, N);
   DBuf<uint32_t> valo(c, N), aslot(c, N), aslot2(c, N), hv(c, N), newhead(c, N), inc(c, N), act_i(c, N), act_grp(c, N);
   DBuf<uint8_t> hd(c, N + 1), keep(c, N);
@@ -488,7 +493,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     out.tab.alloc(c, out.T);
     hipLaunchKernelGGL(fill_u32_kernel, dim3(cdiv(out.T, TB)), dim3(TB), 0, c->stream, out.tab.p, (uint64_t)out.T,
                        0xFFFFFFFFu - (uint32_t)N);
-    PFP_HIP(hipMemsetAsync(out.rank.p, 0xff, N * 4, c->stream));
+    PFP_HIP(hipMemsetAsync(out.rank.p, 0xff, NP * 4, c->stream));
   }
   const int nb = bits_for(N);           // key of a later round = (group head << nb) | (1 + rank of the continuation)
   const int keybits = 2 * nb;
@@ -580,7 +585,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     std::swap(aslot.p, aslot2.p);
     m = m2;
     if (m == 0) break;
-    PFP_REQUIRE(h < 2 * N, PFP_EHIP, "suffix sort failed to converge");
+    PFP_REQUIRE(h < 2 * NP, PFP_EHIP, "suffix sort failed to converge");
     if (!keyo.p) keyo.alloc(c, m);
     // Rounds after the first: the unresolved suffixes are already grouped, only the 32-bit "next"
     // key has to be ordered inside every group.  When the groups are many and of moderate size (a
@@ -599,6 +604,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       (void)was_pivot;
       continue;                 // the sorted prefix common to all groups is still h: no doubling of h
     }
+    if (range_mode) { out.complete = false; break; }     // doubling would read ranks of suffixes other ranks hold
     if (lazy_pending) {
       lazy_pending = false;
       if ((uint64_t)m * kLazyRatio > N) {      // most lookups would need the search: scatter the settled ranks once
@@ -668,10 +674,7 @@ void gather_ranks(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint
   PFP_HIP(hipGetLastError());
 }
 
-void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out) {
-  PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
-  SufGeom g{MODE_DICT, N, endpos};
-  // byte frequencies -> alphabetic code
+static KeyCode dict_key_code(pfp_ctx *c, const uint8_t *bytes, uint64_t N) {
   DBuf<uint32_t> hist(c, 256);
   hist.zero();
   hipLaunchKernelGGL(byte_histogram_kernel, dim3(std::min<uint64_t>(cdiv64(N, 4096), (uint64_t)c->n_cu * 8)), dim3(256), 0,
@@ -679,7 +682,13 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   std::vector<uint32_t> hh(256);
   PFP_HIP(hipMemcpyAsync(hh.data(), hist.p, 1024, hipMemcpyDeviceToHost, c->stream));
   sync(c);
-  const KeyCode kc = make_key_code(hh.data());
+  return make_key_code(hh.data());
+}
+
+void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out) {
+  PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
+  SufGeom g{MODE_DICT, N, endpos};
+  const KeyCode kc = dict_key_code(c, bytes, N);
   DBuf<uint64_t> key(c, N);
   DBuf<uint32_t> val(c, N);
   { KScope ks(c, "pfp::init_keys_packed_kernel", N * 13);
@@ -689,6 +698,118 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   sync(c);      // kc is a stack object
   out.bytes = bytes; out.kbits = kc.kbits;
   doubling(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true);
+}
+
+// ---- key-range sharded variant (multi-GPU)
+__global__ void sample_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t stride, uint32_t ns, KeyCode kp,
+                                   uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+  __shared__ uint32_t lut[256];
+  lut[threadIdx.x] = kp.lut[threadIdx.x];
+  __syncthreads();
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= ns) return;
+  const uint64_t i = (uint64_t)k * stride;
+  key[k] = i < N ? packed_key_at(s, i, kp.kbits, lut) : ~0ull;
+  val[k] = k;
+}
+// flag the suffixes whose key lies in [klo, khi) (khi_open: no upper bound) and count those below klo
+__global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp, uint64_t klo,
+                                                          uint64_t khi, int khi_open, uint8_t *__restrict__ flag,
+                                                          unsigned long long *__restrict__ below) {
+  __shared__ uint32_t lut[256];
+  __shared__ unsigned long long wsum[4];
+  lut[threadIdx.x] = kp.lut[threadIdx.x];
+  __syncthreads();
+  unsigned long long cnt = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t k = packed_key_at(s, i, kp.kbits, lut);
+    cnt += k < klo ? 1ull : 0ull;
+    flag[i] = (k >= klo && (khi_open || k < khi)) ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) { const unsigned long long t = wsum[0] + wsum[1] + wsum[2] + wsum[3]; if (t) atomicAdd(below, t); }
+}
+__global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__restrict__ s, uint64_t n, KeyCode kp,
+                                                             const uint32_t *__restrict__ idx, uint64_t *__restrict__ key,
+                                                             uint32_t *__restrict__ val) {
+  __shared__ uint32_t lut[256];
+  lut[threadIdx.x] = kp.lut[threadIdx.x];
+  __syncthreads();
+  uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (a >= n) return;
+  const uint32_t i = idx[a];
+  key[a] = packed_key_at(s, i, kp.kbits, lut); val[a] = i;
+}
+
+void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, uint32_t part,
+                              uint32_t parts, SuffixOrder &out) {
+  PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
+  PFP_REQUIRE(parts >= 1 && part < parts, PFP_EINVAL, "bad key-range share");
+  SufGeom g{MODE_DICT, N, endpos};
+  const KeyCode kc = dict_key_code(c, bytes, N);
+  // splitters: every stride-th suffix's key, sorted; the same on every rank
+  uint64_t klo = 0, khi = ~0ull;
+  if (parts > 1) {
+    const uint32_t ns = (uint32_t)std::min<uint64_t>(N, 1u << 16);
+    const uint64_t stride = N / ns;
+    DBuf<uint64_t> sk(c, ns), sko(c, ns);
+    DBuf<uint32_t> sv(c, ns), svo(c, ns);
+    hipLaunchKernelGGL(sample_keys_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, c->stream, bytes, N, stride, ns, kc, sk.p, sv.p);
+    sort_pairs_u64_u32(c, sk.p, sko.p, sv.p, svo.p, ns, 0, 64);
+    std::vector<uint64_t> hs(ns);
+    PFP_HIP(hipMemcpyAsync(hs.data(), sko.p, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    if (part > 0) klo = hs[(uint64_t)part * ns / parts];
+    if (part + 1 < parts) khi = hs[(uint64_t)(part + 1) * ns / parts];
+  }
+  const int khi_open = part + 1 == parts ? 1 : 0;
+  DBuf<uint8_t> flag(c, N);
+  DBuf<unsigned long long> below(c, 1);
+  below.zero();
+  hipLaunchKernelGGL(range_flags_kernel, dim3((int)std::min<uint64_t>(cdiv64(N, 256), (uint64_t)c->n_cu * 16)), dim3(256), 0,
+                     c->stream, bytes, N, kc, klo, khi, khi_open, flag.p, below.p);
+  DBuf<uint32_t> idx(c, N), cnt_d(c, 1);
+  select_index_u32(c, flag.p, idx.p, cnt_d.p, N);
+  PFP_HIP(hipMemcpyAsync(c->h_scalars, cnt_d.p, 4, hipMemcpyDeviceToHost, c->stream));
+  PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, below.p, 8, hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  uint32_t n_mine;
+  memcpy(&n_mine, c->h_scalars, 4);
+  const uint64_t slot_base = c->h_scalars[1];
+  flag.release();
+  DBuf<uint64_t> key(c, std::max<uint64_t>(n_mine, 1));
+  DBuf<uint32_t> val(c, std::max<uint64_t>(n_mine, 1));
+  if (n_mine) {
+    KScope ks(c, "pfp::init_keys_packed_kernel", (uint64_t)n_mine * 17);
+    hipLaunchKernelGGL(init_keys_list_kernel, dim3(cdiv(n_mine, 256)), dim3(256), 0, c->stream, bytes, (uint64_t)n_mine, kc, idx.p,
+                       key.p, val.p);
+  }
+  idx.release();
+  out.lut.alloc(c, 256);
+  PFP_HIP(hipMemcpyAsync(out.lut.p, kc.lut, 1024, hipMemcpyHostToDevice, c->stream));
+  sync(c);      // kc is a stack object
+  out.bytes = bytes; out.kbits = kc.kbits;
+  doubling(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true, (uint64_t)n_mine);
+  out.slot_base = slot_base; out.klo = klo; out.khi = khi_open ? ~0ull : khi;
+}
+
+__global__ void gather_slots_range_kernel(RankView L, uint64_t klo, uint64_t khi, uint64_t slot_base, uint64_t count,
+                                          const uint64_t *__restrict__ pos, uint32_t *__restrict__ out) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= count) return;
+  const uint64_t j = pos[a];
+  const uint64_t k = packed_key_at(L.bytes, j, L.kbits, L.lut);
+  uint32_t r = 0;
+  if (k >= klo && (khi == ~0ull || k < khi)) { bool settled; r = (uint32_t)(slot_base + rank_at(L, j, settled) + 1); }
+  out[a] = r;
+}
+void gather_slots_range(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint64_t count, uint32_t *d_out) {
+  if (!count) return;
+  hipLaunchKernelGGL(gather_slots_range_kernel, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, rank_view(so), so.klo, so.khi,
+                     so.slot_base, count, d_pos, d_out);
+  PFP_HIP(hipGetLastError());
 }
 
 void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrder &out) {

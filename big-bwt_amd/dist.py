@@ -7,10 +7,18 @@ pfthreads.hpp:456-493 does).  Per rank:
     tails      allgather     last `halo` bytes of every shard (phrases that straddle a boundary)
     local      compute       scan halo+shard, own the phrases ending in the shard, local dedup
     dicts/occ  allgatherv    local dictionaries (O(|D|), small for repetitive collections)
-    global     compute       dedup of the union -> global dictionary, its suffix order (replicated),
+    global     compute       dedup of the union -> global dictionary (replicated); its suffix array
+                             sharded by key range: every rank sorts the suffixes whose first-round
+                             key lies in its part of the key space (same splitters everywhere, no
+                             exchange) and holds one contiguous range of SA(D)
+    words      allgather     slot of every word's first suffix (4 B per word) + how many BWT
+                             positions each range emits -> word ranks, output offsets;
                              own parse translated to global lexicographic ranks
     parse      allgatherv    parse symbols, last, sai  (O(P) = O(n/p))
-    merge      compute       BWT of the parse (replicated), slice [lo,hi) of the BWT / SA
+    merge      compute       BWT of the parse (replicated), then the BWT / SA positions that the
+                             held range of SA(D) emits (one contiguous slice per rank)
+A range whose groups cannot be settled without other ranks' ranks (a long exact repeat inside the
+dictionary) makes all ranks fall back to the replicated sort and equal output slices.
 
 The algorithm is written once as a generator that yields collective requests; `run` drives it with
 torch.distributed, `simulate` drives R of them in one process (tests: R virtual ranks on one GPU).
@@ -49,7 +57,7 @@ def slice_bounds(n_out, rank, size):
 
 
 # ----------------------------------------------------------------------------- the algorithm
-def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO):
+def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True):
     """Generator.  `shard`: 1-D uint8 device tensor, this rank's byte range of the text.
     Yields ('allgather', tensor) and receives the list of all ranks' tensors.
     Returns dict(bwt=slice tensor, sa=slice tensor|None, lo, hi, n_total, stats)."""
@@ -93,9 +101,27 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO):
     union_occ = torch.cat(occs).contiguous()
     word_base = sum(o.numel() for o in occs[:rank])
     d_sym = torch.empty(info["phrases"], dtype=torch.int32, device=dev)
+    wslot = torch.zeros(union_occ.numel(), dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)
-    ginfo = ctx.dist_global(union.data_ptr(), union.numel(), union_occ.data_ptr(), union_occ.numel(), word_base, d_sym.data_ptr())
-    del union, union_occ, dicts, occs, d_dict, d_occ
+    parts = size if shard_sa else 1
+    ginfo = ctx.dist_global_sort(union.data_ptr(), union.numel(), union_occ.data_ptr(), union_occ.numel(), rank if parts > 1 else 0,
+                                 parts, wslot.data_ptr())
+    status = yield ("allgather", torch.tensor([1 if ginfo["complete"] else 0, ginfo["emits"]], dtype=torch.int64, device=dev))
+    if parts > 1 and not all(int(s[0]) for s in status):
+        # some range needs ranks it does not hold: every rank sorts everything (the replicated path)
+        parts = 1
+        wslot.zero_()
+        ginfo = ctx.dist_global_sort(union.data_ptr(), union.numel(), union_occ.data_ptr(), union_occ.numel(), 0, 1, wslot.data_ptr())
+    emits = [int(s[1]) for s in status]
+    wslots = yield ("allgather", wslot[: ginfo["words"]].contiguous())
+    if parts > 1:
+        wslot_all = torch.cat(wslots).contiguous()
+        torch.cuda.synchronize(dev)
+        ctx.dist_global_finish(wslot_all.data_ptr(), parts, word_base, d_sym.data_ptr())
+        del wslot_all
+    else:
+        ctx.dist_global_finish(wslot.data_ptr(), 1, word_base, d_sym.data_ptr())
+    del union, union_occ, dicts, occs, d_dict, d_occ, wslot, wslots
     # --- the whole parse everywhere
     syms = yield ("allgather", d_sym)
     lasts = yield ("allgather", d_last)
@@ -106,21 +132,28 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO):
         sais = yield ("allgather", d_sai)
         sai_all = torch.cat(sais).contiguous()
     n_out = n_total + 1
-    lo, hi = slice_bounds(n_out, rank, size)
+    if parts > 1:
+        if sum(emits) != n_out:
+            raise pfp.PfpError(-6, f"the ranges of SA(D) emit {sum(emits)} positions, text length + 1 is {n_out}")
+        lo = sum(emits[:rank])
+        hi = lo + emits[rank]
+    else:
+        lo, hi = slice_bounds(n_out, rank, size)
     bwt = torch.empty(hi - lo + 16, dtype=torch.uint8, device=dev)
     sa = torch.empty(hi - lo + 1, dtype=torch.int64, device=dev) if flags else None
     torch.cuda.synchronize(dev)
     ctx.dist_merge(sym_all.data_ptr(), sym_all.numel(), last_all.data_ptr(), sai_all.data_ptr() if want_sai else None, flags,
                    n_total, lo, hi, bwt.data_ptr(), sa.data_ptr() if flags else None)
-    stats = dict(local=info, glob=ginfo, phrases_total=int(sym_all.numel()), shard_bytes=n_shard, extra_triggers=len(extra))
+    stats = dict(local=info, glob=ginfo, phrases_total=int(sym_all.numel()), shard_bytes=n_shard, extra_triggers=len(extra),
+                 sa_shares=parts)
     return dict(bwt=bwt[: hi - lo], sa=sa[: hi - lo] if flags else None, lo=lo, hi=hi, n_total=n_total, stats=stats)
 
 
-def run(ctx, shard, w=10, p=100, flags=0, halo=DEFAULT_HALO, group=None):
+def run(ctx, shard, w=10, p=100, flags=0, halo=DEFAULT_HALO, group=None, shard_sa=True):
     """Drive `phases` with torch.distributed (backend nccl == RCCL on ROCm; gloo works for CPU tests of the plumbing)."""
     import torch.distributed as dist
     rank, size = dist.get_rank(group), dist.get_world_size(group)
-    gen = phases(ctx, shard, rank, size, w, p, flags, halo)
+    gen = phases(ctx, shard, rank, size, w, p, flags, halo, shard_sa)
     reply = None
     try:
         while True:
@@ -133,12 +166,12 @@ def run(ctx, shard, w=10, p=100, flags=0, halo=DEFAULT_HALO, group=None):
         return fin.value
 
 
-def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO):
+def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True):
     """Run R virtual ranks in one process (ctxs[r], shards[r] may all live on one GPU): every
     collective is served by plain concatenation.  Used by the GPU tests to check the distributed
     chain bit for bit against the single-GPU chain."""
     size = len(shards)
-    gens = [phases(ctxs[r], shards[r], r, size, w, p, flags, halo) for r in range(size)]
+    gens = [phases(ctxs[r], shards[r], r, size, w, p, flags, halo, shard_sa) for r in range(size)]
     replies = [None] * size
     results = [None] * size
     live = set(range(size))

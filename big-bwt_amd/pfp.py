@@ -31,7 +31,7 @@ SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror"
            "pfp_free", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak",
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_dev", "pfp_get_stats",
            "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
-           "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_merge", "pfp_dist_release"]
+           "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_merge", "pfp_dist_release"]
 
 
 class PfpError(RuntimeError):
@@ -318,6 +318,18 @@ class Context:
         self._check(self.lib.pfp_dist_global(self._h, C.c_void_p(d_union), C.c_uint64(union_bytes), C.c_void_p(d_union_occ),
                                              C.c_uint64(n_union), C.c_uint64(my_word_base), C.c_void_p(d_sym_out), info))
         return dict(words=int(info[0]), dict_bytes=int(info[1]), rounds=int(info[2]))
+
+    def dist_global_sort(self, d_union, union_bytes, d_union_occ, n_union, part, parts, d_wslot_out):
+        info = (C.c_uint64 * 8)()
+        self._check(self.lib.pfp_dist_global_sort(self._h, C.c_void_p(d_union), C.c_uint64(union_bytes), C.c_void_p(d_union_occ),
+                                                  C.c_uint64(n_union), C.c_uint32(part), C.c_uint32(parts), C.c_void_p(d_wslot_out),
+                                                  info))
+        return dict(words=int(info[0]), dict_bytes=int(info[1]), rounds=int(info[2]), complete=bool(info[3]), slots=int(info[4]),
+                    slot_base=int(info[5]), emits=int(info[6]))
+
+    def dist_global_finish(self, d_wslot_all, parts, my_word_base, d_sym_out):
+        self._check(self.lib.pfp_dist_global_finish(self._h, C.c_void_p(d_wslot_all), C.c_uint32(parts), C.c_uint64(my_word_base),
+                                                    C.c_void_p(d_sym_out)))
 
     def dist_merge(self, d_sym, P, d_last, d_sai, flags, n_total, out_lo, out_hi, d_bwt_slice, d_sa_slice=None):
         self._check(self.lib.pfp_dist_merge(self._h, C.c_void_p(d_sym), C.c_uint64(P), C.c_void_p(d_last),

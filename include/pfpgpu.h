@@ -179,9 +179,23 @@ void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
  *       occ; my_word_base = index of this rank's first word in the union.  Builds the global
  *       dictionary and writes this rank's parse as global 1-based ranks (u32[local phrases]).
  *       out_info = {global words, global dict bytes, doubling rounds}
+ *   pfp_dist_global_sort / pfp_dist_global_finish: the same in two steps, with the suffix array of
+ *       the global dictionary sharded by key range (the reference shards the same array by index
+ *       range across threads, pfthreads.hpp:171-176): share `part` of `parts` sorts the suffixes
+ *       whose first-round key falls in its part of the key space (splitters from a deterministic
+ *       sample, identical on all ranks, no exchange) and holds one contiguous range of SA(D).
+ *       d_wslot_out (u32[n_union], the first out_info[0] used): 1 + SA(D) slot of every global
+ *       word's first suffix if this share holds it, else 0.  out_info = {global words, global
+ *       dict bytes, sorting rounds, complete (0/1), slots held, first slot, BWT positions the held
+ *       slots emit, 0}.  complete == 0: some group could not be settled without other shares'
+ *       ranks - every rank must then redo the step with parts = 1 (the replicated sort).
+ *       The caller allgathers d_wslot_out (and complete / emit counts) and passes all `parts`
+ *       arrays, out_info[0] entries each, back to back to pfp_dist_global_finish, which ranks the
+ *       words and writes this rank's parse.  parts = 1 needs no exchange (= pfp_dist_global).
  *   pfp_dist_merge       : d_sym/d_last/d_sai = the whole parse in text order (all ranks);
  *       n_total = text length; emits BWT positions [out_lo,out_hi) into d_bwt_slice (u8) and, with
- *       flags, SA values into d_sa_slice (u64).
+ *       flags, SA values into d_sa_slice (u64).  After a sharded sort [out_lo,out_hi) must be the
+ *       range the held slots emit: out_lo = sum of the emit counts of the lower shares.
  * ------------------------------------------------------------------------------------ */
 int pfp_dist_propose_triggers(pfp_ctx *ctx, const void *d_text, uint64_t n, int w, uint64_t p,
                               uint32_t out_hashes[8], uint32_t *n_hashes);
@@ -191,6 +205,10 @@ int pfp_dist_local_parse(pfp_ctx *ctx, const void *d_text, uint64_t n, uint64_t 
 int pfp_dist_export_local(pfp_ctx *ctx, void *d_dict, void *d_occ, void *d_last, void *d_sai);
 int pfp_dist_global(pfp_ctx *ctx, const void *d_union, uint64_t union_bytes, const void *d_union_occ,
                     uint64_t n_union, uint64_t my_word_base, void *d_sym_out, uint64_t out_info[3]);
+int pfp_dist_global_sort(pfp_ctx *ctx, const void *d_union, uint64_t union_bytes, const void *d_union_occ,
+                         uint64_t n_union, uint32_t part, uint32_t parts, void *d_wslot_out, uint64_t out_info[8]);
+int pfp_dist_global_finish(pfp_ctx *ctx, const void *d_wslot_all, uint32_t parts, uint64_t my_word_base,
+                           void *d_sym_out);
 int pfp_dist_merge(pfp_ctx *ctx, const void *d_sym, uint64_t P, const void *d_last, const void *d_sai, int flags,
                    uint64_t n_total, uint64_t out_lo, uint64_t out_hi, void *d_bwt_slice, void *d_sa_slice);
 void pfp_dist_release(pfp_ctx *ctx);

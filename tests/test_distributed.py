@@ -81,14 +81,19 @@ def test_allgather_plumbing_gloo_world2():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R", [2, 3])
-def test_distributed_chain_matches_oracle(O, pkg, R):
+@pytest.mark.parametrize("shard_sa", [True, False], ids=["sa_by_key_range", "sa_replicated"])
+@pytest.mark.parametrize("R", [2, 3, 5])
+@pytest.mark.parametrize("nblock", [True, False], ids=["n_block", "no_n_block"])
+def test_distributed_chain_matches_oracle(O, pkg, R, shard_sa, nblock):
     """R virtual ranks on one GPU: text shards -> halo -> local parse -> union dictionary ->
-    replicated sorts -> output slices; concatenated slices must equal the oracle's files."""
+    suffix array of the dictionary (sharded by key range, or replicated) -> output slices;
+    concatenated slices must equal the oracle's files."""
     import importlib
     d = importlib.import_module("bigbwt_amd.dist")
     dev = torch.device("cuda:0")
-    text = O.gen_fasta(150000, 6, 0.002, 41, n_blocks=[(40000, 60000)])     # N block: giant phrase -> shared extra triggers
+    # N block: giant phrase -> shared extra triggers; its 2 kB all-N phrases are a long exact repeat inside
+    # the dictionary, which a key range may be unable to settle alone (-> replicated fallback)
+    text = O.gen_fasta(150000, 6, 0.002, 41, n_blocks=[(40000, 60000)] if nblock else [])
     n = len(text)
     cuts = [0] + [n * (r + 1) // R + (7 * r - 3) for r in range(R - 1)] + [n]     # uneven, unaligned shards
     ctxs = [pkg.Context(0) for _ in range(R)]
@@ -97,8 +102,11 @@ def test_distributed_chain_matches_oracle(O, pkg, R):
             shards = [torch.from_numpy(text[cuts[r]:cuts[r + 1]].copy()).to(dev) for r in range(R)]
             for c in ctxs:
                 c.set_max_phrase(2000)
-            res = d.simulate(ctxs, shards, 10, 100, flags, halo=4096)
-            assert res[0]["stats"]["extra_triggers"] >= 1
+            res = d.simulate(ctxs, shards, 10, 100, flags, halo=4096, shard_sa=shard_sa)
+            assert res[0]["stats"]["extra_triggers"] >= (1 if nblock else 0)
+            shares = {r["stats"]["sa_shares"] for r in res}
+            assert shares == ({R} if (shard_sa and not nblock) else ({1} if not shard_sa else shares & {1, R})) and len(shares) == 1
+            assert all(res[k]["hi"] == res[k + 1]["lo"] for k in range(R - 1))
             bwt = torch.cat([r["bwt"] for r in res]).cpu().numpy()
             want = O.bigbwt(text, 10, 100, flags)
             assert res[0]["lo"] == 0 and res[-1]["hi"] == n + 1
@@ -107,6 +115,29 @@ def test_distributed_chain_matches_oracle(O, pkg, R):
                 sa = torch.cat([r["sa"] for r in res]).cpu().numpy().astype(np.uint64)
                 assert sa[0] == n and np.array_equal(sa[1:], want["sa"])
             assert sum(r["stats"]["local"]["phrases"] for r in res) == res[0]["stats"]["phrases_total"]
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.gpu
+def test_sharded_sort_falls_back_when_a_range_cannot_finish(O, pkg, monkeypatch):
+    """a dictionary word with a long exact repeat (an N run cut into 20 kB phrases) leaves a group that
+    pivot rounds cannot settle inside one key range: all ranks fall back to the replicated sort"""
+    import importlib
+    d = importlib.import_module("bigbwt_amd.dist")
+    dev = torch.device("cuda:0")
+    text = O.gen_fasta(120000, 2, 0.001, 47, n_blocks=[(20000, 80000)])
+    n = len(text)
+    ctxs = [pkg.Context(0) for _ in range(2)]
+    try:
+        for c in ctxs:
+            c.set_max_phrase(0)          # no extra triggers: the N block stays one giant phrase
+        shards = [torch.from_numpy(text[: n // 2].copy()).to(dev), torch.from_numpy(text[n // 2:].copy()).to(dev)]
+        res = d.simulate(ctxs, shards, 10, 100, 0, halo=1 << 17)
+        bwt = torch.cat([r["bwt"] for r in res]).cpu().numpy()
+        assert np.array_equal(bwt, O.bigbwt(text, 10, 100, 0)["bwt"])
+        assert res[0]["stats"]["sa_shares"] in (1, 2)       # 1 when the fallback was taken
     finally:
         for c in ctxs:
             c.close()
