@@ -45,4 +45,18 @@ __device__ __forceinline__ uint32_t group8_or(uint32_t v) {
   return v;
 }
 
+// 16 flag bytes -> four words with bit 0 of every byte set where the flag is non-zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
+  x |= x >> 4; x |= x >> 2; x |= x >> 1;
+  return x & 0x01010101u;
+}
+__device__ __forceinline__ void load_flags16(const uint8_t *__restrict__ flags, uint64_t base, uint64_t n, uint32_t w[4]) {
+  if (base + 16 <= n) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(flags + base);
+    w[0] = nonzero_bytes(v.x); w[1] = nonzero_bytes(v.y); w[2] = nonzero_bytes(v.z); w[3] = nonzero_bytes(v.w);
+  } else {
+    w[0] = w[1] = w[2] = w[3] = 0;
+    for (int k = 0; k < 16; k++) if (base + k < n && flags[base + k]) w[k >> 2] |= 1u << (8 * (k & 3));
+  }
+}
 }  // namespace pfp

@@ -1,5 +1,6 @@
 // prims.hip -- rocPRIM instantiations (isolated in one translation unit: they compile slowly).
 #include "prims.hpp"
+#include "devutil.hpp"
 #include <rocprim/rocprim.hpp>
 
 namespace pfp {
@@ -76,19 +77,6 @@ void select_flagged_u32(pfp_ctx *c, const uint32_t *in, const uint8_t *flags, ui
 // ~95 G flags/s (2.8 ms for the 260 M hard-group flags of the 253 MB workload); the flags are bytes, so a
 // workgroup can count and place 4096 of them from 16-byte loads: two streaming passes over n bytes.
 constexpr int kSelTile = 4096;
-__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
-  x |= x >> 4; x |= x >> 2; x |= x >> 1;
-  return x & 0x01010101u;
-}
-__device__ __forceinline__ void load_flags16(const uint8_t *__restrict__ flags, uint64_t base, uint64_t n, uint32_t w[4]) {
-  if (base + 16 <= n) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(flags + base);
-    w[0] = nonzero_bytes(v.x); w[1] = nonzero_bytes(v.y); w[2] = nonzero_bytes(v.z); w[3] = nonzero_bytes(v.w);
-  } else {
-    w[0] = w[1] = w[2] = w[3] = 0;
-    for (int k = 0; k < 16; k++) if (base + k < n && flags[base + k]) w[k >> 2] |= 1u << (8 * (k & 3));
-  }
-}
 __global__ __launch_bounds__(256) void flag_count_kernel(const uint8_t *__restrict__ flags, uint64_t n, uint32_t *__restrict__ blocksum) {
   __shared__ uint32_t ws[4];
   const uint64_t base = (uint64_t)blockIdx.x * kSelTile + (uint64_t)threadIdx.x * 16;

@@ -141,6 +141,7 @@ __device__ __forceinline__ uint64_t packed_key_at(const uint8_t *__restrict__ s,
   uint32_t term = 0;
 #pragma unroll
   for (int j = 0; j < 32; j++) {
+    if ((j == 16 || j == 20 || j == 24 || j == 28) && !__any(pos > 0)) break;     // every active lane has filled its key
     if (pos > 0) {
       const uint32_t c = (w8[j >> 2] >> (8 * (j & 3))) & 0xff;
       const uint32_t e = lut[c];
@@ -293,6 +294,44 @@ __global__ void compact3_kernel(uint64_t m, const uint8_t *__restrict__ keep, co
   if (a >= m || !keep[a]) return;
   const uint32_t o = inc[a] - 1;
   aslot2[o] = aslot[a]; act_i[o] = val[a] & ~finbit; act_grp[o] = newhead[a];
+}
+
+// Compaction of the active list: kept suffixes and kept group heads counted per 256 list positions
+// from 16-byte loads of the flag bytes, tiny scans over those sums, then one thread per list position
+// places its (slot, suffix, group) triple (coalesced reads, consecutive writes).  Replaces an N-long
+// inclusive scan into a 4-byte array and its re-read.
+constexpr int kTile = 256;
+__global__ __launch_bounds__(256) void active_count_kernel(const uint8_t *__restrict__ keep, const uint8_t *__restrict__ hd,
+                                                           uint64_t m, uint32_t *__restrict__ tile_keep,
+                                                           uint32_t *__restrict__ tile_heads) {
+  // thread = 16 flags, 16 threads = one tile of 256
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t base = t * 16;
+  uint32_t k[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0};
+  if (base < m) { load_flags16(keep, base, m, k); load_flags16(hd, base, m, h); }
+  uint32_t ck = __popc(k[0]) + __popc(k[1]) + __popc(k[2]) + __popc(k[3]);
+  uint32_t ch = __popc(k[0] & h[0]) + __popc(k[1] & h[1]) + __popc(k[2] & h[2]) + __popc(k[3] & h[3]);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { ck += __shfl_down(ck, o, 16); ch += __shfl_down(ch, o, 16); }
+  if ((threadIdx.x & 15) == 0 && base < m) { tile_keep[t >> 4] = ck; tile_heads[t >> 4] = ch; }
+}
+__global__ __launch_bounds__(256) void active_place_kernel(const uint8_t *__restrict__ keep, uint64_t m,
+                                                           const uint32_t *__restrict__ tile_off,
+                                                           const uint32_t *__restrict__ aslot, const uint32_t *__restrict__ val,
+                                                           const uint32_t *__restrict__ newhead, uint32_t finbit,
+                                                           uint32_t *__restrict__ aslot2, uint32_t *__restrict__ act_i,
+                                                           uint32_t *__restrict__ act_grp) {
+  __shared__ uint32_t ws[4];
+  const uint64_t a = (uint64_t)blockIdx.x * kTile + threadIdx.x;
+  const bool k = a < m && keep[a];
+  const unsigned long long mask = __ballot(k);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) ws[wv] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  if (!k) return;
+  uint32_t pos = tile_off[blockIdx.x] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  for (int q = 0; q < wv; q++) pos += ws[q];
+  aslot2[pos] = aslot[a]; act_i[pos] = val[a] & ~finbit; act_grp[pos] = newhead[a];
 }
 
 // number of unresolved groups after a round (their heads stay unresolved with them).  A fixed grid
@@ -507,6 +546,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   bool pivot_ok = true;
   bool lazy_pending = false;    // dictionary mode: rank[] of the suffixes settled by the first round not scattered (yet)
   DBuf<uint8_t> veto, keep0;
+  DBuf<uint32_t> tile_keep, tile_heads, tile_off, tile_hoff;
   uint32_t piv_cap = kPivotCap;  // bytes compared per member in the next pivot round
   bool long_cap_tried = false;
   for (;;) {
@@ -548,16 +588,24 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
                          pivot_round ? kPivBits : nb, (have_prev && seg_round) ? act_grp.p : (const uint32_t *)nullptr,
                          pivot_round ? veto.p : (const uint8_t *)nullptr, out.sa.p, out.rank.p, out.grp.p, keep.p);
     }
-    inclusive_count_eq_u8(c, keep.p, 1, inc.p, m);
-    PFP_HIP(hipMemsetAsync(ngrp_d.p, 0, 4, c->stream));
-    { KScope ks(c, "pfp::compact3_kernel", m * 17);
-      hipLaunchKernelGGL(compact3_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keep.p, inc.p, aslot.p,
-                         valo.p, newhead.p, out.finbit, aslot2.p, act_i.p, act_grp.p); }
-    hipLaunchKernelGGL(count_groups_kernel, dim3((int)std::min<uint64_t>(cdiv64(m, 256), 2048)), dim3(256), 0, c->stream, m,
-                       keep.p, hd.p, ngrp_d.p);
-    PFP_HIP(hipGetLastError());
-    PFP_HIP(hipMemcpyAsync(c->h_scalars, inc.p + (m - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, ngrp_d.p, 4, hipMemcpyDeviceToHost, c->stream));
+    {
+      // kept suffixes / kept group heads per tile -> offsets -> placement
+      const uint64_t ntile = cdiv64(m, kTile);
+      if (!tile_keep.p) { tile_keep.alloc(c, cdiv64(N, kTile) + 1); tile_heads.alloc(c, cdiv64(N, kTile) + 1);
+                          tile_off.alloc(c, cdiv64(N, kTile) + 1); tile_hoff.alloc(c, cdiv64(N, kTile) + 1); }
+      PFP_HIP(hipMemsetAsync(tile_keep.p + ntile, 0, 4, c->stream));
+      PFP_HIP(hipMemsetAsync(tile_heads.p + ntile, 0, 4, c->stream));
+      KScope ks(c, "pfp::compact3_kernel", m * 2 + 0);
+      hipLaunchKernelGGL(active_count_kernel, dim3((unsigned)cdiv64(ntile, 16)), dim3(256), 0, c->stream, keep.p, hd.p, m,
+                         tile_keep.p, tile_heads.p);
+      exclusive_sum_u32(c, tile_keep.p, tile_off.p, ntile + 1);
+      exclusive_sum_u32(c, tile_heads.p, tile_hoff.p, ntile + 1);
+      hipLaunchKernelGGL(active_place_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, keep.p, m, tile_off.p, aslot.p,
+                         valo.p, newhead.p, out.finbit, aslot2.p, act_i.p, act_grp.p);
+      PFP_HIP(hipGetLastError());
+      PFP_HIP(hipMemcpyAsync(c->h_scalars, tile_off.p + ntile, 4, hipMemcpyDeviceToHost, c->stream));
+      PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, tile_hoff.p + ntile, 4, hipMemcpyDeviceToHost, c->stream));
+    }
     sync(c);
     uint32_t m2, ngrp;
     memcpy(&m2, c->h_scalars, 4); memcpy(&ngrp, c->h_scalars + 1, 4);
