@@ -109,7 +109,8 @@ void gather_slots_range(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos
 void materialize_ranks(pfp_ctx *c, SuffixOrder &so, const uint64_t *d_positions, uint64_t count);
 void materialize_all_ranks(pfp_ctx *c, SuffixOrder &so);
 // plain suffix array of an integer string with unique smallest last symbol (sacak_int)
-void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out);
+// max_sym: largest symbol value (spare key bits then describe runs of equal symbols)
+void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym = 0xFFFFFFFFu);
 // plain suffix array of a byte string with s[N-1]==0 unique smallest (sacak)
 void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrder &out);
 

@@ -157,7 +157,7 @@ void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t 
   PFP_HIP(hipMemcpyAsync(sym.p, parse_sym, P * 4, hipMemcpyDeviceToDevice, c->stream));
   PFP_HIP(hipMemsetAsync(sym.p + P, 0, 4, c->stream));
   SuffixOrder so;
-  sort_int_suffixes(c, sym.p, P + 1, so);
+  sort_int_suffixes(c, sym.p, P + 1, so, d);      // symbols are 1-based word ranks <= d
   if (c->debug) validate_int_sa(c, sym.p, so);
   out.rounds = so.rounds;
   out.ilist.alloc(c, P + 1);

@@ -405,7 +405,7 @@ int pfp_sacak_int(pfp_ctx *c, const uint32_t *s, uint32_t *SA, uint64_t n, uint6
   DBuf<uint32_t> ds(c, n);
   h2d(c, ds.p, s, n);
   SuffixOrder so;
-  sort_int_suffixes(c, ds.p, n, so);
+  sort_int_suffixes(c, ds.p, n, so, k ? (uint32_t)std::min<uint64_t>(k - 1, 0xFFFFFFFFull) : 0xFFFFFFFFu);      // symbols < k (k = 0: not stated)
   d2h(c, SA, so.sa.p, n);
   sync(c);
   return PFP_OK;
