@@ -239,6 +239,50 @@ __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const uint
   }
 }
 
+// The same per-slot outputs when the records travelled in the top 16 bits of the first-round keys
+// (SuffixOrder::paybits): a streaming read of skeys; only slots that later rounds re-ordered
+// (refined[t]) fetch their record, and a count code of 255 its word's count.
+__global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const uint32_t *__restrict__ sa,
+                                                           const uint64_t *__restrict__ skeys,
+                                                           const uint8_t *__restrict__ refined, const uint8_t *__restrict__ b,
+                                                           const uint32_t *__restrict__ pos_word,
+                                                           const uint32_t *__restrict__ endpos,
+                                                           const uint32_t *__restrict__ wocc, uint32_t d, int w,
+                                                           uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc) {
+  uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (t0 >= N) return;
+  uint32_t c8[8], p8[8];
+  const int nk = (N - t0) >= 8 ? 8 : (int)(N - t0);
+  uint64_t rf = 0;
+  if (refined) rf = nk == 8 ? *reinterpret_cast<const uint64_t *>(refined + t0) : ~0ull;      // tail: take the slow path
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    uint32_t rec = 0;
+    if (k < nk) {
+      rec = (uint32_t)(skeys[t0 + k] >> 48);
+      if ((rf >> (8 * k)) & 0xffu) {
+        const uint32_t i = sa[t0 + k], wd = pos_word[i];
+        rec = 0;
+        if (wd < d && (endpos[i] - i) > (uint32_t)w) {
+          const uint32_t occ = wocc[wd];
+          rec = (i == 0 ? (uint32_t)kEndOfWord : (uint32_t)b[i - 1]) | ((occ < 255u ? occ : 255u) << 8);
+        }
+      }
+    }
+    p8[k] = rec & 0xffu; c8[k] = rec >> 8;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) if (c8[k] == 255u) c8[k] = wocc[pos_word[sa[t0 + k]]];
+  if (nk == 8) {
+    *reinterpret_cast<uint4 *>(cnt + t0) = make_uint4(c8[0], c8[1], c8[2], c8[3]);
+    *reinterpret_cast<uint4 *>(cnt + t0 + 4) = make_uint4(c8[4], c8[5], c8[6], c8[7]);
+    *reinterpret_cast<uint2 *>(pc + t0) = make_uint2(p8[0] | (p8[1] << 8) | (p8[2] << 16) | (p8[3] << 24),
+                                                     p8[4] | (p8[5] << 8) | (p8[6] << 16) | (p8[7] << 24));
+  } else {
+    for (int k = 0; k < nk; k++) { cnt[t0 + k] = c8[k]; pc[t0 + k] = (uint8_t)p8[k]; }
+  }
+}
+
 // a group is "hard" when its members disagree on the preceding char (pfbwt.cpp:524-536), or, with
 // SA output, whenever it has more than one member (pfbwt.cpp:568, 612)
 __global__ void group_flags_kernel(uint64_t N, const uint32_t *__restrict__ grp, const uint8_t *__restrict__ pc,
@@ -565,11 +609,19 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   DBuf<uint16_t> pp16;
   DBuf<uint64_t> pp64;
   DBuf<uint32_t> cnt(c, N + 8), ist;
-  if (flags) { ist.alloc(c, N + 8); pp64.alloc(c, NP); } else pp16.alloc(c, NP);
+  // records already sit at their slots - unless most slots were re-ordered after the first round (a
+  // dictionary of near-identical variants), where fetching each such record costs more than the gather
+  const bool from_keys = !flags && so.paybits == 16 && so.skeys.p && so.n_refined * 5 < N;
+  if (flags) { ist.alloc(c, N + 8); pp64.alloc(c, NP); } else if (!from_keys) pp16.alloc(c, NP);
   DBuf<uint8_t> pc(c, N + 8), hard(c, N);
   DBuf<uint64_t> off(c, N + 1);
   PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream));
   hard.zero();
+  if (from_keys) {
+    KScope ks(c, "pfp::slot_gather_kernel", N * (8 + 1 + 5));
+    hipLaunchKernelGGL(slot_payload_kernel, dim3(cdiv(cdiv64(N, 8), 256)), dim3(256), 0, c->stream, N, so.sa.p, so.skeys.p,
+                       so.refined.p, D.bytes.p, ix.pos_word.p, ix.endpos.p, D.wocc.p, d, w, cnt.p, pc.p);
+  } else {
   { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + (flags ? 8 : 2)));
     if (flags) hipLaunchKernelGGL(pprec_kernel<uint64_t>, dim3(cdiv(NP, TB)), dim3(TB), 0, c->stream, D.bytes.p, NP, d, w,
                                   ix.pos_word.p, ix.endpos.p, D.wocc.p, pp64.p);
@@ -581,6 +633,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
                                   ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, ist.p);
     else hipLaunchKernelGGL(slot_gather_kernel<uint16_t>, grid, dim3(256), 0, c->stream, N, so.sa.p, pp16.p,
                             ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, (uint32_t *)nullptr); }
+  }
   exclusive_sum_u32_u64(c, cnt.p, off.p, N + 1);
   { KScope ks(c, "pfp::group_flags_kernel", N * 5);
   hipLaunchKernelGGL(group_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.grp.p, pc.p, flags ? 1 : 0, hard.p); }

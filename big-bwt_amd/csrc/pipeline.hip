@@ -120,7 +120,9 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
   }
   {
     PhaseTimer t(c, &st.ms_sa_dict);
-    sort_dict_suffixes(c, ch.D.bytes.p, ch.D.dsize, ch.ix.endpos.p, ch.so);
+    // BWT only: the merge records ride in the spare bits of the first-round keys (SuffixOrder::paybits)
+    const SlotPayloadSrc pay{ch.ix.pos_word.p, ch.ix.endpos.p, ch.D.wocc.p, (uint32_t)ch.D.d, w};
+    sort_dict_suffixes(c, ch.D.bytes.p, ch.D.dsize, ch.ix.endpos.p, ch.so, want_sai ? nullptr : &pay);
     if (c->debug) validate_suffix_order(c, ch.D.bytes.p, ch.so, true, "dict SA");
     compute_lexrank(c, ch.D, ch.so, ch.ix);
     if (c->debug) validate_lexrank(c, ch.D, ch.ix);
@@ -527,7 +529,8 @@ int pfp_merge(pfp_ctx *c, const uint8_t *dict, uint64_t dict_size, const uint32_
   D.wocc.alloc(c, D.d);
   h2d(c, D.wocc.p, occ, D.d);
   if (c->debug) validate_index(c, D, ix);
-  sort_dict_suffixes(c, D.bytes.p, D.dsize, ix.endpos.p, so);
+  const SlotPayloadSrc pay{ix.pos_word.p, ix.endpos.p, D.wocc.p, (uint32_t)D.d, w};
+  sort_dict_suffixes(c, D.bytes.p, D.dsize, ix.endpos.p, so, flags ? nullptr : &pay);
   if (c->debug) validate_suffix_order(c, D.bytes.p, so, true, "dict SA");
   compute_lexrank(c, D, so, ix);
   if (c->debug) validate_lexrank(c, D, ix);
@@ -617,6 +620,7 @@ struct DistState {
   SuffixOrder so;
   DBuf<uint32_t> occ_lex;
   uint64_t local_total = 0;     // BWT positions the held slots emit
+  bool want_sai = false;
 };
 static DistState *dist_of(pfp_ctx *c) {
   if (!c->dist) c->dist = new DistState();
@@ -697,6 +701,7 @@ int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t ha
   ds->P_local = kend - ds->k0;
   // T' index x of the local text is global text position global_offset - halo_len + x - 1; sai = end position + 1
   const uint64_t sai_base = global_offset - halo_len;
+  ds->want_sai = want_sai != 0;
   build_dictionary_shard(c, ds->tx, n, w, ds->ends, ds->n_ends, ds->k0, ds->P_local, want_sai != 0, sai_base, ds->L);
   out_sizes[0] = ds->L.dsize - 1;      // local dictionary bytes without the final 0x00
   out_sizes[1] = ds->L.d;
@@ -746,15 +751,17 @@ int pfp_dist_global_sort(pfp_ctx *c, const void *d_union, uint64_t union_bytes, 
   build_dictionary_words(c, U.bytes.p, U.woff.p, U.wlen.p, n_union, (const uint32_t *)d_union_occ, union_bytes, ds->G);
   build_dict_index(c, ds->G, ds->ix);
   const uint32_t d = (uint32_t)ds->G.d;
+  const SlotPayloadSrc pay{ds->ix.pos_word.p, ds->ix.endpos.p, ds->G.wocc.p, d, ds->w};
+  const SlotPayloadSrc *payp = ds->want_sai ? nullptr : &pay;      // no sa info was parsed: the merge will be BWT only
   if (parts == 1) {
-    sort_dict_suffixes(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, ds->so);
+    sort_dict_suffixes(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, ds->so, payp);
     if (c->debug) validate_suffix_order(c, ds->G.bytes.p, ds->so, true, "global dict SA");
     DBuf<uint32_t> slots(c, d);
     gather_ranks(c, ds->so, ds->G.woff.p, d, slots.p);
     hipLaunchKernelGGL(add_one_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, slots.p, (uint32_t *)d_wslot_out);
     ds->local_total = 0;
   } else {
-    sort_dict_suffixes_range(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, part, parts, ds->so);
+    sort_dict_suffixes_range(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, part, parts, ds->so, payp);
     gather_slots_range(c, ds->so, ds->G.woff.p, d, (uint32_t *)d_wslot_out);
     ds->local_total = ds->so.complete ? count_slot_outputs(c, ds->G, ds->ix, ds->so, ds->w) : 0;
   }

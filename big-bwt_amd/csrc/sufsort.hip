@@ -179,19 +179,31 @@ __device__ __forceinline__ uint32_t rank_at(const RankView &L, uint64_t j, bool 
   uint32_t hi = (b + 1 < L.T) ? 0xFFFFFFFFu - L.tab[L.T - 2 - b] : (uint32_t)L.N;
   while (lo < hi) {
     const uint32_t mid = lo + ((hi - lo) >> 1);
-    if (L.skeys[mid] < k) lo = mid + 1; else hi = mid;
+    if ((L.skeys[mid] & L.keymask) < k) lo = mid + 1; else hi = mid;
   }
   return lo;
 }
 
+// merge record of position i: low byte = preceding char (1 = whole word, pfbwt.cpp:153; 0 = emits
+// nothing, <= w long, pfbwt.cpp:151), high byte = occurrences of its word, 255 = "255 or more"
+__device__ __forceinline__ uint32_t slot_record(const uint8_t *__restrict__ b, uint64_t i, const SlotPayloadSrc &P) {
+  const uint32_t wd = P.pos_word[i];
+  if (!(wd < P.d && (P.endpos[i] - (uint32_t)i) > (uint32_t)P.w)) return 0u;
+  const uint32_t pc = (i == 0) ? kEndOfWord : b[i - 1];
+  const uint32_t occ = P.wocc[wd];
+  return pc | ((occ < 255u ? occ : 255u) << 8);
+}
 __global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
-                                                               uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+                                                               SlotPayloadSrc P, int paybits, uint64_t *__restrict__ key,
+                                                               uint32_t *__restrict__ val) {
   __shared__ uint32_t lut[256];
   lut[threadIdx.x] = kp.lut[threadIdx.x];
   __syncthreads();
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  key[i] = packed_key_at(s, i, kp.kbits, lut); val[i] = (uint32_t)i;
+  uint64_t k = packed_key_at(s, i, kp.kbits, lut);
+  if (paybits) k |= (uint64_t)slot_record(s, i, P) << 48;
+  key[i] = k; val[i] = (uint32_t)i;
 }
 
 __global__ void init_keys_bytes_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
@@ -393,11 +405,11 @@ __global__ void heads_kernel(uint64_t m, const uint64_t *__restrict__ key, const
 
 // First round of dictionary mode (slot == index): group heads, and the bucket table of the sorted
 // keys for rank_at: the first slot of every occupied top-bits bucket marks its reversed entry.
-__global__ void heads0_kernel(uint64_t m, const uint64_t *__restrict__ key, int shift, uint32_t T,
+__global__ void heads0_kernel(uint64_t m, const uint64_t *__restrict__ key, uint64_t keymask, int shift, uint32_t T,
                               uint8_t *__restrict__ hd, uint32_t *__restrict__ hv, uint32_t *__restrict__ tab) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
-  const uint64_t k = key[a], kprev = a ? key[a - 1] : ~k;
+  const uint64_t k = key[a] & keymask, kprev = a ? (key[a - 1] & keymask) : ~k;
   const bool h = k != kprev;
   hd[a] = h ? 1 : 0;
   hv[a] = h ? (uint32_t)a : 0u;
@@ -535,7 +547,7 @@ static const uint32_t kPivotCap = []() { const char *e = getenv("PFP_PIVOT_CAP")
 static const uint64_t kLazyRatio = []() { const char *e = getenv("PFP_LAZY_RATIO"); return e ? (uint64_t)atoll(e) : 8ull; }();
 
 RankView rank_view(const SuffixOrder &so) {
-  return RankView{so.rank.p, so.skeys.p, so.tab.p, so.lut.p, so.bytes, so.N, so.kbits, so.shift, so.T, so.finbit};
+  return RankView{so.rank.p, so.skeys.p, so.tab.p, so.lut.p, so.bytes, so.N, so.kbits, so.shift, so.T, so.finbit, so.keymask};
 }
 
 static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> &val, uint64_t h0, SuffixOrder &out,
@@ -586,8 +598,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   for (;;) {
     if (first && lazy) {
       { KScope ks(c, "pfp::heads_kernel", m * 13);
-        hipLaunchKernelGGL(heads0_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, out.shift, out.T, hd.p, hv.p,
-                           out.tab.p); }
+        hipLaunchKernelGGL(heads0_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, out.keymask, out.shift, out.T,
+                           hd.p, hv.p, out.tab.p); }
       inclusive_max_u32(c, out.tab.p, out.tab.p, out.T);
     } else if (seg_round) {
       KScope ks(c, "pfp::heads_kernel", m * 14);
@@ -649,6 +661,12 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       lazy_pending = true;
       keep0.alloc(c, N);
       PFP_HIP(hipMemcpyAsync(keep0.p, keep.p, N, hipMemcpyDeviceToDevice, c->stream));
+      out.n_refined = m2;
+      if (out.paybits) {       // the merge wants to know which slots were re-ordered after this round
+        out.refined.alloc(c, N + 16);
+        PFP_HIP(hipMemcpyAsync(out.refined.p, keep.p, N, hipMemcpyDeviceToDevice, c->stream));
+        PFP_HIP(hipMemsetAsync(out.refined.p + N, 0, 16, c->stream));
+      }
     }
 
     static const bool trace_rounds = getenv("PFP_TRACE_ROUNDS") != nullptr;
@@ -693,7 +711,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
         KScope ks(c, "pfp::write_back_kernel", N * (4 + 4 + 1 + 4));
         hipLaunchKernelGGL(scatter_settled_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, out.sa.p, out.grp.p, keep0.p,
                            out.finbit, out.rank.p);
-        out.skeys.release();
+        if (!out.paybits) out.skeys.release();      // with payload the merge still reads the records from skeys
         out.tab.release();
       }
       keep0.release();
@@ -767,14 +785,19 @@ static KeyCode dict_key_code(pfp_ctx *c, const uint8_t *bytes, uint64_t N) {
   return make_key_code(hh.data());
 }
 
-void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out) {
+void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out,
+                        const SlotPayloadSrc *pay) {
   PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
   SufGeom g{MODE_DICT, N, endpos};
   const KeyCode kc = dict_key_code(c, bytes, N);
   DBuf<uint64_t> key(c, N);
   DBuf<uint32_t> val(c, N);
-  { KScope ks(c, "pfp::init_keys_packed_kernel", N * 13);
-    hipLaunchKernelGGL(init_keys_packed_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kc, key.p, val.p); }
+  static const bool no_payload = getenv("PFP_NO_PAYLOAD") != nullptr;
+  out.paybits = (pay && !no_payload && kc.kbits + 1 <= 48) ? 16 : 0;
+  out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
+  { KScope ks(c, "pfp::init_keys_packed_kernel", N * (13 + (out.paybits ? 9 : 0)));
+    hipLaunchKernelGGL(init_keys_packed_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kc,
+                       pay ? *pay : SlotPayloadSrc{}, out.paybits, key.p, val.p); }
   out.lut.alloc(c, 256);
   PFP_HIP(hipMemcpyAsync(out.lut.p, kc.lut, 1024, hipMemcpyHostToDevice, c->stream));
   sync(c);      // kc is a stack object
@@ -814,19 +837,21 @@ __global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restr
   if (threadIdx.x == 0) { const unsigned long long t = wsum[0] + wsum[1] + wsum[2] + wsum[3]; if (t) atomicAdd(below, t); }
 }
 __global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__restrict__ s, uint64_t n, KeyCode kp,
-                                                             const uint32_t *__restrict__ idx, uint64_t *__restrict__ key,
-                                                             uint32_t *__restrict__ val) {
+                                                             SlotPayloadSrc P, int paybits, const uint32_t *__restrict__ idx,
+                                                             uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
   __shared__ uint32_t lut[256];
   lut[threadIdx.x] = kp.lut[threadIdx.x];
   __syncthreads();
   uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (a >= n) return;
   const uint32_t i = idx[a];
-  key[a] = packed_key_at(s, i, kp.kbits, lut); val[a] = i;
+  uint64_t k = packed_key_at(s, i, kp.kbits, lut);
+  if (paybits) k |= (uint64_t)slot_record(s, i, P) << 48;
+  key[a] = k; val[a] = i;
 }
 
 void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, uint32_t part,
-                              uint32_t parts, SuffixOrder &out) {
+                              uint32_t parts, SuffixOrder &out, const SlotPayloadSrc *pay) {
   PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
   PFP_REQUIRE(parts >= 1 && part < parts, PFP_EINVAL, "bad key-range share");
   SufGeom g{MODE_DICT, N, endpos};
@@ -863,10 +888,13 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   flag.release();
   DBuf<uint64_t> key(c, std::max<uint64_t>(n_mine, 1));
   DBuf<uint32_t> val(c, std::max<uint64_t>(n_mine, 1));
+  static const bool no_payload = getenv("PFP_NO_PAYLOAD") != nullptr;
+  out.paybits = (pay && !no_payload && kc.kbits + 1 <= 48) ? 16 : 0;
+  out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
   if (n_mine) {
     KScope ks(c, "pfp::init_keys_packed_kernel", (uint64_t)n_mine * 17);
-    hipLaunchKernelGGL(init_keys_list_kernel, dim3(cdiv(n_mine, 256)), dim3(256), 0, c->stream, bytes, (uint64_t)n_mine, kc, idx.p,
-                       key.p, val.p);
+    hipLaunchKernelGGL(init_keys_list_kernel, dim3(cdiv(n_mine, 256)), dim3(256), 0, c->stream, bytes, (uint64_t)n_mine, kc,
+                       pay ? *pay : SlotPayloadSrc{}, out.paybits, idx.p, key.p, val.p);
   }
   idx.release();
   out.lut.alloc(c, 256);
