@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void active_place_kernel(const uint8_t *__rest
   if (!k) return;
   uint32_t pos = tile_off[blockIdx.x] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
   for (int q = 0; q < wv; q++) pos += ws[q];
-  aslot2[pos] = aslot[a]; act_i[pos] = val[a] & ~finbit; act_grp[pos] = newhead[a];
+  aslot2[pos] = aslot ? aslot[a] : (uint32_t)a; act_i[pos] = val[a] & ~finbit; act_grp[pos] = newhead[a];      // no list yet: slot == index
 }
 
 // number of unresolved groups after a round (their heads stay unresolved with them).  A fixed grid
@@ -566,7 +566,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   DBuf<uint32_t> valo(c, N), aslot(c, N), aslot2(c, N), hv(c, N), newhead(c, N), inc(c, N), act_i(c, N), act_grp(c, N);
   DBuf<uint8_t> hd(c, N + 1), keep(c, N);
   sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, N, 0, key0_bits);
-  hipLaunchKernelGGL(iota32_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, aslot.p, N);
+  if (!dict_keys) hipLaunchKernelGGL(iota32_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, aslot.p, N);
   uint64_t m = N, h = h0;
   out.rounds = 0;
   bool first = true;
@@ -646,8 +646,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
                          tile_keep.p, tile_heads.p);
       exclusive_sum_u32(c, tile_keep.p, tile_off.p, ntile + 1);
       exclusive_sum_u32(c, tile_heads.p, tile_hoff.p, ntile + 1);
-      hipLaunchKernelGGL(active_place_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, keep.p, m, tile_off.p, aslot.p,
-                         valo.p, newhead.p, out.finbit, aslot2.p, act_i.p, act_grp.p);
+      hipLaunchKernelGGL(active_place_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, keep.p, m, tile_off.p,
+                         round0 ? (const uint32_t *)nullptr : aslot.p, valo.p, newhead.p, out.finbit, aslot2.p, act_i.p, act_grp.p);
       PFP_HIP(hipGetLastError());
       PFP_HIP(hipMemcpyAsync(c->h_scalars, tile_off.p + ntile, 4, hipMemcpyDeviceToHost, c->stream));
       PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, tile_hoff.p + ntile, 4, hipMemcpyDeviceToHost, c->stream));

@@ -13,7 +13,9 @@ def bench_name(n):
     if m and 'rocprim' not in n[:40]:
         k = m.group(1)
         k = {'heads0_kernel': 'heads_kernel', 'heads32_kernel': 'heads_kernel', 'write_back0_kernel': 'write_back_kernel',
-             'scatter_settled_kernel': 'write_back_kernel', 'build_keys32_kernel': 'build_keys_kernel'}.get(k, k)
+             'scatter_settled_kernel': 'write_back_kernel', 'build_keys32_kernel': 'build_keys_kernel',
+             'slot_payload_kernel': 'slot_gather_kernel', 'active_place_kernel': 'compact3_kernel', 'active_count_kernel': 'compact3_kernel',
+             'flag_place_kernel': 'select_flags_kernel', 'flag_count_kernel': 'select_flags_kernel'}.get(k, k)
         return 'pfp::' + k
     if 'onesweep' in n or 'radix_sort' in n or 'block_sort' in n:
         return 'rocprim::radix_sort_pairs<u64,u32>' if re.search(r'unsigned long, unsigned int|unsigned long,unsigned int', n) else 'rocprim::radix_sort_pairs<u32,u32>'
