@@ -68,6 +68,7 @@ struct SuffixOrder {
   uint64_t N = 0;        // slots held here: all NP suffixes, or (key-range sharded sort) one contiguous range of SA(D)
   uint64_t NP = 0;       // positions of the sorted string
   uint64_t slot_base = 0;        // range mode: SA(D) slot of local slot 0
+  uint64_t range_emits = 0;      // range mode: BWT positions the range emits (when a count source was given)
   uint64_t klo = 0, khi = ~0ull; // range mode: first-round keys in [klo, khi) (khi == ~0: no upper bound)
   bool range = false, complete = true;   // range mode stops (complete = false) where it would need other ranks' ranks
   DBuf<uint32_t> sa;     // [N] suffix start positions in sorted order (ties: position order)
@@ -112,7 +113,8 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
 // groups never straddle shares, and pivot rounds compare strings, not ranks, so a share is finished
 // without its neighbours.  out.complete == false: a group was left that only doubling could settle.
 void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, uint32_t part,
-                              uint32_t parts, SuffixOrder &out, const SlotPayloadSrc *pay = nullptr);
+                              uint32_t parts, SuffixOrder &out, const SlotPayloadSrc *pay = nullptr,
+                              const SlotPayloadSrc *count = nullptr);
 // range mode: out[j] = 1 + SA(D) slot of the suffix starting at pos[j] if it belongs to this share, else 0
 void gather_slots_range(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint64_t count, uint32_t *d_out);
 // rank[] is written sparsely by the sorter; fill it for given positions (device array) / everywhere
@@ -131,7 +133,9 @@ struct DictIndex {        // per-position / per-word helper arrays over the dict
   DBuf<uint32_t> wend;       // [d+1] terminator position of word j (wend[d] = dsize-1)
   DBuf<uint32_t> lexrank;    // [d] 0-based lexicographic rank of word j
 };
-void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix);
+void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix);      // needs D.woff / D.wlen
+// D.bytes/D.dsize given (words + 0x01, final 0x00): fills D.d, D.woff, D.wlen; at most max_words words expected
+void word_table_from_bytes(pfp_ctx *c, Dictionary &D, uint64_t max_words);
 void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrder &so, DictIndex &ix);
 void compute_lexrank_from_slots(pfp_ctx *c, const Dictionary &D, const uint32_t *d_wslot_all, uint32_t parts, DictIndex &ix);
 uint64_t count_slot_outputs(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, int w);

@@ -23,32 +23,58 @@ static constexpr int TB = 256;
 
 // ------------------------------------------------------------------ dictionary index
 
-__global__ void pos_word_kernel(const uint8_t *__restrict__ b, uint64_t N, const uint32_t *__restrict__ inc,
-                                uint32_t *__restrict__ pos_word, uint32_t *__restrict__ wend, uint32_t d) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  bool term = b[i] == kEndOfWord;
-  uint32_t wd = inc[i] - (term ? 1u : 0u);
-  pos_word[i] = wd;
-  if (term) wend[wd] = (uint32_t)i;
-  if (i == N - 1) wend[d] = (uint32_t)i;
-}
-__global__ void endpos_kernel(uint64_t N, const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ wend,
-                              uint32_t *__restrict__ endpos) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) endpos[i] = wend[pos_word[i]];
+// Per-position word id and terminator position, written from the word table (8 lanes per word): the
+// dictionary is laid out from known word offsets and lengths, nothing has to be counted back out of
+// its bytes (an N-long scan and two N-long passes before).
+__global__ __launch_bounds__(256) void dict_index_fill_kernel(uint32_t d, const uint64_t *__restrict__ woff,
+                                                              const uint32_t *__restrict__ wlen, uint64_t dsize,
+                                                              uint32_t *__restrict__ pos_word, uint32_t *__restrict__ endpos,
+                                                              uint32_t *__restrict__ wend) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t j = t >> 3;
+  const uint32_t l8 = (uint32_t)(t & 7);
+  if (j > d) return;
+  if (j == d) {      // the final 0x00 is its own word
+    if (l8 == 0) { pos_word[dsize - 1] = d; endpos[dsize - 1] = (uint32_t)(dsize - 1); wend[d] = (uint32_t)(dsize - 1); }
+    return;
+  }
+  const uint64_t s0 = woff[j], e = s0 + wlen[j];     // e: the word's 0x01
+  if (l8 == 0) wend[j] = (uint32_t)e;
+  for (uint64_t i = s0 + l8; i <= e; i += 8) { pos_word[i] = (uint32_t)j; endpos[i] = (uint32_t)e; }
 }
 
 void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix) {
   const uint64_t N = D.dsize;
+  PFP_REQUIRE(D.woff.p && D.wlen.p, PFP_EINVAL, "dictionary without a word table");
   ix.pos_word.alloc(c, N);
   ix.endpos.alloc(c, N);
   ix.wend.alloc(c, D.d + 1);
-  DBuf<uint32_t> inc(c, N);
-  inclusive_count_eq_u8(c, D.bytes.p, kEndOfWord, inc.p, N);
-  hipLaunchKernelGGL(pos_word_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, D.bytes.p, N, inc.p, ix.pos_word.p,
-                     ix.wend.p, (uint32_t)D.d);
-  hipLaunchKernelGGL(endpos_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, ix.pos_word.p, ix.wend.p, ix.endpos.p);
+  KScope ks(c, "pfp::dict_index_fill_kernel", N * 8);
+  hipLaunchKernelGGL(dict_index_fill_kernel, dim3(cdiv(((uint64_t)D.d + 1) * 8, TB)), dim3(TB), 0, c->stream, (uint32_t)D.d,
+                     D.woff.p, D.wlen.p, N, ix.pos_word.p, ix.endpos.p, ix.wend.p);
+  PFP_HIP(hipGetLastError());
+}
+
+// word table of a dictionary given as bytes (words + 0x01, closed by 0x00): terminator positions by
+// compaction of the 0x01 bytes, then starts and lengths
+__global__ void words_from_ends_kernel(uint32_t d, const uint32_t *__restrict__ ends, uint64_t dsize, uint64_t *__restrict__ woff,
+                                       uint32_t *__restrict__ wlen) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) woff[d] = dsize - 1;
+  if (j >= d) return;
+  const uint64_t s0 = j ? (uint64_t)ends[j - 1] + 1 : 0;
+  woff[j] = s0;
+  wlen[j] = (uint32_t)(ends[j] - s0);
+}
+void word_table_from_bytes(pfp_ctx *c, Dictionary &D, uint64_t max_words) {
+  DBuf<uint32_t> ends(c, max_words + 1), cnt(c, 1);
+  select_byte_index_u32(c, D.bytes.p, kEndOfWord, ends.p, cnt.p, D.dsize);
+  D.d = read_scalar(c, cnt.p);
+  PFP_REQUIRE(D.d <= max_words, PFP_EFORMAT, "more words in the dictionary bytes than announced");
+  D.woff.alloc(c, D.d + 1); D.wlen.alloc(c, std::max<uint64_t>(D.d, 1));
+  if (D.d)
+    hipLaunchKernelGGL(words_from_ends_kernel, dim3(cdiv(D.d, TB)), dim3(TB), 0, c->stream, (uint32_t)D.d, ends.p, D.dsize, D.woff.p,
+                       D.wlen.p);
   PFP_HIP(hipGetLastError());
 }
 

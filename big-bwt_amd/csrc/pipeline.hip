@@ -439,14 +439,8 @@ static void dictionary_from_host(pfp_ctx *c, const uint8_t *s, uint64_t n, Dicti
   D.bytes.alloc(c, n + 64);
   h2d(c, D.bytes.p, s, n);
   PFP_HIP(hipMemsetAsync(D.bytes.p + n, 0, 64, c->stream));
-  DBuf<uint32_t> inc(c, n);
-  inclusive_count_eq_u8(c, D.bytes.p, kEndOfWord, inc.p, n);
-  D.d = read_scalar(c, inc.p + (n - 1));
+  word_table_from_bytes(c, D, n);
   build_dict_index(c, D, ix);
-  D.woff.alloc(c, D.d + 1); D.wlen.alloc(c, D.d);
-  hipLaunchKernelGGL(words_from_wend_kernel, dim3(cdiv(D.d, TB)), dim3(TB), 0, c->stream, (uint32_t)D.d, ix.wend.p,
-                     D.woff.p, D.wlen.p);
-  PFP_HIP(hipGetLastError());
 }
 
 int pfp_gsacak(pfp_ctx *c, const uint8_t *s, uint32_t *SA, uint64_t n) {
@@ -736,15 +730,13 @@ int pfp_dist_global_sort(pfp_ctx *c, const void *d_union, uint64_t union_bytes, 
   DistState *ds = dist_of(c);
   PFP_REQUIRE(n_union >= 1, PFP_EINVAL, "empty union");
   // the union is itself a (not sorted, not duplicate-free) dictionary: words + 0x01, closed by one 0x00
-  Dictionary U; DictIndex uix;
-  U.dsize = union_bytes + 1; U.d = n_union;
+  Dictionary U;
+  U.dsize = union_bytes + 1;
   U.bytes.alloc(c, U.dsize + 64);
   PFP_HIP(hipMemcpyAsync(U.bytes.p, d_union, union_bytes, hipMemcpyDeviceToDevice, c->stream));
   PFP_HIP(hipMemsetAsync(U.bytes.p + union_bytes, 0, 65, c->stream));
-  build_dict_index(c, U, uix);
-  U.woff.alloc(c, n_union + 1); U.wlen.alloc(c, n_union);
-  hipLaunchKernelGGL(words_from_wend_kernel, dim3(cdiv(n_union, TB)), dim3(TB), 0, c->stream, (uint32_t)n_union, uix.wend.p,
-                     U.woff.p, U.wlen.p);
+  word_table_from_bytes(c, U, n_union);           // only the word boundaries of the union are needed
+  PFP_REQUIRE(U.d == n_union, PFP_EFORMAT, "the union holds a different number of words than occ entries");
   ds->G = Dictionary();
   ds->ix = DictIndex();
   ds->so = SuffixOrder();
@@ -761,9 +753,12 @@ int pfp_dist_global_sort(pfp_ctx *c, const void *d_union, uint64_t union_bytes, 
     hipLaunchKernelGGL(add_one_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, slots.p, (uint32_t *)d_wslot_out);
     ds->local_total = 0;
   } else {
-    sort_dict_suffixes_range(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, part, parts, ds->so, payp);
+    sort_dict_suffixes_range(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, part, parts, ds->so, payp, &pay);
     gather_slots_range(c, ds->so, ds->G.woff.p, d, (uint32_t *)d_wslot_out);
-    ds->local_total = ds->so.complete ? count_slot_outputs(c, ds->G, ds->ix, ds->so, ds->w) : 0;
+    ds->local_total = ds->so.complete ? ds->so.range_emits : 0;
+    if (c->debug && ds->so.complete)
+      PFP_REQUIRE(count_slot_outputs(c, ds->G, ds->ix, ds->so, ds->w) == ds->local_total, PFP_EHIP,
+                  "emit count by position differs from the count by slot");
   }
   PFP_HIP(hipGetLastError());
   sync(c);

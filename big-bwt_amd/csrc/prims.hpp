@@ -26,4 +26,5 @@ void inclusive_count_eq_u8(pfp_ctx *c, const uint8_t *bytes, uint8_t value, uint
 void select_flagged_u32(pfp_ctx *c, const uint32_t *in, const uint8_t *flags, uint32_t *out, uint32_t *d_count, size_t n);
 // out = i for flags[i]!=0
 void select_index_u32(pfp_ctx *c, const uint8_t *flags, uint32_t *out, uint32_t *d_count, size_t n);
+void select_byte_index_u32(pfp_ctx *c, const uint8_t *bytes, uint8_t value, uint32_t *out, uint32_t *d_count, size_t n);
 }  // namespace pfp

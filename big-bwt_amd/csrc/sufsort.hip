@@ -818,23 +818,35 @@ __global__ void sample_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, ui
   val[k] = k;
 }
 // flag the suffixes whose key lies in [klo, khi) (khi_open: no upper bound) and count those below klo
+// Also sums, over the suffixes of the range, the occurrences of their words (count.pos_word != null): the
+// number of BWT positions this range will emit, known before anything is sorted.
 __global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp, uint64_t klo,
-                                                          uint64_t khi, int khi_open, uint8_t *__restrict__ flag,
-                                                          unsigned long long *__restrict__ below) {
+                                                          uint64_t khi, int khi_open, SlotPayloadSrc count,
+                                                          uint8_t *__restrict__ flag, unsigned long long *__restrict__ below) {
   __shared__ uint32_t lut[256];
-  __shared__ unsigned long long wsum[4];
+  __shared__ unsigned long long wsum[2][4];
   lut[threadIdx.x] = kp.lut[threadIdx.x];
   __syncthreads();
-  unsigned long long cnt = 0;
+  unsigned long long cnt = 0, emits = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256) {
     const uint64_t k = packed_key_at(s, i, kp.kbits, lut);
     cnt += k < klo ? 1ull : 0ull;
-    flag[i] = (k >= klo && (khi_open || k < khi)) ? 1 : 0;
+    const bool mine = k >= klo && (khi_open || k < khi);
+    flag[i] = mine ? 1 : 0;
+    if (mine && count.pos_word) {
+      const uint32_t wd = count.pos_word[i];
+      if (wd < count.d && (count.endpos[i] - (uint32_t)i) > (uint32_t)count.w) emits += count.wocc[wd];
+    }
   }
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o, 64); emits += __shfl_down(emits, o, 64); }
+  if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = cnt; wsum[1][threadIdx.x >> 6] = emits; }
   __syncthreads();
-  if (threadIdx.x == 0) { const unsigned long long t = wsum[0] + wsum[1] + wsum[2] + wsum[3]; if (t) atomicAdd(below, t); }
+  if (threadIdx.x == 0) {
+    const unsigned long long t = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+    const unsigned long long e = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    if (t) atomicAdd(below, t);
+    if (e) atomicAdd(below + 1, e);
+  }
 }
 __global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__restrict__ s, uint64_t n, KeyCode kp,
                                                              SlotPayloadSrc P, int paybits, const uint32_t *__restrict__ idx,
@@ -851,7 +863,7 @@ __global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__re
 }
 
 void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, uint32_t part,
-                              uint32_t parts, SuffixOrder &out, const SlotPayloadSrc *pay) {
+                              uint32_t parts, SuffixOrder &out, const SlotPayloadSrc *pay, const SlotPayloadSrc *count) {
   PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
   PFP_REQUIRE(parts >= 1 && part < parts, PFP_EINVAL, "bad key-range share");
   SufGeom g{MODE_DICT, N, endpos};
@@ -873,18 +885,19 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   }
   const int khi_open = part + 1 == parts ? 1 : 0;
   DBuf<uint8_t> flag(c, N);
-  DBuf<unsigned long long> below(c, 1);
+  DBuf<unsigned long long> below(c, 2);
   below.zero();
   hipLaunchKernelGGL(range_flags_kernel, dim3((int)std::min<uint64_t>(cdiv64(N, 256), (uint64_t)c->n_cu * 16)), dim3(256), 0,
-                     c->stream, bytes, N, kc, klo, khi, khi_open, flag.p, below.p);
+                     c->stream, bytes, N, kc, klo, khi, khi_open, count ? *count : SlotPayloadSrc{}, flag.p, below.p);
   DBuf<uint32_t> idx(c, N), cnt_d(c, 1);
   select_index_u32(c, flag.p, idx.p, cnt_d.p, N);
   PFP_HIP(hipMemcpyAsync(c->h_scalars, cnt_d.p, 4, hipMemcpyDeviceToHost, c->stream));
-  PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, below.p, 8, hipMemcpyDeviceToHost, c->stream));
+  PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, below.p, 16, hipMemcpyDeviceToHost, c->stream));
   sync(c);
   uint32_t n_mine;
   memcpy(&n_mine, c->h_scalars, 4);
   const uint64_t slot_base = c->h_scalars[1];
+  const uint64_t range_emits = c->h_scalars[2];
   flag.release();
   DBuf<uint64_t> key(c, std::max<uint64_t>(n_mine, 1));
   DBuf<uint32_t> val(c, std::max<uint64_t>(n_mine, 1));
@@ -902,7 +915,7 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   sync(c);      // kc is a stack object
   out.bytes = bytes; out.kbits = kc.kbits;
   doubling(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true, (uint64_t)n_mine);
-  out.slot_base = slot_base; out.klo = klo; out.khi = khi_open ? ~0ull : khi;
+  out.slot_base = slot_base; out.klo = klo; out.khi = khi_open ? ~0ull : khi; out.range_emits = range_emits;
 }
 
 __global__ void gather_slots_range_kernel(RankView L, uint64_t klo, uint64_t khi, uint64_t slot_base, uint64_t count,
