@@ -44,11 +44,19 @@ def all_gather_var(t, group=None):
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
     mx = max(max(sizes), 1)
-    buf = torch.zeros(mx, dtype=t.dtype, device=t.device)
-    buf[: t.numel()] = t
-    outs = [torch.empty(mx, dtype=t.dtype, device=t.device) for _ in range(world)]
-    dist.all_gather(outs, buf, group=group)
-    return [o[:s] for o, s in zip(outs, sizes)]
+    if sizes.count(mx) == world and t.numel() == mx:
+        buf = t.contiguous()
+    else:
+        buf = torch.zeros(mx, dtype=t.dtype, device=t.device)
+        buf[: t.numel()] = t
+    flat = torch.empty(world * mx, dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(flat, buf, group=group)      # one RCCL all-gather into one buffer, no per-rank copies
+    except (RuntimeError, NotImplementedError, AttributeError):
+        outs = [torch.empty(mx, dtype=t.dtype, device=t.device) for _ in range(world)]
+        dist.all_gather(outs, buf, group=group)
+        return [o[:s] for o, s in zip(outs, sizes)]
+    return [flat[r * mx: r * mx + s] for r, s in enumerate(sizes)]
 
 
 def slice_bounds(n_out, rank, size):
