@@ -193,19 +193,70 @@ __device__ __forceinline__ uint32_t slot_record(const uint8_t *__restrict__ b, u
   const uint32_t occ = P.wocc[wd];
   return pc | ((occ < 255u ? occ : 255u) << 8);
 }
+// The same keys for ALL positions, without walking 20-odd characters per suffix: a workgroup lays the
+// codes of 256 consecutive characters down as one bit stream in LDS (bit offset = prefix sum of the code
+// lengths), and the key of position t is the kbits bits that start at t's offset, cut at its word's
+// terminator (endpos) and at 32 characters - exactly what packed_key_at assembles character by
+// character (checked against it under PFP_DEBUG).  224 positions per workgroup, 32 characters of overlap.
+constexpr int kKeyPos = 224;
 __global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
-                                                               SlotPayloadSrc P, int paybits, uint64_t *__restrict__ key,
+                                                               const uint32_t *__restrict__ endpos, SlotPayloadSrc P,
+                                                               int paybits, uint64_t *__restrict__ key,
                                                                uint32_t *__restrict__ val) {
-  __shared__ uint32_t lut[256];
-  lut[threadIdx.x] = kp.lut[threadIdx.x];
+  __shared__ uint32_t off[257];
+  __shared__ uint32_t bs[200];
+  __shared__ uint32_t wsum[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint64_t B0 = (uint64_t)blockIdx.x * kKeyPos;
+  const uint64_t pos = B0 + t;
+  if (t < 200) bs[t] = 0;
+  const uint32_t c = pos < N ? s[pos] : 0u;
+  const uint32_t e = kp.lut[c];
+  const uint32_t l = e & 63u, cd = e >> 6;
+  uint32_t inc = l;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+  if (lane == 63) wsum[wv] = inc;
   __syncthreads();
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  uint64_t k = packed_key_at(s, i, kp.kbits, lut);
-  if (paybits) k |= (uint64_t)slot_record(s, i, P) << 48;
-  key[i] = k; val[i] = (uint32_t)i;
+  uint32_t base = 0;
+  for (int q = 0; q < wv; q++) base += wsum[q];
+  const uint32_t p = base + inc - l;            // bit offset of this character's code
+  off[t] = p;
+  if (t == 255) off[256] = p + l;
+  {
+    const uint32_t w = p >> 5, o = p & 31u;
+    if (o + l <= 32) atomicOr(&bs[w], cd << (32 - o - l));
+    else {
+      const uint32_t r = o + l - 32;            // bits that spill into the next word
+      atomicOr(&bs[w], cd >> r);
+      atomicOr(&bs[w + 1], (cd & ((1u << r) - 1u)) << (32 - r));
+    }
+  }
+  __syncthreads();
+  if (t >= kKeyPos || pos >= N) return;
+  const uint32_t eo = endpos[pos];              // terminator of this position's word
+  const uint32_t toterm = eo - (uint32_t)pos + 1;                 // characters up to and including it
+  const uint32_t nch = toterm < 32u ? toterm : 32u;
+  const uint32_t avail = off[t + nch] - p;
+  const uint32_t kb = (uint32_t)kp.kbits;
+  const uint32_t take = avail < kb ? avail : kb;
+  const uint32_t w = p >> 5, sh = p & 31u;
+  const uint64_t hi = ((uint64_t)bs[w] << 32) | bs[w + 1];
+  uint64_t x = hi << sh;
+  if (sh) x |= (uint64_t)(bs[w + 2] >> (32 - sh));
+  uint64_t k = x >> (64 - kb);
+  if (take < kb) k &= ~((1ull << (kb - take)) - 1ull);
+  const uint32_t term = (toterm <= 32u && off[t + toterm] - p <= kb) ? 1u : 0u;
+  k = (k << 1) | term;
+  if (paybits) k |= (uint64_t)slot_record(s, pos, P) << 48;
+  key[pos] = k; val[pos] = (uint32_t)pos;
 }
-
+// PFP_DEBUG: the bit-stream keys against the character-by-character ones
+__global__ void check_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp, const uint64_t *__restrict__ key,
+                                  uint64_t keymask, unsigned long long *__restrict__ bad) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if ((key[i] & keymask) != packed_key_at(s, i, kp.kbits, kp.lut)) atomicAdd(bad, 1ull);
+}
 __global__ void init_keys_bytes_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
                                        uint32_t *__restrict__ val) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -796,8 +847,16 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   out.paybits = (pay && !no_payload && kc.kbits + 1 <= 48) ? 16 : 0;
   out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
   { KScope ks(c, "pfp::init_keys_packed_kernel", N * (13 + (out.paybits ? 9 : 0)));
-    hipLaunchKernelGGL(init_keys_packed_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kc,
+    hipLaunchKernelGGL(init_keys_packed_kernel, dim3((unsigned)cdiv64(N, kKeyPos)), dim3(256), 0, c->stream, bytes, N, kc, endpos,
                        pay ? *pay : SlotPayloadSrc{}, out.paybits, key.p, val.p); }
+  if (c->debug) {
+    DBuf<unsigned long long> bad(c, 1);
+    bad.zero();
+    hipLaunchKernelGGL(check_keys_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kc, key.p, out.keymask, bad.p);
+    PFP_HIP(hipMemcpyAsync(c->h_scalars, bad.p, 8, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    PFP_REQUIRE(c->h_scalars[0] == 0, PFP_EHIP, "bit-stream keys differ from packed_key_at at " + std::to_string(c->h_scalars[0]) + " positions");
+  }
   out.lut.alloc(c, 256);
   PFP_HIP(hipMemcpyAsync(out.lut.p, kc.lut, 1024, hipMemcpyHostToDevice, c->stream));
   sync(c);      // kc is a stack object
