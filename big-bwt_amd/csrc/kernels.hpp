@@ -117,9 +117,6 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
                               const SlotPayloadSrc *count = nullptr);
 // range mode: out[j] = 1 + SA(D) slot of the suffix starting at pos[j] if it belongs to this share, else 0
 void gather_slots_range(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint64_t count, uint32_t *d_out);
-// rank[] is written sparsely by the sorter; fill it for given positions (device array) / everywhere
-void materialize_ranks(pfp_ctx *c, SuffixOrder &so, const uint64_t *d_positions, uint64_t count);
-void materialize_all_ranks(pfp_ctx *c, SuffixOrder &so);
 // plain suffix array of an integer string with unique smallest last symbol (sacak_int)
 // max_sym: largest symbol value (spare key bits then describe runs of equal symbols)
 void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym = 0xFFFFFFFFu);

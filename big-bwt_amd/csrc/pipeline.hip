@@ -69,17 +69,6 @@ __global__ __launch_bounds__(256) void dict_permute_kernel(uint32_t d, const uin
   }
 }
 
-// word table of a dictionary given as bytes (reference .dict): starts and lengths
-__global__ void words_from_wend_kernel(uint32_t d, const uint32_t *__restrict__ wend, uint64_t *__restrict__ woff,
-                                       uint32_t *__restrict__ wlen) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j == 0) woff[d] = wend[d];
-  if (j >= d) return;
-  uint64_t s = j ? (uint64_t)wend[j - 1] + 1 : 0;
-  woff[j] = s;
-  wlen[j] = (uint32_t)(wend[j] - s);
-}
-
 struct Chain {
   StagedText tx;
   DBuf<uint64_t> ends;

@@ -311,7 +311,7 @@ __global__ void iota32_kernel(uint32_t *p, uint64_t n) {
 }
 
 // key of an unresolved suffix: (its group's head slot, 1 + rank of the suffix h further on).
-// The suffix position and its group travel with the active list (compact3_kernel), so the only
+// The suffix position and its group travel with the active list (active_place_kernel), so the only
 // random access is rank[i+h].  In dictionary mode an unresolved suffix is always longer than the
 // sorted prefix h (otherwise write_back would have retired it), so i+h stays inside its word.
 __global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ act_i,
@@ -325,29 +325,6 @@ __global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const uint3
   const uint64_t nxt = (g.mode == MODE_DICT || (uint64_t)i + h < g.N) ? (uint64_t)rank_at(L, (uint64_t)i + h, settled) + 1 : 0;
   key[a] = (grp << nb) | nxt;
   val[a] = i | (settled ? L.finbit : 0u);
-}
-
-// Sparse rank materialisation (helpers).  Measured and NOT used inside the doubling loop: marking the
-// needed positions i+h in a bitmap and filling rank[] for them with one pass over all slots costs N
-// cache-resident random bit reads per round (4 ms at N = 260 M), no cheaper than the dense
-// scatter of write_back it was meant to replace (profiles/r01_notes.md).
-__global__ void mark_needed_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ act_i,
-                                   uint32_t *__restrict__ bits) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= m) return;
-  const uint64_t j = (uint64_t)act_i[a] + h;
-  if (j < g.N) atomicOr(&bits[j >> 5], 1u << (j & 31));
-}
-__global__ void mark_positions_kernel(uint64_t cnt, const uint64_t *__restrict__ pos, uint32_t *__restrict__ bits) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a < cnt) { const uint64_t j = pos[a]; atomicOr(&bits[j >> 5], 1u << (j & 31)); }
-}
-__global__ void provide_ranks_kernel(uint64_t N, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ grp,
-                                     const uint32_t *__restrict__ bits, uint32_t *__restrict__ rank) {
-  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N) return;
-  const uint32_t j = sa[t];
-  if ((bits[j >> 5] >> (j & 31)) & 1u) rank[j] = grp[t];
 }
 
 // segmented variant of a doubling round: the unresolved suffixes are already grouped (the active
@@ -380,17 +357,6 @@ __global__ void heads32_kernel(uint64_t m, const uint8_t *__restrict__ gs, const
   bool h = gs[a] || key[a] != key[a - 1];
   hd[a] = h ? 1 : 0;
   hv[a] = h ? aslot[a] : 0u;
-}
-
-// stream compaction of the active list: (slot, suffix, group) of every suffix that stays unresolved
-__global__ void compact3_kernel(uint64_t m, const uint8_t *__restrict__ keep, const uint32_t *__restrict__ inc,
-                                const uint32_t *__restrict__ aslot, const uint32_t *__restrict__ val,
-                                const uint32_t *__restrict__ newhead, uint32_t finbit, uint32_t *__restrict__ aslot2,
-                                uint32_t *__restrict__ act_i, uint32_t *__restrict__ act_grp) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= m || !keep[a]) return;
-  const uint32_t o = inc[a] - 1;
-  aslot2[o] = aslot[a]; act_i[o] = val[a] & ~finbit; act_grp[o] = newhead[a];
 }
 
 // Compaction of the active list: kept suffixes and kept group heads counted per 256 list positions
@@ -429,20 +395,6 @@ __global__ __launch_bounds__(256) void active_place_kernel(const uint8_t *__rest
   uint32_t pos = tile_off[blockIdx.x] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
   for (int q = 0; q < wv; q++) pos += ws[q];
   aslot2[pos] = aslot ? aslot[a] : (uint32_t)a; act_i[pos] = val[a] & ~finbit; act_grp[pos] = newhead[a];      // no list yet: slot == index
-}
-
-// number of unresolved groups after a round (their heads stay unresolved with them).  A fixed grid
-// of grid-stride workgroups, one atomic per workgroup: a per-wave atomic on one word serialises
-// (4 M atomics = 24 ms at N = 260 M).
-__global__ __launch_bounds__(256) void count_groups_kernel(uint64_t m, const uint8_t *__restrict__ keep,
-                                                           const uint8_t *__restrict__ hd, uint32_t *__restrict__ n_groups) {
-  uint32_t cnt = 0;
-  for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < m; a += (uint64_t)gridDim.x * 256) cnt += (keep[a] && hd[a]) ? 1u : 0u;
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
-  __shared__ uint32_t ws[4];
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t t = ws[0] + ws[1] + ws[2] + ws[3]; if (t) atomicAdd(n_groups, t); }
 }
 
 __global__ void heads_kernel(uint64_t m, const uint64_t *__restrict__ key, const uint32_t *__restrict__ aslot,
@@ -614,7 +566,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   out.sa.alloc(c, N); out.rank.alloc(c, NP); out.grp.alloc(c, N + 8);
   if (N == 0) return;
   DBuf<uint64_t> keyo(c, N);
-  DBuf<uint32_t> valo(c, N), aslot(c, N), aslot2(c, N), hv(c, N), newhead(c, N), inc(c, N), act_i(c, N), act_grp(c, N);
+  DBuf<uint32_t> valo(c, N), aslot(c, N), aslot2(c, N), hv(c, N), newhead(c, N), act_i(c, N), act_grp(c, N);
   DBuf<uint8_t> hd(c, N + 1), keep(c, N);
   sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, N, 0, key0_bits);
   if (!dict_keys) hipLaunchKernelGGL(iota32_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, aslot.p, N);
@@ -637,7 +589,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   out.finbit = (g.mode == MODE_DICT && N < (1ull << 31) && !no_finflag) ? 0x80000000u : 0u;
   static const bool use_segsort = []() { const char *e = getenv("PFP_SEGSORT"); return !(e && e[0] == '0'); }();
   DBuf<uint8_t> gs;
-  DBuf<uint32_t> k32, k32o, segb, sege, nseg_d, ngrp_d(c, 1);
+  DBuf<uint32_t> k32, k32o, segb, sege, nseg_d;
   bool seg_round = false;       // the keys of this round live in k32o (segmented path) instead of keyo
   bool pivot_round = false;     // the keys of this round are pivot order keys (build_keys_pivot_kernel)
   bool pivot_ok = true;
@@ -794,24 +746,6 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     h *= 2;
     out.rounds++;
   }
-}
-
-// rank[] of a finished SuffixOrder is only defined where a doubling round needed it; these fill it
-// for a list of positions / for every position (debug validation, pfp tests)
-void materialize_ranks(pfp_ctx *c, SuffixOrder &so, const uint64_t *d_positions, uint64_t count) {
-  DBuf<uint32_t> bits(c, so.N / 32 + 2);
-  bits.zero();
-  hipLaunchKernelGGL(mark_positions_kernel, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, count, d_positions, bits.p);
-  hipLaunchKernelGGL(provide_ranks_kernel, dim3(cdiv(so.N, 256)), dim3(256), 0, c->stream, so.N, so.sa.p, so.grp.p, bits.p,
-                     so.rank.p);
-  PFP_HIP(hipGetLastError());
-}
-void materialize_all_ranks(pfp_ctx *c, SuffixOrder &so) {
-  DBuf<uint32_t> bits(c, so.N / 32 + 2);
-  PFP_HIP(hipMemsetAsync(bits.p, 0xff, (so.N / 32 + 2) * 4, c->stream));
-  hipLaunchKernelGGL(provide_ranks_kernel, dim3(cdiv(so.N, 256)), dim3(256), 0, c->stream, so.N, so.sa.p, so.grp.p, bits.p,
-                     so.rank.p);
-  PFP_HIP(hipGetLastError());
 }
 
 __global__ void gather_ranks_kernel(RankView L, uint64_t count, const uint64_t *__restrict__ pos, uint32_t *__restrict__ out) {
