@@ -408,15 +408,30 @@ __global__ void heads_kernel(uint64_t m, const uint64_t *__restrict__ key, const
 
 // First round of dictionary mode (slot == index): group heads, and the bucket table of the sorted
 // keys for rank_at: the first slot of every occupied top-bits bucket marks its reversed entry.
-__global__ void heads0_kernel(uint64_t m, const uint64_t *__restrict__ key, uint64_t keymask, int shift, uint32_t T,
-                              uint8_t *__restrict__ hd, uint32_t *__restrict__ hv, uint32_t *__restrict__ tab) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= m) return;
-  const uint64_t k = key[a] & keymask, kprev = a ? (key[a - 1] & keymask) : ~k;
-  const bool h = k != kprev;
-  hd[a] = h ? 1 : 0;
-  hv[a] = h ? (uint32_t)a : 0u;
-  if (a == 0 || (k >> shift) != (kprev >> shift)) tab[T - 1 - (uint32_t)(k >> shift)] = 0xFFFFFFFFu - (uint32_t)a;
+// Per workgroup of 256 slots also the index of its last head (0 = none, slot 0 is always a head): a
+// max-scan over those 4 bytes per 256 slots gives every workgroup of write_back0 its carry-in, and
+// the head of each slot is found from the head flags with ballots - no N-long scan of head indices.
+__global__ __launch_bounds__(256) void heads0_kernel(uint64_t m, const uint64_t *__restrict__ key, uint64_t keymask, int shift,
+                                                     uint32_t T, uint8_t *__restrict__ hd, uint32_t *__restrict__ tile_last,
+                                                     uint32_t *__restrict__ tab) {
+  __shared__ uint32_t wl[4];
+  const uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool h = false;
+  if (a < m) {
+    const uint64_t k = key[a] & keymask, kprev = a ? (key[a - 1] & keymask) : ~k;
+    h = k != kprev;
+    hd[a] = h ? 1 : 0;
+    if (a == 0 || (k >> shift) != (kprev >> shift)) tab[T - 1 - (uint32_t)(k >> shift)] = 0xFFFFFFFFu - (uint32_t)a;
+  }
+  const unsigned long long mask = __ballot(h);
+  if ((threadIdx.x & 63) == 0)
+    wl[threadIdx.x >> 6] = mask ? (uint32_t)(blockIdx.x * 256ull + (threadIdx.x & ~63) + (63 - __clzll((long long)mask))) : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t v = wl[0];
+    for (int q = 1; q < 4; q++) v = wl[q] > v ? wl[q] : v;
+    tile_last[blockIdx.x] = v;
+  }
 }
 __global__ void fill_u32_kernel(uint32_t *p, uint64_t n, uint32_t v) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -424,18 +439,39 @@ __global__ void fill_u32_kernel(uint32_t *p, uint64_t n, uint32_t v) {
 }
 // First round of dictionary mode: sa and grp are the sorted values / scanned heads themselves
 // (streaming copies); rank[] is written only for the suffixes that stay unresolved.
-__global__ void write_back0_kernel(uint64_t m, const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead,
-                                   const uint8_t *__restrict__ hd, const uint64_t *__restrict__ key0,
-                                   uint32_t *__restrict__ sa, uint32_t *__restrict__ rank,
-                                   uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= m) return;
-  const uint32_t i = val[a], head = newhead[a];
+__global__ __launch_bounds__(256) void write_back0_kernel(uint64_t m, const uint32_t *__restrict__ val,
+                                                          const uint32_t *__restrict__ tile_scan,
+                                                          const uint8_t *__restrict__ hd, const uint64_t *__restrict__ key0,
+                                                          uint32_t *__restrict__ sa, uint32_t *__restrict__ rank,
+                                                          uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
+  __shared__ uint32_t wl[4];
+  const uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // all loads first: nothing below the barrier waits on memory except the carry-in
+  const bool in = a < m;
+  const bool h = in && hd[a];
+  const bool hnext = in && (a + 1 == m || hd[a + 1]);
+  const uint32_t i = in ? val[a] : 0u;
+  const uint32_t flagbit = in ? (uint32_t)(key0[a] & 1ull) : 0u;
+  const uint32_t carry = blockIdx.x ? tile_scan[blockIdx.x - 1] : 0u;
+  const unsigned long long mask = __ballot(h);
+  const uint32_t wbase = (uint32_t)(blockIdx.x * 256ull + (threadIdx.x & ~63));
+  if (lane == 0) wl[wv] = mask ? wbase + (63 - __clzll((long long)mask)) : 0u;
+  __syncthreads();
+  if (!in) return;
+  // head of slot a: the last head flag at or before it - in its wave, else in an earlier wave of the
+  // workgroup, else the carry-in (last head of all earlier workgroups)
+  const unsigned long long upto = mask & (~0ull >> (63 - lane));
+  uint32_t head;
+  if (upto) head = wbase + (63 - __clzll((long long)upto));
+  else {
+    head = carry;
+    for (int q = 0; q < wv; q++) head = wl[q] > head ? wl[q] : head;
+  }
   sa[a] = i;
   grp[a] = head;
-  const bool single = hd[a] && (a + 1 == m || hd[a + 1]);
-  bool fin = false;
-  if (!single) fin = (key0[a] & 1ull) != 0;       // the terminator is inside the key: the tied strings are identical
+  const bool single = h && hnext;
+  const bool fin = !single && flagbit;       // the terminator is inside the key: the tied strings are identical
   const bool k = !single && !fin;
   if (k) rank[i] = head;
   keep[a] = k ? 1 : 0;
@@ -602,8 +638,9 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     if (first && lazy) {
       { KScope ks(c, "pfp::heads_kernel", m * 13);
         hipLaunchKernelGGL(heads0_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, out.keymask, out.shift, out.T,
-                           hd.p, hv.p, out.tab.p); }
+                           hd.p, hv.p /* last head per 256 slots */, out.tab.p); }
       inclusive_max_u32(c, out.tab.p, out.tab.p, out.T);
+      inclusive_max_u32(c, hv.p, newhead.p /* carry-in per 256 slots */, cdiv64(m, 256));
     } else if (seg_round) {
       KScope ks(c, "pfp::heads_kernel", m * 14);
       hipLaunchKernelGGL(heads32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, gs.p, k32o.p, aslot.p, hd.p, hv.p);
@@ -611,9 +648,9 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       KScope ks(c, "pfp::heads_kernel", m * 17);
       hipLaunchKernelGGL(heads_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p);
     }
-    inclusive_max_u32(c, hv.p, newhead.p, m);
     const bool round0 = first && lazy;
     first = false;
+    if (!round0) inclusive_max_u32(c, hv.p, newhead.p, m);
     if (round0) {
       { KScope ks(c, "pfp::write_back_kernel", m * (4 + 4 + 1 + 8 + 4 + 4 + 1));
         hipLaunchKernelGGL(write_back0_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, valo.p, newhead.p, hd.p, keyo.p,
@@ -650,7 +687,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       exclusive_sum_u32(c, tile_keep.p, tile_off.p, ntile + 1);
       exclusive_sum_u32(c, tile_heads.p, tile_hoff.p, ntile + 1);
       hipLaunchKernelGGL(active_place_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, keep.p, m, tile_off.p,
-                         round0 ? (const uint32_t *)nullptr : aslot.p, valo.p, newhead.p, out.finbit, aslot2.p, act_i.p, act_grp.p);
+                         round0 ? (const uint32_t *)nullptr : aslot.p, valo.p, round0 ? out.grp.p : newhead.p, out.finbit, aslot2.p,
+                         act_i.p, act_grp.p);
       PFP_HIP(hipGetLastError());
       PFP_HIP(hipMemcpyAsync(c->h_scalars, tile_off.p + ntile, 4, hipMemcpyDeviceToHost, c->stream));
       PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, tile_hoff.p + ntile, 4, hipMemcpyDeviceToHost, c->stream));
