@@ -199,54 +199,61 @@ __device__ __forceinline__ uint32_t slot_record(const uint8_t *__restrict__ b, u
 // terminator (endpos) and at 32 characters - exactly what packed_key_at assembles character by
 // character (checked against it under PFP_DEBUG).  224 positions per workgroup, 32 characters of overlap.
 constexpr int kKeyPos = 224;
-__global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
-                                                               const uint32_t *__restrict__ endpos, SlotPayloadSrc P,
-                                                               int paybits, uint64_t *__restrict__ key,
-                                                               uint32_t *__restrict__ val) {
-  __shared__ uint32_t off[257];
-  __shared__ uint32_t bs[200];
-  __shared__ uint32_t wsum[4];
+struct KeyStreamLds { uint32_t off[257]; uint32_t bs[200]; uint32_t wsum[4]; };
+// workgroup-cooperative: returns the key (code bits << 1 | terminator flag) of position B0 + threadIdx.x
+// for threadIdx.x < kKeyPos and position < N; every thread of the workgroup must call it
+__device__ __forceinline__ uint64_t block_stream_key(KeyStreamLds &L, const uint8_t *__restrict__ s, uint64_t N,
+                                                     const KeyCode &kp, const uint32_t *__restrict__ endpos, uint64_t B0) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const uint64_t B0 = (uint64_t)blockIdx.x * kKeyPos;
   const uint64_t pos = B0 + t;
-  if (t < 200) bs[t] = 0;
+  if (t < 200) L.bs[t] = 0;
   const uint32_t c = pos < N ? s[pos] : 0u;
   const uint32_t e = kp.lut[c];
   const uint32_t l = e & 63u, cd = e >> 6;
   uint32_t inc = l;
   for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-  if (lane == 63) wsum[wv] = inc;
+  if (lane == 63) L.wsum[wv] = inc;
   __syncthreads();
   uint32_t base = 0;
-  for (int q = 0; q < wv; q++) base += wsum[q];
+  for (int q = 0; q < wv; q++) base += L.wsum[q];
   const uint32_t p = base + inc - l;            // bit offset of this character's code
-  off[t] = p;
-  if (t == 255) off[256] = p + l;
+  L.off[t] = p;
+  if (t == 255) L.off[256] = p + l;
   {
     const uint32_t w = p >> 5, o = p & 31u;
-    if (o + l <= 32) atomicOr(&bs[w], cd << (32 - o - l));
+    if (o + l <= 32) atomicOr(&L.bs[w], cd << (32 - o - l));
     else {
       const uint32_t r = o + l - 32;            // bits that spill into the next word
-      atomicOr(&bs[w], cd >> r);
-      atomicOr(&bs[w + 1], (cd & ((1u << r) - 1u)) << (32 - r));
+      atomicOr(&L.bs[w], cd >> r);
+      atomicOr(&L.bs[w + 1], (cd & ((1u << r) - 1u)) << (32 - r));
     }
   }
   __syncthreads();
-  if (t >= kKeyPos || pos >= N) return;
+  if (t >= kKeyPos || pos >= N) return 0;
   const uint32_t eo = endpos[pos];              // terminator of this position's word
   const uint32_t toterm = eo - (uint32_t)pos + 1;                 // characters up to and including it
   const uint32_t nch = toterm < 32u ? toterm : 32u;
-  const uint32_t avail = off[t + nch] - p;
+  const uint32_t avail = L.off[t + nch] - p;
   const uint32_t kb = (uint32_t)kp.kbits;
   const uint32_t take = avail < kb ? avail : kb;
   const uint32_t w = p >> 5, sh = p & 31u;
-  const uint64_t hi = ((uint64_t)bs[w] << 32) | bs[w + 1];
+  const uint64_t hi = ((uint64_t)L.bs[w] << 32) | L.bs[w + 1];
   uint64_t x = hi << sh;
-  if (sh) x |= (uint64_t)(bs[w + 2] >> (32 - sh));
+  if (sh) x |= (uint64_t)(L.bs[w + 2] >> (32 - sh));
   uint64_t k = x >> (64 - kb);
   if (take < kb) k &= ~((1ull << (kb - take)) - 1ull);
-  const uint32_t term = (toterm <= 32u && off[t + toterm] - p <= kb) ? 1u : 0u;
-  k = (k << 1) | term;
+  const uint32_t term = (toterm <= 32u && L.off[t + toterm] - p <= kb) ? 1u : 0u;
+  return (k << 1) | term;
+}
+__global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
+                                                               const uint32_t *__restrict__ endpos, SlotPayloadSrc P,
+                                                               int paybits, uint64_t *__restrict__ key,
+                                                               uint32_t *__restrict__ val) {
+  __shared__ KeyStreamLds L;
+  const uint64_t B0 = (uint64_t)blockIdx.x * kKeyPos;
+  uint64_t k = block_stream_key(L, s, N, kp, endpos, B0);
+  const uint64_t pos = B0 + threadIdx.x;
+  if (threadIdx.x >= kKeyPos || pos >= N) return;
   if (paybits) k |= (uint64_t)slot_record(s, pos, P) << 48;
   key[pos] = k; val[pos] = (uint32_t)pos;
 }
@@ -851,32 +858,45 @@ __global__ void sample_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, ui
 // flag the suffixes whose key lies in [klo, khi) (khi_open: no upper bound) and count those below klo
 // Also sums, over the suffixes of the range, the occurrences of their words (count.pos_word != null): the
 // number of BWT positions this range will emit, known before anything is sorted.
-__global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp, uint64_t klo,
-                                                          uint64_t khi, int khi_open, SlotPayloadSrc count,
-                                                          uint8_t *__restrict__ flag, unsigned long long *__restrict__ below) {
-  __shared__ uint32_t lut[256];
+__global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
+                                                          const uint32_t *__restrict__ endpos, uint64_t klo, uint64_t khi,
+                                                          int khi_open, SlotPayloadSrc count, uint8_t *__restrict__ flag,
+                                                          unsigned long long *__restrict__ tile_below,
+                                                          unsigned long long *__restrict__ tile_emits) {
+  __shared__ KeyStreamLds L;
   __shared__ unsigned long long wsum[2][4];
-  lut[threadIdx.x] = kp.lut[threadIdx.x];
-  __syncthreads();
+  const uint64_t B0 = (uint64_t)blockIdx.x * kKeyPos;
+  const uint64_t k = block_stream_key(L, s, N, kp, endpos, B0);
+  const uint64_t i = B0 + threadIdx.x;
   unsigned long long cnt = 0, emits = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256) {
-    const uint64_t k = packed_key_at(s, i, kp.kbits, lut);
-    cnt += k < klo ? 1ull : 0ull;
+  if (threadIdx.x < kKeyPos && i < N) {
+    cnt = k < klo ? 1ull : 0ull;
     const bool mine = k >= klo && (khi_open || k < khi);
     flag[i] = mine ? 1 : 0;
     if (mine && count.pos_word) {
       const uint32_t wd = count.pos_word[i];
-      if (wd < count.d && (count.endpos[i] - (uint32_t)i) > (uint32_t)count.w) emits += count.wocc[wd];
+      if (wd < count.d && (count.endpos[i] - (uint32_t)i) > (uint32_t)count.w) emits = count.wocc[wd];
     }
   }
   for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o, 64); emits += __shfl_down(emits, o, 64); }
   if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = cnt; wsum[1][threadIdx.x >> 6] = emits; }
   __syncthreads();
+  if (threadIdx.x == 0) {       // per-workgroup sums (one atomic per workgroup on one address would serialise 1.6 M of them)
+    tile_below[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+    tile_emits[blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+  }
+}
+__global__ __launch_bounds__(256) void sum2_u64_kernel(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b,
+                                                       uint64_t n, unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long ws[2][4];
+  unsigned long long x = 0, y = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) { x += a[i]; y += b[i]; }
+  for (int o = 32; o > 0; o >>= 1) { x += __shfl_down(x, o, 64); y += __shfl_down(y, o, 64); }
+  if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = x; ws[1][threadIdx.x >> 6] = y; }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned long long t = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
-    const unsigned long long e = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
-    if (t) atomicAdd(below, t);
-    if (e) atomicAdd(below + 1, e);
+    atomicAdd(out, ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3]);
+    atomicAdd(out + 1, ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3]);
   }
 }
 __global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__restrict__ s, uint64_t n, KeyCode kp,
@@ -918,8 +938,14 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   DBuf<uint8_t> flag(c, N);
   DBuf<unsigned long long> below(c, 2);
   below.zero();
-  hipLaunchKernelGGL(range_flags_kernel, dim3((int)std::min<uint64_t>(cdiv64(N, 256), (uint64_t)c->n_cu * 16)), dim3(256), 0,
-                     c->stream, bytes, N, kc, klo, khi, khi_open, count ? *count : SlotPayloadSrc{}, flag.p, below.p);
+  {
+    const uint64_t nblk = cdiv64(N, kKeyPos);
+    DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
+    hipLaunchKernelGGL(range_flags_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, bytes, N, kc, endpos, klo, khi, khi_open,
+                       count ? *count : SlotPayloadSrc{}, flag.p, tb.p, te.p);
+    hipLaunchKernelGGL(sum2_u64_kernel, dim3((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), dim3(256), 0, c->stream, tb.p, te.p, nblk,
+                       below.p);
+  }
   DBuf<uint32_t> idx(c, N), cnt_d(c, 1);
   select_index_u32(c, flag.p, idx.p, cnt_d.p, N);
   PFP_HIP(hipMemcpyAsync(c->h_scalars, cnt_d.p, 4, hipMemcpyDeviceToHost, c->stream));
