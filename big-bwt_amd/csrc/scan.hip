@@ -334,6 +334,18 @@ uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_use
   hipLaunchKernelGGL(window_hash_kernel, dim3(take), dim3(kCand), 0, c->stream, tx.tbase(), w, picks.p, hashes.p);
   PFP_HIP(hipMemcpyAsync(hv.data(), hashes.p, (size_t)take * kCand * 4, hipMemcpyDeviceToHost, c->stream));
   sync(c);
+  // The first window of the text must never become a trigger by this route: the reference writes 0x02
+  // where the end-of-string 0x00 belongs when (and only when) ITS trigger set fires there (SURVEY.md
+  // 2.2-Q1, reproduced), so an extra trigger on that window would change one output byte.
+  uint32_t h_first = 0xFFFFFFFFu;
+  if (n_used >= (uint64_t)w) {
+    std::vector<uint8_t> fw((size_t)w);
+    PFP_HIP(hipMemcpyAsync(fw.data(), tx.tbase(), (size_t)w, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    uint64_t h = 0;
+    for (int k = 0; k < w; k++) h = (h * 256 + fw[k]) % 1999999973ull;      // newscan.cpp:168-202
+    h_first = (uint32_t)h;
+  }
   // per giant phrase: the candidate window that is rarest among kCand consecutive ones.  A
   // window seen more than 4 times there recurs every < 64 bytes (a run of one repeated char,
   // a short period): adding it would only trade the giant phrase for millions of tiny ones.
@@ -343,6 +355,7 @@ uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_use
     uint32_t best = 0, best_mult = kCand + 1;
     for (uint32_t x = 0; x < kCand; x++) {
       uint32_t mult = 0;
+      if (cand[x] == h_first) continue;
       for (uint32_t y = 0; y < kCand; y++) mult += cand[y] == cand[x];
       if (mult < best_mult) { best_mult = mult; best = cand[x]; }
     }

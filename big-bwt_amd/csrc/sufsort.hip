@@ -1013,7 +1013,8 @@ void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder 
   const uint32_t real_max = read_scalar(c, mx.p);
   PFP_REQUIRE(real_max <= max_sym, PFP_EFORMAT, "integer string holds a symbol above its alphabet size");
   const int sb = bits_for(real_max);
-  if (64 - 2 * sb >= 6) {
+  static const bool no_runkeys = getenv("PFP_NO_RUNKEYS") != nullptr;
+  if (64 - 2 * sb >= 6 && !no_runkeys) {
     DBuf<uint32_t> v(c, N), pm(c, N);
     hipLaunchKernelGGL(run_marks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, sym, (uint32_t)N, v.p);
     inclusive_max_u32(c, v.p, pm.p, N);

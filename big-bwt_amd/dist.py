@@ -85,11 +85,19 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
     # --- one trigger set for all ranks: the reference's plus the union of every rank's proposals for
     #     splitting giant phrases (N runs); the outputs do not depend on the parse
     mine = ctx.dist_propose_triggers(local.data_ptr(), local.numel(), w, p)
-    prop = torch.full((8,), -1, dtype=torch.int64, device=dev)
+    prop = torch.full((9,), -1, dtype=torch.int64, device=dev)
     if mine:
         prop[: len(mine)] = torch.tensor(mine, dtype=torch.int64, device=dev)
+    if rank == 0 and n_shard >= w:
+        # the text's first window must not become an extra trigger (it would turn the end-of-string byte of
+        # the BWT into the reference's first-window quirk): rank 0 announces its hash
+        h0 = 0
+        for b in shard[:w].tolist():
+            h0 = (h0 * 256 + b) % 1999999973          # newscan.cpp:168-202
+        prop[8] = h0
     props = yield ("allgather", prop)
-    extra = sorted({int(v) for t in props for v in t.tolist() if v >= 0})[:32]
+    banned = {int(t[8]) for t in props if int(t[8]) >= 0}
+    extra = sorted({int(v) for t in props for v in t[:8].tolist() if v >= 0} - banned)[:32]
     info = ctx.dist_local_parse(local.data_ptr(), local.numel(), left.numel(), w, p, rank == 0, rank == size - 1, goff, want_sai,
                                 extra)
     if rank < size - 1:
