@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgs a, const ui
 // hard_big_kernel.  (One group at a time per wave took 7.7 us per group, 22 ms at 8.8 M groups.)
 constexpr int kHardLds = 1024;   // occurrences of one batch ranked in LDS
 constexpr int kHardMem = 256;    // members of one batch
+constexpr int kHardSortMin = 512;   // a group with more occurrences than this (and <= kHardLds) is sorted, not ranked all-pairs
 struct BigGroup { uint64_t g; uint64_t E; uint32_t k; uint32_t pad; };
 struct HardLds {
   uint32_t lpos[kHardLds];
@@ -478,10 +479,16 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
 }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(v, o, 64); v = x > v ? x : v; }
+  return v;
+}
 __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, const uint32_t *__restrict__ heads,
                                                           const uint32_t *__restrict__ nheads_p,
                                                           unsigned long long *__restrict__ stats,
-                                                          BigGroup *__restrict__ big, uint32_t big_cap) {
+                                                          BigGroup *__restrict__ big, uint32_t big_cap,
+                                                          BigGroup *__restrict__ mid, uint32_t mid_cap) {
   __shared__ HardLds S[4];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   HardLds &L = S[wv];
@@ -502,8 +509,12 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, const uin
       const uint64_t Eg = a.off[g + kk] - base;
       if (kk && !(base + Eg <= a.out_lo || base >= a.out_hi)) {      // inside this rank's slice
         my_chars += Eg; my_groups += 1;
-        if (Eg <= (uint64_t)kHardLds && kk <= (uint32_t)kHardMem) { live = true; k = kk; E = (uint32_t)Eg; }
-        else {       // too large for the LDS tables: hard_big_kernel (whole grid, one thread per occurrence)
+        const bool sorted_path = a.dbg_mode ? a.dbg_mode == 3 : Eg > (uint64_t)kHardSortMin;
+        if (Eg <= (uint64_t)kHardLds && kk <= (uint32_t)kHardMem && !sorted_path) { live = true; k = kk; E = (uint32_t)Eg; }
+        else if (Eg <= (uint64_t)kHardLds && sorted_path) {      // one wave sorts it in LDS: hard_sort_kernel
+          const unsigned long long idx = atomicAdd(&stats[3], 1ull);
+          if (idx < mid_cap) mid[idx] = BigGroup{g, Eg, kk, 0};
+        } else {     // too large for the LDS tables: hard_big_kernel (whole grid, one thread per occurrence)
           const unsigned long long idx = atomicAdd(&stats[2], 1ull);
           if (idx < big_cap) big[idx] = BigGroup{g, Eg, kk, 0};
         }
@@ -587,6 +598,57 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, const uin
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { my_chars += __shfl_down(my_chars, o, 64); my_groups += __shfl_down(my_groups, o, 64); }
   if (lane == 0 && (my_chars | my_groups)) { atomicAdd(&stats[0], my_chars); atomicAdd(&stats[1], my_groups); }
+}
+
+// Groups of 513..1024 occurrences (a word family of a collection of hundreds of copies): ranking every
+// occurrence against all others costs E^2 LDS reads; one wave sorts the group's positions with a bitonic
+// network instead (E log^2 E / 2 exchanges; 12.6 GB / 1024 copies: 374 -> ~250 ms).  Kept out of
+// hard_groups_kernel so that its 10 KB of sort buffers per wave do not halve that kernel's occupancy
+// (they did: 11 -> 20 ms on the 64-copy workload).  The member search is by position here (a member table
+// would not fit for k > 256): every occurrence finds its member by bisection over the slots' offsets.
+__global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgs a, const BigGroup *__restrict__ mid, uint32_t nmid) {
+  __shared__ uint64_t skey[4][kHardLds];       // (position << 16 | occurrence index)
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint64_t *K = skey[wv];
+  for (uint32_t qi = blockIdx.x * 4 + wv; qi < nmid; qi += gridDim.x * 4) {
+    const uint64_t g = mid[qi].g;
+    const uint32_t E = (uint32_t)mid[qi].E, k = mid[qi].k;
+    const uint64_t base = a.off[g];
+    uint32_t n = 64;
+    while (n < E) n <<= 1;
+    for (uint32_t e = lane; e < n; e += 64) {
+      uint64_t key = ~0ull;
+      if (e < E) {
+        uint32_t lo = 0, hi = k;                 // member holding occurrence e: off[g+lo] - base <= e
+        while (hi - lo > 1) { const uint32_t mdl = (lo + hi) >> 1; if (a.off[g + mdl] - base <= e) lo = mdl; else hi = mdl; }
+        const uint32_t pos = a.ilist[slot_ist(a, g + lo) + (e - (uint32_t)(a.off[g + lo] - base))];
+        key = ((uint64_t)pos << 16) | e;
+      }
+      K[e] = key;
+    }
+    wave_lds_sync();
+    for (uint32_t k2 = 2; k2 <= n; k2 <<= 1)
+      for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = lane; i < (n >> 1); i += 64) {
+          const uint32_t x = ((i & ~(j - 1)) << 1) | (i & (j - 1)), y = x | j;
+          const uint64_t kx = K[x], ky = K[y];
+          if ((kx > ky) == ((x & k2) == 0)) { K[x] = ky; K[y] = kx; }
+        }
+        wave_lds_sync();
+      }
+    for (uint32_t r = lane; r < E; r += 64) {
+      const uint64_t key = K[r];
+      const uint32_t pos = (uint32_t)(key >> 16), e = (uint32_t)(key & 0xffffu);
+      const uint64_t o = base + r;
+      if (o < a.out_lo || o >= a.out_hi) continue;
+      uint32_t lo = 0, hi = k;
+      while (hi - lo > 1) { const uint32_t mdl = (lo + hi) >> 1; if (a.off[g + mdl] - base <= e) lo = mdl; else hi = mdl; }
+      const uint64_t t = g + lo;
+      a.bwt[o] = fix_char(a.pc[t]);
+      if (a.want_sa) { const uint32_t i = a.sa[t]; a.out_sa[o] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i); }
+    }
+    wave_lds_sync();
+  }
 }
 
 // large hard groups: one thread per occurrence, rank = own index + lower_bound in every other
@@ -681,8 +743,11 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   a.bwt = out.d_bwt - out_lo; a.out_sa = out.d_sa ? out.d_sa - out_lo : nullptr;
   DBuf<unsigned long long> hstats(c, 5);
   hstats.zero();
-  uint32_t big_cap = 1u << 16;
+  uint32_t big_cap = 1u << 20;
   DBuf<BigGroup> big(c, big_cap);
+  // such a group emits > kHardSortMin positions (PFP_HARD_MODE=3, tests: every group takes this path)
+  const uint32_t mid_cap = (uint32_t)std::min<uint64_t>(a.dbg_mode == 3 ? N / 2 + 2 : n_out / (kHardSortMin + 1) + 64, 0x7FFFFFFFull);
+  DBuf<BigGroup> mid(c, mid_cap);
   {
     const uint32_t nblk = (uint32_t)cdiv64(N, kSlots);
     DBuf<uint32_t> heavy(c, nblk), nheavy(c, 1);
@@ -699,7 +764,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   for (;;) {
     { KScope ks(c, "pfp::hard_groups_kernel", N * 5);
       hipLaunchKernelGGL(hard_groups_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, a, heads.p, nheads.p, hstats.p, big.p,
-                         big_cap); }
+                         big_cap, mid.p, mid_cap); }
     PFP_HIP(hipGetLastError());
     PFP_HIP(hipMemcpyAsync(c->h_scalars, hstats.p, 40, hipMemcpyDeviceToHost, c->stream));
     sync(c);
@@ -710,7 +775,14 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   }
   out.hard_chars = c->h_scalars[0];
   out.hard_groups = c->h_scalars[1];
-  out.hard_big_groups = c->h_scalars[2]; out.hard_max_chars = c->h_scalars[3]; out.hard_max_members = c->h_scalars[4];
+  out.hard_big_groups = c->h_scalars[2]; out.hard_max_chars = 0; out.hard_max_members = c->h_scalars[4];
+  const uint32_t nmid = (uint32_t)std::min<uint64_t>(c->h_scalars[3], mid_cap);
+  PFP_REQUIRE(c->h_scalars[3] <= mid_cap, PFP_EHIP, "more sorted-path hard groups than the output can hold");
+  if (nmid) {
+    KScope ks(c, "pfp::hard_sort_kernel", 0);
+    hipLaunchKernelGGL(hard_sort_kernel, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, mid.p, nmid);
+    PFP_HIP(hipGetLastError());
+  }
   const uint32_t nbig = (uint32_t)c->h_scalars[2];
   if (nbig) {
     // occurrences of the queued groups, laid end to end
