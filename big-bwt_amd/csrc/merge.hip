@@ -779,7 +779,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   const uint32_t nmid = (uint32_t)std::min<uint64_t>(c->h_scalars[3], mid_cap);
   PFP_REQUIRE(c->h_scalars[3] <= mid_cap, PFP_EHIP, "more sorted-path hard groups than the output can hold");
   if (nmid) {
-    KScope ks(c, "pfp::hard_sort_kernel", 0);
+    KScope ks(c, "pfp::hard_sort_kernel", (uint64_t)nmid * (kHardSortMin + 1) * (flags ? 21 : 5));      // lower bound: ilist entry + char (+ SA) per occurrence
     hipLaunchKernelGGL(hard_sort_kernel, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, mid.p, nmid);
     PFP_HIP(hipGetLastError());
   }
