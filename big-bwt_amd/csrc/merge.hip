@@ -391,20 +391,12 @@ __device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L
       const uint8_t cl = L.lcls[s];
       uint32_t ch = 0;
       const bool in_slice = base + x >= a.out_lo && base + x < a.out_hi;
+      (void)in_slice;
       if (cl == CLS_FILL) {
         ch = fix_char(L.lpc[s]);
-        if (a.want_sa && in_slice) {
-          const uint32_t i = a.sa[t0 + s];
-          const uint64_t pos = a.ilist[slot_ist(a, t0 + s) + (uint32_t)(x - L.loff[s])];
-          a.out_sa[base + x] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
-        }
       } else if (cl == CLS_FULL) {
         const uint64_t pos = a.ilist[slot_ist(a, t0 + s) + (uint32_t)(x - L.loff[s])];
         ch = a.bwlast[pos];
-        if (a.want_sa && in_slice) {
-          const uint32_t i = a.sa[t0 + s];
-          a.out_sa[base + x] = (a.pos_base + base + x == 0) ? a.n_out_global - 1 : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
-        }
       }   // CLS_HARD: left 0 here, written by the hard-group kernels that run after this one
       const uint32_t sh = (uint32_t)ch << (8 * (k & 3));
       if (k < 4) r0 |= sh; else if (k < 8) r1 |= sh; else if (k < 12) r2 |= sh; else r3 |= sh;
@@ -418,6 +410,22 @@ __device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L
     for (int k = 0; k < 16; k++)
       if (k < nb && base + x0 + k >= a.out_lo && base + x0 + k < a.out_hi) dst[k] = (uint8_t)(rr[k >> 2] >> (8 * (k & 3)));
   }
+}
+
+// SA value of block-relative output position x (fill and full-word entries; hard groups write their
+// own).  One lane per position, so that the 8-byte stores of a wave are 512 contiguous bytes - the
+// 16-positions-per-thread layout of expand_16 would put every lane's store in a different 128-byte line.
+__device__ __forceinline__ void expand_sa_1(const MergeArgs &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
+                                            uint64_t x) {
+  if (base + x < a.out_lo || base + x >= a.out_hi) return;
+  int lo = 0, hi = ns;                    // loff[lo] <= x < loff[hi]
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (L.loff[mid] <= x) lo = mid; else hi = mid; }
+  const uint8_t cl = L.lcls[lo];
+  if (cl != CLS_FILL && cl != CLS_FULL) return;
+  const uint32_t i = a.sa[t0 + lo];
+  const uint64_t pos = a.ilist[slot_ist(a, t0 + lo) + (uint32_t)(x - L.loff[lo])];
+  a.out_sa[base + x] = (cl == CLS_FULL && a.pos_base + base + x == 0) ? a.n_out_global - 1
+                                                                      : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
 }
 
 __global__ __launch_bounds__(256) void expand_kernel(MergeArgs a, uint32_t *__restrict__ heavy, uint32_t *__restrict__ nheavy,
@@ -434,6 +442,8 @@ __global__ __launch_bounds__(256) void expand_kernel(MergeArgs a, uint32_t *__re
   const uint64_t mine = Ltot <= kExpandQuota ? Ltot : kExpandQuota;
   if (Ltot > kExpandQuota && threadIdx.x == 0) { uint32_t i = atomicAdd(nheavy, 1u); if (i < heavy_cap) heavy[i] = blockIdx.x; }
   for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < mine; x0 += 256 * 16) expand_16(a, L, t0, ns, base, x0, Ltot);
+  if (a.want_sa)
+    for (uint64_t x = threadIdx.x; x < mine; x += 256) expand_sa_1(a, L, t0, ns, base, x);
 }
 
 __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgs a, const uint32_t *__restrict__ heavy, uint32_t nheavy) {
@@ -447,6 +457,9 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgs a, const ui
     const uint64_t Ltot = L.loff[ns];
     for (uint64_t x0 = kExpandQuota + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; x0 < Ltot; x0 += (uint64_t)gridDim.x * 256 * 16)
       expand_16(a, L, t0, ns, base, x0, Ltot);
+    if (a.want_sa)
+      for (uint64_t x = kExpandQuota + (uint64_t)blockIdx.x * 256 + threadIdx.x; x < Ltot; x += (uint64_t)gridDim.x * 256)
+        expand_sa_1(a, L, t0, ns, base, x);
   }
 }
 
