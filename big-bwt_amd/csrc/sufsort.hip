@@ -521,13 +521,28 @@ __global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t 
   if (i != piv) {
     settled = 0;
     const uint8_t *pa = s + i + from, *pp = s + piv + from;
-    bool done = false;
-    for (uint32_t off = 0; off < cap && !done; off += 16) {
-      const uint4 xa = ld16u(pa + off), xp = ld16u(pp + off);
-      const uint64_t x[2] = {(uint64_t)xa.x | ((uint64_t)xa.y << 32), (uint64_t)xa.z | ((uint64_t)xa.w << 32)};
-      const uint64_t y[2] = {(uint64_t)xp.x | ((uint64_t)xp.y << 32), (uint64_t)xp.z | ((uint64_t)xp.w << 32)};
+    // skim 32 bytes per step until the strings differ or the member ends, then look inside that chunk
+    uint32_t off = 0;
+    uint4 xa0, xa1, xp0, xp1;
+    bool hit = false;
+    for (; off < cap; off += 32) {
+      xa0 = ld16u(pa + off); xa1 = ld16u(pa + off + 16); xp0 = ld16u(pp + off); xp1 = ld16u(pp + off + 16);
+      const uint32_t diff = (xa0.x ^ xp0.x) | (xa0.y ^ xp0.y) | (xa0.z ^ xp0.z) | (xa0.w ^ xp0.w) | (xa1.x ^ xp1.x) |
+                            (xa1.y ^ xp1.y) | (xa1.z ^ xp1.z) | (xa1.w ^ xp1.w);
+#define PFP_LT2(v) (((v) - 0x02020202u) & ~(v) & 0x80808080u)
+      const uint32_t term = PFP_LT2(xa0.x) | PFP_LT2(xa0.y) | PFP_LT2(xa0.z) | PFP_LT2(xa0.w) | PFP_LT2(xa1.x) | PFP_LT2(xa1.y) |
+                            PFP_LT2(xa1.z) | PFP_LT2(xa1.w);
+#undef PFP_LT2
+      if (diff | term) { hit = true; break; }
+    }
+    if (hit) {
+      const uint64_t x[4] = {(uint64_t)xa0.x | ((uint64_t)xa0.y << 32), (uint64_t)xa0.z | ((uint64_t)xa0.w << 32),
+                             (uint64_t)xa1.x | ((uint64_t)xa1.y << 32), (uint64_t)xa1.z | ((uint64_t)xa1.w << 32)};
+      const uint64_t y[4] = {(uint64_t)xp0.x | ((uint64_t)xp0.y << 32), (uint64_t)xp0.z | ((uint64_t)xp0.w << 32),
+                             (uint64_t)xp1.x | ((uint64_t)xp1.y << 32), (uint64_t)xp1.z | ((uint64_t)xp1.w << 32)};
+      bool done = false;
 #pragma unroll
-      for (int q = 0; q < 2 && !done; q++) {
+      for (int q = 0; q < 4 && !done; q++) {
         const uint64_t tb = (x[q] - 0x0202020202020202ull) & ~x[q] & 0x8080808080808080ull;   // bytes < 2; lowest flag exact
         if (x[q] == y[q]) { if (tb) { settled = finbit; done = true; } continue; }
         const int fd = __builtin_ctzll(x[q] ^ y[q]) >> 3;
