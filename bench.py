@@ -245,6 +245,12 @@ def main():
         except Exception:
             pass
         scan_row = next((x for x in rows if x["kernel"] == "pfp::kr_flag_kernel"), None)
+        if scan_row is not None:
+            # exact rolling Karp-Rabin: ~20 VALU instructions per text byte (byte extracts, one 40-bit Barrett
+            # reduction, the divisibility test, mask update).  256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T
+            # lane-instructions/s put this kernel's ceiling at ~1.97 TB/s of text, a quarter of the HBM peak.
+            scan_row = dict(scan_row, valu_bound_GBps=1966.0, frac_of_valu_bound=round(scan_row["achieved_GBps"] / 1966.0, 4),
+                            note="VALU-bound: ~20 instructions per byte; HBM peak is not reachable for this arithmetic")
         # the host-buffer entry point (pageable H2D of the text + D2H of the .bwt included): reported, never `value`
         host_boundary, host_ok = None, None
         if world == 1:
