@@ -105,7 +105,10 @@ def test_distributed_chain_matches_oracle(O, pkg, R, shard_sa, nblock):
             res = d.simulate(ctxs, shards, 10, 100, flags, halo=4096, shard_sa=shard_sa)
             assert res[0]["stats"]["extra_triggers"] >= (1 if nblock else 0)
             shares = {r["stats"]["sa_shares"] for r in res}
-            assert shares == ({R} if (shard_sa and not nblock) else ({1} if not shard_sa else shares & {1, R})) and len(shares) == 1
+            # debugging switches that turn pivot rounds off make every range fall back to the replicated sort
+            hobbled = any(os.environ.get(k) for k in ("PFP_NO_FINFLAG", "PFP_PIVOT_CAP"))
+            must_shard = shard_sa and not nblock and not hobbled
+            assert shares == ({R} if must_shard else ({1} if not shard_sa else shares & {1, R})) and len(shares) == 1
             assert all(res[k]["hi"] == res[k + 1]["lo"] for k in range(R - 1))
             bwt = torch.cat([r["bwt"] for r in res]).cpu().numpy()
             want = O.bigbwt(text, 10, 100, flags)
