@@ -511,7 +511,7 @@ constexpr uint32_t kPivCapMax = 8192;
 __global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t m, uint64_t from, uint32_t cap,
                                         const uint32_t *__restrict__ act_i, const uint32_t *__restrict__ act_grp,
                                         const uint32_t *__restrict__ sa, uint32_t finbit, uint64_t *__restrict__ key,
-                                        uint32_t *__restrict__ val) {
+                                        uint32_t *__restrict__ key32, uint32_t *__restrict__ val) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const uint32_t i = act_i[a], grp = act_grp[a];
@@ -557,16 +557,19 @@ __global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t 
     }
     // not done: still equal to P after cap bytes -> P's class, without the settled bit
   }
-  key[a] = ((uint64_t)grp << kPivBits) | ok;
+  if (key32) key32[a] = ok;                 // segmented sort: the group is the segment, only the order key is sorted
+  else key[a] = ((uint64_t)grp << kPivBits) | ok;
   val[a] = i | settled;
 }
 // a member of P's class without the settled bit (equal to P for cap bytes, unknown beyond): nobody in
 // that class may settle this round
-__global__ void pivot_veto_kernel(uint64_t m, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val,
-                                  const uint32_t *__restrict__ newhead, uint32_t finbit, uint8_t *__restrict__ veto) {
+__global__ void pivot_veto_kernel(uint64_t m, const uint64_t *__restrict__ key, const uint32_t *__restrict__ key32,
+                                  const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead, uint32_t finbit,
+                                  uint8_t *__restrict__ veto) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
-  if (((uint32_t)key[a] & ((1u << kPivBits) - 1)) == kPivEq && !(val[a] & finbit)) veto[newhead[a]] = 1;
+  const uint32_t ok = key32 ? key32[a] : ((uint32_t)key[a] & ((1u << kPivBits) - 1));
+  if (ok == kPivEq && !(val[a] & finbit)) veto[newhead[a]] = 1;
 }
 
 // write the refined order back and decide which suffixes stay unresolved.
@@ -683,8 +686,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       if (pivot_round) {
         if (!veto.p) veto.alloc(c, N);
         veto.zero();
-        hipLaunchKernelGGL(pivot_veto_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, valo.p, newhead.p, out.finbit,
-                           veto.p);
+        hipLaunchKernelGGL(pivot_veto_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p,
+                           seg_round ? k32o.p : (const uint32_t *)nullptr, valo.p, newhead.p, out.finbit, veto.p);
       }
       // previous group head of the element now at a: the high part of its sort key, or (segmented
       // rounds keep every element inside its segment) the group of list position a.  The first round
@@ -759,10 +762,25 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     seg_round = false;
     pivot_round = pivot_ok && g.mode == MODE_DICT && out.finbit && kPivotCap >= 16 && ngrp && m / ngrp <= kPivotAvg;
     if (pivot_round) {
+      // large families (a collection of hundreds of copies): the members are already grouped, a
+      // segmented sort of the 23-bit order key moves 16 B per suffix instead of 7 x 24 B
+      bool seg = false;
+      uint32_t ng = 0;
+      if (use_segsort && m >= (1u << 20) && m / ngrp >= 24) {
+        if (!gs.p) { gs.alloc(c, N); k32.alloc(c, N); k32o.alloc(c, N); segb.alloc(c, N + 1); sege.alloc(c, N + 1); nseg_d.alloc(c, 2); }
+        hipLaunchKernelGGL(group_starts_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, act_grp.p, gs.p);
+        select_index_u32(c, gs.p, segb.p, nseg_d.p, m);
+        PFP_HIP(hipMemsetAsync(nseg_d.p + 1, 0, 4, c->stream));
+        ng = read_scalar(c, nseg_d.p);
+        hipLaunchKernelGGL(seg_end_kernel, dim3(cdiv(ng, TB)), dim3(TB), 0, c->stream, ng, (uint32_t)m, segb.p, sege.p,
+                           nseg_d.p + 1);
+        seg = read_scalar(c, nseg_d.p + 1) <= (1u << 15) && m / ng >= 24;
+      }
       { KScope ks(c, "pfp::build_keys_pivot_kernel", m * (4 + 4 + 4 + 12 + 64));
         hipLaunchKernelGGL(build_keys_pivot_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, out.bytes, m, h, piv_cap, act_i.p,
-                           act_grp.p, out.sa.p, out.finbit, key.p, val.p); }
-      sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, nb + kPivBits);
+                           act_grp.p, out.sa.p, out.finbit, key.p, seg ? k32.p : (uint32_t *)nullptr, val.p); }
+      if (seg) { segsort_pairs_u32_u32(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, kPivBits); seg_round = true; }
+      else sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, nb + kPivBits);
       out.rounds++;
       (void)was_pivot;
       continue;                 // the sorted prefix common to all groups is still h: no doubling of h
