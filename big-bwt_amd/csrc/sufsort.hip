@@ -706,7 +706,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
                           tile_off.alloc(c, cdiv64(N, kTile) + 1); tile_hoff.alloc(c, cdiv64(N, kTile) + 1); }
       PFP_HIP(hipMemsetAsync(tile_keep.p + ntile, 0, 4, c->stream));
       PFP_HIP(hipMemsetAsync(tile_heads.p + ntile, 0, 4, c->stream));
-      KScope ks(c, "pfp::compact3_kernel", m * 2 + 0);
+      KScope ks(c, "pfp::compact3_kernel", m * 2 + 0);      // label kept from the kernel this replaced (profiles compare rounds)
       hipLaunchKernelGGL(active_count_kernel, dim3((unsigned)cdiv64(ntile, 16)), dim3(256), 0, c->stream, keep.p, hd.p, m,
                          tile_keep.p, tile_heads.p);
       exclusive_sum_u32(c, tile_keep.p, tile_off.p, ntile + 1);
@@ -766,7 +766,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       // segmented sort of the 23-bit order key moves 16 B per suffix instead of 7 x 24 B
       bool seg = false;
       uint32_t ng = 0;
-      if (use_segsort && m >= (1u << 20) && m / ngrp >= 24) {
+      static const uint32_t seg_min_avg = []() { const char *e = getenv("PFP_SEG_MINAVG"); return e ? (uint32_t)atoi(e) : 24u; }();
+      if (use_segsort && m >= (1u << 20) && m / ngrp >= seg_min_avg) {
         if (!gs.p) { gs.alloc(c, N); k32.alloc(c, N); k32o.alloc(c, N); segb.alloc(c, N + 1); sege.alloc(c, N + 1); nseg_d.alloc(c, 2); }
         hipLaunchKernelGGL(group_starts_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, act_grp.p, gs.p);
         select_index_u32(c, gs.p, segb.p, nseg_d.p, m);
@@ -774,7 +775,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
         ng = read_scalar(c, nseg_d.p);
         hipLaunchKernelGGL(seg_end_kernel, dim3(cdiv(ng, TB)), dim3(TB), 0, c->stream, ng, (uint32_t)m, segb.p, sege.p,
                            nseg_d.p + 1);
-        seg = read_scalar(c, nseg_d.p + 1) <= (1u << 15) && m / ng >= 24;
+        seg = read_scalar(c, nseg_d.p + 1) <= (1u << 15) && m / ng >= seg_min_avg;
       }
       { KScope ks(c, "pfp::build_keys_pivot_kernel", m * (4 + 4 + 4 + 12 + 64));
         hipLaunchKernelGGL(build_keys_pivot_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, out.bytes, m, h, piv_cap, act_i.p,
