@@ -580,8 +580,8 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
                                   const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead,
                                   const uint8_t *__restrict__ hd, uint32_t finbit, const uint64_t *__restrict__ prevkey,
                                   int prevshift, const uint32_t *__restrict__ prevgrp, const uint8_t *__restrict__ veto,
-                                  uint32_t *__restrict__ sa, uint32_t *__restrict__ rank, uint32_t *__restrict__ grp,
-                                  uint8_t *__restrict__ keep) {
+                                  const uint8_t *__restrict__ lazy_bytes, uint32_t *__restrict__ sa,
+                                  uint32_t *__restrict__ rank, uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const uint32_t iv = val[a], i = iv & ~finbit;
@@ -598,8 +598,27 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
   // rank[i] already holds the old group head: a suffix that stays unresolved in a group that kept
   // its head needs no write - the scattered 4-byte store is the expensive access of this kernel
   const uint32_t old = prevkey ? (uint32_t)(prevkey[a] >> prevshift) : (prevgrp ? prevgrp[a] : ~newhead[a]);
-  if (!k || old != newhead[a]) rank[i] = newhead[a] | (k ? 0u : finbit);
+  // Pivot rounds (lazy_bytes != null) do not read rank[], so the rank of a suffix that settles there is
+  // written only if somebody will ask for it - the whole words, whose ranks order the dictionary
+  // (compute_lexrank); every other settled rank is filled in by repair_ranks_kernel if a doubling
+  // round follows after all.  One byte read replaces the scattered 4-byte store.
+  bool wr = k ? old != newhead[a] : true;
+  if (!k && lazy_bytes) wr = i == 0 || lazy_bytes[i - 1] == kEndOfWord;
+  if (wr) rank[i] = newhead[a] | (k ? 0u : finbit);
   keep[a] = k ? 1 : 0;
+}
+
+// ranks that pivot rounds left unwritten: every slot re-ordered after the first round that is not in
+// the active list any more holds a settled suffix
+__global__ void mark_slots_kernel(uint64_t m, const uint32_t *__restrict__ aslot, uint8_t *__restrict__ flag) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < m) flag[aslot[a]] = 1;
+}
+__global__ void repair_ranks_kernel(uint64_t N, const uint8_t *__restrict__ refined, const uint8_t *__restrict__ active,
+                                    const uint32_t *__restrict__ sa, const uint32_t *__restrict__ grp, uint32_t finbit,
+                                    uint32_t *__restrict__ rank) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < N && refined[t] && !active[t]) rank[sa[t]] = grp[t] | finbit;
 }
 
 // after the first round, pivot rounds are tried while the groups are families (average size up to
@@ -656,6 +675,18 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   bool pivot_ok = true;
   bool lazy_pending = false;    // dictionary mode: rank[] of the suffixes settled by the first round not scattered (yet)
   DBuf<uint8_t> veto, keep0;
+  static const bool lazy_pivot_ranks = getenv("PFP_EAGER_PIVOT_RANKS") == nullptr;
+  bool ranks_stale = false;     // pivot rounds skipped rank[] of settled suffixes that are not whole words
+  auto repair_ranks = [&](uint64_t m_active, const uint32_t *aslot_list) {
+    if (!ranks_stale) return;
+    DBuf<uint8_t> act(c, N);
+    act.zero();
+    if (m_active) hipLaunchKernelGGL(mark_slots_kernel, dim3(cdiv(m_active, TB)), dim3(TB), 0, c->stream, m_active, aslot_list, act.p);
+    KScope ks(c, "pfp::write_back_kernel", N * 6);
+    hipLaunchKernelGGL(repair_ranks_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, keep0.p, act.p, out.sa.p, out.grp.p,
+                       out.finbit, out.rank.p);
+    ranks_stale = false;
+  };
   DBuf<uint32_t> tile_keep, tile_heads, tile_off, tile_hoff;
   uint32_t piv_cap = kPivotCap;  // bytes compared per member in the next pivot round
   bool long_cap_tried = false;
@@ -697,7 +728,10 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       hipLaunchKernelGGL(write_back_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p,
                          newhead.p, hd.p, out.finbit, (have_prev && !seg_round) ? keyo.p : (const uint64_t *)nullptr,
                          pivot_round ? kPivBits : nb, (have_prev && seg_round) ? act_grp.p : (const uint32_t *)nullptr,
-                         pivot_round ? veto.p : (const uint8_t *)nullptr, out.sa.p, out.rank.p, out.grp.p, keep.p);
+                         pivot_round ? veto.p : (const uint8_t *)nullptr,
+                         (pivot_round && lazy_pivot_ranks) ? out.bytes : (const uint8_t *)nullptr, out.sa.p, out.rank.p, out.grp.p,
+                         keep.p);
+      if (pivot_round && lazy_pivot_ranks) ranks_stale = true;
     }
     {
       // kept suffixes / kept group heads per tile -> offsets -> placement
@@ -796,8 +830,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
         if (!out.paybits) out.skeys.release();      // with payload the merge still reads the records from skeys
         out.tab.release();
       }
-      keep0.release();
     }
+    repair_ranks(m, aslot.p);                 // a doubling round reads rank[] of arbitrary positions
     const RankView L = rank_view(out);
     if (use_segsort && m >= (1u << 20) && ngrp && m / ngrp >= 24) {
       if (!gs.p) { gs.alloc(c, N); k32.alloc(c, N); k32o.alloc(c, N); segb.alloc(c, N + 1); sege.alloc(c, N + 1); nseg_d.alloc(c, 2); }
@@ -825,6 +859,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
     h *= 2;
     out.rounds++;
   }
+  // PFP_DEBUG validates the rank of every position: fill in what the pivot rounds left out
+  if (c->debug && out.complete) repair_ranks(0, nullptr);
 }
 
 __global__ void gather_ranks_kernel(RankView L, uint64_t count, const uint64_t *__restrict__ pos, uint32_t *__restrict__ out) {
