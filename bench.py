@@ -44,6 +44,8 @@ WORKLOADS = {
                 desc="512x mutated yeast-shaped FASTA (~6.3 GB > 2^32 bytes), -w 10 -p 100, BWT only (robustness / scaling probe)"),
     "huge": dict(G=12_100_020, C=1024, r=1e-3, nblocks=[], w=10, p=100, flags=0,
                  desc="1024x mutated yeast-shaped FASTA (~12.6 GB; the north star's >= 10 GB repetitive input on one GPU), BWT only"),
+    "c4s": dict(G=12_100_020, C=16, r=1e-3, nblocks=[], w=10, p=100, flags=1,
+                desc="BASELINE configs[3] parameters (-w 10 -p 100 -S, full SA) on a 16-copy, 0.2 GB stand-in (parity probe, not a reportable number)"),
     "c5s": dict(G=12_100_020, C=16, r=1e-3, nblocks=[], w=12, p=200, flags=2,
                 desc="BASELINE configs[4] parameters (-w 12 -p 200 -s) on a 16-copy, 0.2 GB stand-in (parity probe, not a reportable number)"),
     "small": dict(G=6_000_000, C=4, r=1e-3, nblocks=[(1_000_000, 300_000)], w=10, p=100, flags=0,
