@@ -809,6 +809,7 @@ int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last
     // the held slots are one contiguous range of SA(D): they emit exactly [out_lo, out_hi)
     PFP_REQUIRE(ds->so.complete, PFP_EINVAL, "this share of the suffix array is incomplete: redo pfp_dist_global_sort with parts = 1");
     PFP_REQUIRE(out_hi - out_lo == ds->local_total, PFP_EINVAL, "output range does not match this share's occurrence count");
+    if (ds->so.N == 0) { sync(c); return PFP_OK; }      // an empty share of the key space emits nothing
     merge_bwt(c, ds->G, ds->ix, ds->so, pb, ds->occ_lex.p, ds->w, flags, ds->local_total, bo, 0, ~0ull, out_lo, n_total + 1);
   } else {
     merge_bwt(c, ds->G, ds->ix, ds->so, pb, ds->occ_lex.p, ds->w, flags, n_total + 1, bo, out_lo, out_hi);

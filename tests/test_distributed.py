@@ -124,6 +124,27 @@ def test_distributed_chain_matches_oracle(O, pkg, R, shard_sa, nblock):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R", [4, 6])
+def test_many_ranks_on_a_tiny_dictionary(O, pkg, R):
+    """a dictionary of ~120 suffixes split over 4-6 key ranges (shares of a few dozen slots, emit counts from 1 up)"""
+    import importlib
+    d = importlib.import_module("bigbwt_amd.dist")
+    t = np.frombuffer((b"ACGTACGTTTGACA" * 40 + b"GGGTTTAAACCC" * 30) * 3, dtype=np.uint8).copy()
+    cuts = [len(t) * r // R for r in range(R + 1)]
+    ctxs = [pkg.Context(0) for _ in range(R)]
+    try:
+        shards = [torch.from_numpy(t[cuts[r]:cuts[r + 1]].copy()).cuda() for r in range(R)]
+        res = d.simulate(ctxs, shards, 4, 11, pkg.FLAG_SA, halo=256)
+        want = O.bigbwt(t, 4, 11, O.FLAG_SA)
+        assert np.array_equal(torch.cat([r["bwt"] for r in res]).cpu().numpy(), want["bwt"])
+        assert np.array_equal(torch.cat([r["sa"] for r in res]).cpu().numpy().astype(np.uint64)[1:], want["sa"])
+        assert sum(r["hi"] - r["lo"] for r in res) == len(t) + 1
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.gpu
 def test_sharded_sort_falls_back_when_a_range_cannot_finish(O, pkg, monkeypatch):
     """a dictionary word with a long exact repeat (an N run cut into 20 kB phrases) leaves a group that
     pivot rounds cannot settle inside one key range: all ranks fall back to the replicated sort"""
