@@ -333,10 +333,17 @@ struct MergeArgs {
   uint64_t pos_base, n_out_global;   // global BWT position of local position 0; global n+1 (== n_out unless the slots are one rank's range)
   uint64_t out_lo, out_hi;   // this call emits BWT positions [out_lo,out_hi) only (multi-GPU slices); bwt/out_sa are indexed by global position
   const uint32_t *sa, *endpos, *grp, *ist, *pos_word, *wistart;
-  const uint8_t *pc, *hard; const uint64_t *off;
+  const uint8_t *pc, *hard;
+  const uint64_t *tbase; const uint32_t *loc;    // output offset of slot t = tbase[t >> 11] + loc[t] (slot_off)
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
   uint8_t *bwt; uint64_t *out_sa;
 };
+// Exclusive prefix of the per-slot counts, kept as a 64-bit base per 2048 slots (= one expand workgroup) and a
+// 32-bit offset inside the tile: 4 bytes per slot to write and read instead of 8, and the N-long scan
+// becomes one streaming tile kernel plus a scan over N/2048 sums.
+constexpr int kOffTileLog = 11;
+__device__ __forceinline__ uint64_t slot_off(const MergeArgs &a, uint64_t t) { return a.tbase[t >> kOffTileLog] + a.loc[t]; }
+
 
 __device__ __forceinline__ uint8_t fix_char(uint8_t ch) { return ch == kDollar ? 0 : ch; }  // pfbwt.cpp:126
 // start of slot t's word in ilist: stored per slot when SA values are wanted, looked up otherwise
@@ -364,7 +371,7 @@ struct ExpandLds {
 };
 
 __device__ __forceinline__ void expand_stage(const MergeArgs &a, ExpandLds &L, uint64_t t0, int ns, uint64_t base) {
-  for (int s = threadIdx.x; s <= ns; s += 256) L.loff[s] = a.off[t0 + s] - base;
+  for (int s = threadIdx.x; s <= ns; s += 256) L.loff[s] = slot_off(a, t0 + s) - base;
   for (int s = threadIdx.x; s < ns; s += 256) {
     uint8_t ch = a.pc[t0 + s];
     L.lpc[s] = ch;
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(256) void expand_kernel(MergeArgs a, uint32_t *__re
   __shared__ ExpandLds L;
   const uint64_t t0 = (uint64_t)blockIdx.x * kSlots;
   const int ns = (a.N - t0) >= (uint64_t)kSlots ? kSlots : (int)(a.N - t0);
-  const uint64_t base = a.off[t0];
+  const uint64_t base = slot_off(a, t0);
   expand_stage(a, L, t0, ns, base);
   const uint64_t Ltot = L.loff[ns];
   if (base + Ltot <= a.out_lo || base >= a.out_hi) return;
@@ -451,7 +458,7 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgs a, const ui
   for (uint32_t q = 0; q < nheavy; q++) {
     const uint64_t t0 = (uint64_t)heavy[q] * kSlots;
     const int ns = (a.N - t0) >= (uint64_t)kSlots ? kSlots : (int)(a.N - t0);
-    const uint64_t base = a.off[t0];
+    const uint64_t base = slot_off(a, t0);
     __syncthreads();
     expand_stage(a, L, t0, ns, base);
     const uint64_t Ltot = L.loff[ns];
@@ -518,8 +525,8 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, const uin
       g = heads[hidx];
       uint32_t kk = 0;
       while (g + kk < a.N && a.grp[g + kk] == (uint32_t)g && a.pc[g + kk] != 0) kk++;
-      base = a.off[g];
-      const uint64_t Eg = a.off[g + kk] - base;
+      base = slot_off(a, g);
+      const uint64_t Eg = slot_off(a, g + kk) - base;
       if (kk && !(base + Eg <= a.out_lo || base >= a.out_hi)) {      // inside this rank's slice
         my_chars += Eg; my_groups += 1;
         const bool sorted_path = a.dbg_mode ? a.dbg_mode == 3 : Eg > (uint64_t)kHardSortMin;
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, const uin
         int lo = 0, hi = nG;                       // gk0[lo] <= q < gk0[hi]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.gk0[mid] <= q) lo = mid; else hi = mid; }
         const uint64_t t = (uint64_t)L.ghead[lo] + (q - L.gk0[lo]);
-        L.lmoff[q] = L.geoff[lo] + (uint32_t)(a.off[t] - L.gbase[lo]);
+        L.lmoff[q] = L.geoff[lo] + (uint32_t)(slot_off(a, t) - L.gbase[lo]);
         L.lmist[q] = slot_ist(a, t);
         uint32_t sl = 0;
         if (a.want_sa) { const uint32_t i = a.sa[t]; sl = a.endpos[i] - i; }
@@ -626,15 +633,15 @@ __global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgs a, const BigGr
   for (uint32_t qi = blockIdx.x * 4 + wv; qi < nmid; qi += gridDim.x * 4) {
     const uint64_t g = mid[qi].g;
     const uint32_t E = (uint32_t)mid[qi].E, k = mid[qi].k;
-    const uint64_t base = a.off[g];
+    const uint64_t base = slot_off(a, g);
     uint32_t n = 64;
     while (n < E) n <<= 1;
     for (uint32_t e = lane; e < n; e += 64) {
       uint64_t key = ~0ull;
       if (e < E) {
         uint32_t lo = 0, hi = k;                 // member holding occurrence e: off[g+lo] - base <= e
-        while (hi - lo > 1) { const uint32_t mdl = (lo + hi) >> 1; if (a.off[g + mdl] - base <= e) lo = mdl; else hi = mdl; }
-        const uint32_t pos = a.ilist[slot_ist(a, g + lo) + (e - (uint32_t)(a.off[g + lo] - base))];
+        while (hi - lo > 1) { const uint32_t mdl = (lo + hi) >> 1; if (slot_off(a, g + mdl) - base <= e) lo = mdl; else hi = mdl; }
+        const uint32_t pos = a.ilist[slot_ist(a, g + lo) + (e - (uint32_t)(slot_off(a, g + lo) - base))];
         key = ((uint64_t)pos << 16) | e;
       }
       K[e] = key;
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgs a, const BigGr
       const uint64_t o = base + r;
       if (o < a.out_lo || o >= a.out_hi) continue;
       uint32_t lo = 0, hi = k;
-      while (hi - lo > 1) { const uint32_t mdl = (lo + hi) >> 1; if (a.off[g + mdl] - base <= e) lo = mdl; else hi = mdl; }
+      while (hi - lo > 1) { const uint32_t mdl = (lo + hi) >> 1; if (slot_off(a, g + mdl) - base <= e) lo = mdl; else hi = mdl; }
       const uint64_t t = g + lo;
       a.bwt[o] = fix_char(a.pc[t]);
       if (a.want_sa) { const uint32_t i = a.sa[t]; a.out_sa[o] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i); }
@@ -673,17 +680,17 @@ __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgs a, const BigGro
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (estart[mid] <= ge) lo = mid; else hi = mid; }
     const uint64_t g = big[lo].g, e = ge - estart[lo];
     const uint32_t k = big[lo].k;
-    const uint64_t base = a.off[g];
+    const uint64_t base = slot_off(a, g);
     uint32_t ml = 0, mh = k;                  // member holding occurrence e
-    while (mh - ml > 1) { uint32_t mid = (ml + mh) >> 1; if (a.off[g + mid] - base <= e) ml = mid; else mh = mid; }
+    while (mh - ml > 1) { uint32_t mid = (ml + mh) >> 1; if (slot_off(a, g + mid) - base <= e) ml = mid; else mh = mid; }
     const uint64_t t = g + ml;
-    const uint32_t j = (uint32_t)(e - (a.off[t] - base));
+    const uint32_t j = (uint32_t)(e - (slot_off(a, t) - base));
     const uint32_t pos = a.ilist[slot_ist(a, t) + j];
     uint64_t r = j;
     for (uint64_t t2 = g; t2 < g + k; t2++) {
       if (t2 == t) continue;
       const uint32_t *lst = a.ilist + slot_ist(a, t2);
-      uint32_t l2 = 0, h2 = (uint32_t)(a.off[t2 + 1] - a.off[t2]);      // # entries < pos
+      uint32_t l2 = 0, h2 = (uint32_t)(slot_off(a, t2 + 1) - slot_off(a, t2));      // # entries < pos
       while (l2 < h2) { uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
       r += l2;
     }
@@ -691,6 +698,37 @@ __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgs a, const BigGro
       a.bwt[base + r] = fix_char(a.pc[t]);
       if (a.want_sa) { const uint32_t i = a.sa[t]; a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i); }
     }
+  }
+}
+
+// loc[t] = sum of cnt over the slots of t's tile before t; tsum[tile] = the tile's total.  256 threads x 8 slots.
+__global__ __launch_bounds__(256) void slot_loc_kernel(const uint32_t *__restrict__ cnt, uint64_t N, uint32_t *__restrict__ loc,
+                                                       uint64_t *__restrict__ tsum, uint32_t *__restrict__ overflow) {
+  __shared__ uint64_t ws[4];
+  const uint64_t t0 = ((uint64_t)blockIdx.x << kOffTileLog) + (uint64_t)threadIdx.x * 8;
+  uint32_t v[8];
+  if (t0 + 8 <= N) {
+    const uint4 x = *reinterpret_cast<const uint4 *>(cnt + t0), y = *reinterpret_cast<const uint4 *>(cnt + t0 + 4);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+  } else {
+    for (int k = 0; k < 8; k++) v[k] = t0 + k < N ? cnt[t0 + k] : 0u;
+  }
+  uint64_t own = 0;
+  for (int k = 0; k < 8; k++) own += v[k];
+  uint64_t inc = own;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+  if (lane == 63) ws[wv] = inc;
+  __syncthreads();
+  uint64_t run = inc - own;
+  for (int q = 0; q < wv; q++) run += ws[q];
+  uint32_t o8[8];
+  for (int k = 0; k < 8; k++) { o8[k] = (uint32_t)run; run += v[k]; }
+  *reinterpret_cast<uint4 *>(loc + t0) = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+  *reinterpret_cast<uint4 *>(loc + t0 + 4) = make_uint4(o8[4], o8[5], o8[6], o8[7]);
+  if (threadIdx.x == 255) {
+    tsum[blockIdx.x] = run;
+    if (run >> 32) atomicOr(overflow, 1u);      // a tile's offsets would not fit 32 bits
   }
 }
 
@@ -715,7 +753,9 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   const bool from_keys = !flags && so.paybits == 16 && so.skeys.p && so.n_refined * 5 < N;
   if (flags) { ist.alloc(c, N + 8); pp64.alloc(c, NP); } else if (!from_keys) pp16.alloc(c, NP);
   DBuf<uint8_t> pc(c, N + 8), hard(c, N);
-  DBuf<uint64_t> off(c, N + 1);
+  const uint64_t ntile = (N >> kOffTileLog) + 1;        // covers slot index N (one past the last)
+  DBuf<uint32_t> loc(c, ntile << kOffTileLog), ovf(c, 1);
+  DBuf<uint64_t> tsum(c, ntile + 1), tbase(c, ntile + 1);
   PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream));
   hard.zero();
   if (from_keys) {
@@ -735,10 +775,15 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     else hipLaunchKernelGGL(slot_gather_kernel<uint16_t>, grid, dim3(256), 0, c->stream, N, so.sa.p, pp16.p,
                             ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, (uint32_t *)nullptr); }
   }
-  exclusive_sum_u32_u64(c, cnt.p, off.p, N + 1);
+  ovf.zero();
+  PFP_HIP(hipMemsetAsync(tsum.p + ntile, 0, 8, c->stream));
+  { KScope ks(c, "pfp::slot_loc_kernel", N * 8);
+    hipLaunchKernelGGL(slot_loc_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, cnt.p, N, loc.p, tsum.p, ovf.p); }
+  exclusive_sum_u64(c, tsum.p, tbase.p, ntile + 1);
   { KScope ks(c, "pfp::group_flags_kernel", N * 5);
   hipLaunchKernelGGL(group_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.grp.p, pc.p, flags ? 1 : 0, hard.p); }
-  const uint64_t n_out = read_scalar(c, off.p + N);
+  PFP_REQUIRE(read_scalar(c, ovf.p) == 0, PFP_ELIMIT, "2048 consecutive suffix-array slots emit 2^32 or more BWT positions");
+  const uint64_t n_out = read_scalar(c, tbase.p + ntile);
   PFP_REQUIRE(expect_n_out == 0 || n_out == expect_n_out, PFP_EFORMAT,
               "merge: sum of occurrence counts (" + std::to_string(n_out) + ") != text length + 1 (" +
                   std::to_string(expect_n_out) + ")");
@@ -749,7 +794,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
   a.sa = so.sa.p; a.endpos = ix.endpos.p; a.grp = so.grp.p; a.ist = flags ? ist.p : nullptr;
   a.pos_word = ix.pos_word.p; a.wistart = wistart.p;
-  a.pc = pc.p; a.hard = hard.p; a.off = off.p;
+  a.pc = pc.p; a.hard = hard.p; a.tbase = tbase.p; a.loc = loc.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p;
   // the caller's buffers hold positions [out_lo, out_hi): rebase so that kernels index by global position
   a.out_lo = out_lo; a.out_hi = out_hi < n_out ? out_hi : n_out;
