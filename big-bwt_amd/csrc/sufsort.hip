@@ -386,12 +386,14 @@ __global__ __launch_bounds__(256) void active_count_kernel(const uint8_t *__rest
   if ((threadIdx.x & 15) == 0 && base < m) { tile_keep[t >> 4] = ck; tile_heads[t >> 4] = ch; }
 }
 __global__ __launch_bounds__(256) void active_place_kernel(const uint8_t *__restrict__ keep, uint64_t m,
+                                                           const uint32_t *__restrict__ tile_keep,
                                                            const uint32_t *__restrict__ tile_off,
                                                            const uint32_t *__restrict__ aslot, const uint32_t *__restrict__ val,
                                                            const uint32_t *__restrict__ newhead, uint32_t finbit,
                                                            uint32_t *__restrict__ aslot2, uint32_t *__restrict__ act_i,
                                                            uint32_t *__restrict__ act_grp) {
   __shared__ uint32_t ws[4];
+  if (tile_keep[blockIdx.x] == 0) return;       // nothing kept in these 256 positions (most tiles after the first round)
   const uint64_t a = (uint64_t)blockIdx.x * kTile + threadIdx.x;
   const bool k = a < m && keep[a];
   const unsigned long long mask = __ballot(k);
@@ -745,7 +747,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
                          tile_keep.p, tile_heads.p);
       exclusive_sum_u32(c, tile_keep.p, tile_off.p, ntile + 1);
       exclusive_sum_u32(c, tile_heads.p, tile_hoff.p, ntile + 1);
-      hipLaunchKernelGGL(active_place_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, keep.p, m, tile_off.p,
+      hipLaunchKernelGGL(active_place_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, keep.p, m, tile_keep.p, tile_off.p,
                          round0 ? (const uint32_t *)nullptr : aslot.p, valo.p, round0 ? out.grp.p : newhead.p, out.finbit, aslot2.p,
                          act_i.p, act_grp.p);
       PFP_HIP(hipGetLastError());
