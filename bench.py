@@ -1,25 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: input MB/s to a bit-exact .bwt on MI355X.
+"""bench.py -- headline benchmark: input MB/s to bit-exact .bwt (+ sampled SA files) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|huge|...]
 
-A "step" is one complete pass of the hot path (window scan -> phrase dedup -> dictionary suffix
-sort -> BWT of the parse -> merge) over one synthetic input that is already resident in HBM when
-the timed region starts, leaving the finished .bwt (and the SA values, for workloads that ask
-for them) in HBM.  Workload (BASELINE.json configs[1]): synthetic human-chr1-shaped FASTA,
-249e6 random ACGT bases with one 18 Mb and two 10 kb blocks of N, 60-column lines, one header,
--w 10 -p 100, BWT only (~253 MB).  One process per GPU.  For N > 1 the ranks build ONE BWT of a
-collection of N such chromosomes (rank r holds variant r of the same base sequence, 0.1 % SNPs -
-a pangenome slice per GPU, weak scaling): text shards + halo exchange, allgatherv of the local
-dictionaries and of the parse over RCCL, replicated dictionary/parse suffix sorts, output-range
-sharded merge (big-bwt_amd/dist.py).  `--multi independent` instead lets every rank build the BWT
-of its own text with no collective.
+A "step" is one complete pass of the hot path (window scan -> phrase dedup -> dictionary suffix sort
+-> BWT of the parse -> merge -> run sampling / 5-byte packing) over one synthetic input that is already
+resident in HBM when the timed region starts, leaving the finished reference-format outputs (.bwt
+bytes, and the .ssa/.esa/.sa bytes the workload's flags ask for) in HBM.  Default workload at N = 1:
+BASELINE.json configs[2], the largest single-GPU configuration (64 mutated copies of a yeast-sized
+genome, ~0.79 GB, -w 10 -p 100, BWT + -s -e).  `--workload c2` is configs[1] (chr1-shaped, 253 MB, BWT
+only), `--workload huge` / `huge_s` the north star's >= 10 GB repetitive input on one GPU.
+One process per GPU.  For N > 1 the ranks build ONE BWT of a collection of N such inputs (rank r holds
+variant r of the same base sequences - a pangenome slice per GPU, weak scaling) through
+big-bwt_amd/dist.py; `--multi independent` lets every rank build the BWT of its own text instead.
 
-Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the library's own
-stream, `cpu_baseline` is the real reference (oracle/_ref, built from the reference's sources)
-timed on this host on a bounded prefix of the same text.
+Rank 0 prints ONE JSON line.  `roofline` = the kernel with the largest share of the step, timed live
+with HIP events on the library's own stream; `roofline_passes` = SURVEY.md 8(d)'s per-pass algorithmic
+bytes over the measured pass times; `cpu_baseline` = the real reference (oracle/_ref: pscan.x -t N ->
+bwtparse -t N -> pfbwt[NT].x, N = host cores) timed on this host on a bounded prefix of the same text.
 """
 import argparse
+import hashlib
+import importlib
 import json
 import os
 import sys
@@ -34,78 +36,34 @@ import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6.3 TB/s
 
-WORKLOADS = {
-    # name: (G bases, copies, mutation rate, N blocks (start,len), w, p, flags, description)
-    "c2": dict(G=249_000_000, C=1, r=0.0, nblocks=[(120_000_000, 18_000_000), (30_000_000, 10_000), (200_000_000, 10_000)],
-               w=10, p=100, flags=0, desc="BASELINE configs[1]: 1x human-chr1-shaped FASTA (~253 MB), -w 10 -p 100, BWT only"),
-    "c3": dict(G=12_100_020, C=64, r=1e-3, nblocks=[], w=10, p=100, flags=6,
-               desc="BASELINE configs[2]: 64x mutated yeast-shaped FASTA (~0.79 GB), -w 10 -p 100, BWT + -s -e"),
-    "big": dict(G=12_100_020, C=512, r=1e-3, nblocks=[], w=10, p=100, flags=0,
-                desc="512x mutated yeast-shaped FASTA (~6.3 GB > 2^32 bytes), -w 10 -p 100, BWT only (robustness / scaling probe)"),
-    "huge": dict(G=12_100_020, C=1024, r=1e-3, nblocks=[], w=10, p=100, flags=0,
-                 desc="1024x mutated yeast-shaped FASTA (~12.6 GB; the north star's >= 10 GB repetitive input on one GPU), BWT only"),
-    "c4s": dict(G=12_100_020, C=16, r=1e-3, nblocks=[], w=10, p=100, flags=1,
-                desc="BASELINE configs[3] parameters (-w 10 -p 100 -S, full SA) on a 16-copy, 0.2 GB stand-in (parity probe, not a reportable number)"),
-    "c5s": dict(G=12_100_020, C=16, r=1e-3, nblocks=[], w=12, p=200, flags=2,
-                desc="BASELINE configs[4] parameters (-w 12 -p 200 -s) on a 16-copy, 0.2 GB stand-in (parity probe, not a reportable number)"),
-    "small": dict(G=6_000_000, C=4, r=1e-3, nblocks=[(1_000_000, 300_000)], w=10, p=100, flags=0,
-                  desc="reduced smoke workload (not a reportable number)"),
-}
+
+def sha_dev(t):
+    """sha256 of a device byte tensor (copied out in 256 MB pieces)"""
+    h = hashlib.sha256()
+    for s in range(0, t.numel(), 1 << 28):
+        h.update(t[s:s + (1 << 28)].cpu().numpy().tobytes())
+    return h.hexdigest()
 
 
-def make_text(dev, wl, seed, variant=0, variant_rate=1e-3):
-    """GEN-shaped synthetic FASTA built directly in HBM (SURVEY.md section 4 family; torch RNG).
-    variant > 0: the same base sequence with its own SNPs and header (one member of a collection)."""
-    G, C_, r = wl["G"], wl["C"], wl["r"]
-    assert G % 60 == 0
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    base = lut[torch.randint(0, 4, (G,), generator=gen, device=dev, dtype=torch.int64)]
-    for st, ln in wl["nblocks"]:
-        base[st:st + ln] = ord("N")
-    if variant > 0:
-        gen.manual_seed(seed * 7919 + variant)
-        k = int(G * variant_rate)
-        pos = torch.randint(0, G, (k,), generator=gen, device=dev)
-        keep = base[pos] != ord("N")
-        base[pos[keep]] = lut[torch.randint(0, 4, (int(keep.sum()),), generator=gen, device=dev, dtype=torch.int64)]
-    parts = []
-    nl = torch.full((G // 60, 1), ord("\n"), dtype=torch.uint8, device=dev)
-    for c in range(C_):
-        seq = base
-        if r > 0:
-            seq = base.clone()
-            k = int(G * r)
-            pos = torch.randint(0, G, (k,), generator=gen, device=dev)
-            seq[pos] = lut[torch.randint(0, 4, (k,), generator=gen, device=dev, dtype=torch.int64)]
-        parts.append(torch.tensor(list(b">copy%d\n" % (c + variant * C_)), dtype=torch.uint8, device=dev))
-        parts.append(torch.cat([seq.view(-1, 60), nl], dim=1).reshape(-1))
-    text = torch.cat(parts).contiguous()
-    del base, parts
-    return text
-
-
-def first_window_triggers(text, w, p, O):
-    return O.kr_window(bytes(text[:w].cpu().numpy().tobytes())) % p == 0
-
-
-def cpu_baseline(text_host, w, p, flags, O, sample_bytes):
-    """the real reference (newscanNT.x -> bwtparse -> pfbwtNT.x, 1 thread) on a prefix of the text"""
-    sample = text_host[:sample_bytes]
+def cpu_baseline(text_host, w, p, flags, O, threads):
+    """the real reference on a prefix of the text: pscan.x -t N -> bwtparse -t N -> pfbwt.x -t N (pfbwtNT.x
+    when -s/-e is asked for, as bigbwt:132,141 does)"""
     if O.have_ref():
-        r = O.run_ref(sample.tobytes(), w, p, flags, threads=0, want_intermediates=False)
+        r = O.run_ref(text_host.tobytes(), w, p, flags, threads=threads, want_intermediates=False)
         secs = sum(r["seconds"].values())
-        kind, bwt = "reference", np.frombuffer(r["bwt"], dtype=np.uint8)
+        kind = "reference"
+        outs = {k: np.frombuffer(r[k], dtype=np.uint8) for k in ("bwt", "sa", "ssa", "esa") if k in r}
         detail = {k: round(v, 3) for k, v in r["seconds"].items()}
+        cores = threads if threads > 0 else 1
     else:
         t0 = time.time()
-        bwt = O.bigbwt(sample, w, p, flags)["bwt"]
+        o = O.bigbwt(text_host, w, p, flags)
         secs = time.time() - t0
-        kind, detail = "port", {}
-    return dict(value=round(len(sample) / secs / 1e6, 3), unit="MB/s", cores=1, kind=kind,
-                sample=f"first {len(sample)} bytes of the same text, same flags; stages s: {detail}",
-                seconds=round(secs, 3)), bwt
+        kind, detail, cores = "port", {}, 1
+        outs = {"bwt": o["bwt"]}
+    return dict(value=round(len(text_host) / secs / 1e6, 3), unit="MB/s", cores=cores, kind=kind,
+                sample=f"first {len(text_host)} bytes of the same text, same flags, -t {threads}; stage seconds: {detail}",
+                seconds=round(secs, 3)), outs
 
 
 def main():
@@ -113,9 +71,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample-mb", type=float, default=40.0)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--cpu-sample-mb", type=float, default=100.0, help="prefix of the text the reference is timed on (0: whole text)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-boundary", action="store_true")
     ap.add_argument("--multi", default="collection", choices=["collection", "independent"],
                     help="N>1: one BWT of a sharded collection (RCCL exchanges) or one independent text per GPU")
     args = ap.parse_args()
@@ -137,43 +96,59 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     pkg = entry.load_package()          # fails loudly if libpfpgpu.so is missing
-    wl = WORKLOADS[args.workload]
-    w, p, flags = wl["w"], wl["p"], wl["flags"]
-    O = entry.load_oracle() if rank == 0 else None
-
+    synth = importlib.import_module("bigbwt_amd.synth")
     collection = world > 1 and args.multi == "collection"
-    seed = 2 if collection else 2 + 1000 * rank
-    while True:                                           # reject inputs whose first window triggers
-        text = make_text(dev, wl, seed, variant=rank if collection else 0)
-        bad = torch.tensor([1 if (rank == 0 and first_window_triggers(text, w, p, O)) else 0], dtype=torch.int64, device=dev)
-        if collection:
-            dist.broadcast(bad, src=0)                    # every shard derives from the same base seed
-        if int(bad.item()) == 0:
-            break
-        seed += 1
+    wl_name = args.workload or "c3"
+    wl = synth.WORKLOADS[wl_name]
+    w, p, flags = wl["w"], wl["p"], wl["flags"]
+    O = entry.load_oracle() if (rank == 0 and not args.no_cpu_baseline and world == 1) else None
+
+    # rank r holds variant r of the same base sequences (collection) or its own text (independent: other seed)
+    variant = rank if world > 1 else 0
+    text = synth.workload_text_torch(dev, wl_name, variant=variant)
     n = text.numel()
     bwt = torch.empty(n + 1 + 16, dtype=torch.uint8, device=dev)
     sa = torch.empty(n + 1, dtype=torch.int64, device=dev) if (flags and not collection) else None
     torch.cuda.synchronize()
 
     ctx = pkg.Context(local_rank)
-    dist_mod_pfp = None
-    last_result = {}
-    if collection:
-        import importlib
-        dist_mod_pfp = importlib.import_module("bigbwt_amd.dist")
+    dist_mod_pfp = importlib.import_module("bigbwt_amd.dist") if collection else None
+    last = {}
+    outbuf = {}          # reference-format outputs in HBM: sa5 / ssa / esa (sized by the first warm-up step)
 
-    def step():
+    def finish_formats(n_used, sizing=False):
+        """what pfbwt writes besides .bwt, from the device-resident BWT / SA values (inside the timed step)"""
+        n_out = n_used + 1
+        if flags & pkg.FLAG_SA:
+            if sizing:
+                outbuf["sa"] = torch.empty(5 * n_used + 16, dtype=torch.uint8, device=dev)
+            ctx.pack5_dev(sa.data_ptr() + 8, n_used, outbuf["sa"].data_ptr())
+            last["sa_bytes"] = 5 * n_used
+        for key, flag, run_end in (("ssa", pkg.FLAG_SSA, False), ("esa", pkg.FLAG_ESA, True)):
+            if not flags & flag:
+                continue
+            if sizing:
+                k = ctx.sample_runs_dev(bwt.data_ptr(), sa.data_ptr(), n_out, 0, -1, -1, run_end)
+                outbuf[key] = torch.empty(10 * k + 16, dtype=torch.uint8, device=dev)
+                outbuf[key + "_cap"] = k
+            k = ctx.sample_runs_dev(bwt.data_ptr(), sa.data_ptr(), n_out, 0, -1, -1, run_end, outbuf[key].data_ptr(), outbuf[key + "_cap"])
+            last[key + "_bytes"] = 10 * k
+
+    def step(sizing=False):
         if collection:
-            last_result["r"] = dist_mod_pfp.run(ctx, text, w, p, flags)
+            last["r"] = dist_mod_pfp.run(ctx, text, w, p, flags)
             return n
-        return ctx.bigbwt_dev(text.data_ptr(), n, bwt.data_ptr(), sa.data_ptr() if flags else None, w, p, flags)
+        used = ctx.bigbwt_dev(text.data_ptr(), n, bwt.data_ptr(), sa.data_ptr() if flags else None, w, p, flags)
+        last["n_used"] = used
+        finish_formats(used, sizing)
+        return used
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    step(sizing=True)
+    for _ in range(max(0, args.warmup - 1)):
         step()
     ctx.set_kernel_trace(True)          # HIP events around every kernel, on the library's own stream
     barrier(); torch.cuda.synchronize()
@@ -198,9 +173,13 @@ def main():
 
     # per-phase breakdown of one extra (untimed) profiled step
     ctx.set_profiling(True)
+    t1 = time.perf_counter()
     step()
+    torch.cuda.synchronize()
+    prof_ms = (time.perf_counter() - t1) * 1e3
     st = ctx.stats()
     ctx.set_profiling(False)
+    mem = ctx.mem_stats()
 
     # ---- correctness of what was just measured (outside the timed region)
     def hist(t):
@@ -210,7 +189,7 @@ def main():
         return h
     hist_t = hist(text)
     if collection:
-        res = last_result["r"]
+        res = last["r"]
         hist_b = hist(res["bwt"])
         dist.all_reduce(hist_t); dist.all_reduce(hist_b)
         hist_t[0] += 1
@@ -219,10 +198,24 @@ def main():
     else:
         hist_t[0] += 1
         hist_b = hist(bwt[: n + 1])
-    verified = bool(torch.equal(hist_t, hist_b))
+    permutation_ok = bool(torch.equal(hist_t, hist_b))
 
     out = None
     if rank == 0:
+        # ---- the measured device buffers against the reference's digests for this exact text (tests/golden/golden_full.json,
+        #      made by running oracle/_ref on the same synthetic text in the build container)
+        digests = None
+        if world == 1:
+            try:
+                gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_full.json"))).get(wl_name)
+            except Exception:
+                gold = None
+            if gold and gold["n"] == n:
+                digests = {"text": sha_dev(text) == gold["text_sha256"], "bwt": sha_dev(bwt[: n + 1]) == gold["bwt_sha256"]}
+                for key in ("sa", "ssa", "esa"):
+                    if key in outbuf and key + "_sha256" in gold:
+                        digests[key] = sha_dev(outbuf[key][: last[key + "_bytes"]]) == gold[key + "_sha256"]
+
         # ---- roofline: per-kernel device time measured live (HIP events on the ctx stream, timed steps)
         rows = []
         for r in ktable:
@@ -240,61 +233,98 @@ def main():
                         frac=dom["frac"], traffic=None, us_per_launch=dom["us_per_launch"],
                         launches_per_step=dom["launches_per_step"], algo_bytes_per_launch=dom["algo_bytes_per_launch"],
                         share_of_step=round(dom["ms_per_step"] / ms_per_step, 3))
-        # HBM traffic of that kernel from the committed PMC passes (same workload), per launch like `achieved`
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_pmc_traffic.json")))
-            if args.workload == "c2" and world == 1 and dom["kernel"] in pmc["kernels"]:
-                roofline["traffic"] = int(pmc["kernels"][dom["kernel"]]["hbm_bytes_per_chain_corrected"] / dom["launches_per_step"])
-                roofline["traffic_source"] = "profiles/r01_c2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; 2*FETCH+WRITE)"
-        except Exception:
-            pass
+        # HBM traffic of that kernel from the committed PMC passes of the same workload, per launch like `achieved`
+        for rnd in ("r02", "r01"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{wl_name}_pmc_traffic.json")))
+                if world == 1 and dom["kernel"] in pmc["kernels"]:
+                    roofline["traffic"] = int(pmc["kernels"][dom["kernel"]]["hbm_bytes_per_chain_corrected"] / dom["launches_per_step"])
+                    roofline["traffic_source"] = f"profiles/{rnd}_{wl_name}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; 2*FETCH+WRITE)"
+                    break
+            except Exception:
+                pass
+
+        # ---- per-pass fractions with SURVEY.md 8(d)'s algorithmic-byte formulas over the synced phase times of the profiled step
+        P, D_, H = st["n_phrases"], st["dict_size"], st["hard_chars"]
+        nn = st["n"] if not collection else n
+        R = {k: last.get(k + "_bytes", 0) // 10 for k in ("ssa", "esa")}
+        b_scan = nn + 8 * P
+        b_hash = nn + w * P + 8 * P
+        b_merge = (nn + 1) + 12 * D_ + 5 * (P + 1) + 8 * H
+        if flags & 1:
+            b_merge += 10 * nn
+        if flags & 6:
+            b_merge += 10 * (R["ssa"] + R["esa"]) + 5 * nn
+        ktime = {r["kernel"]: r["ms_per_step"] for r in rows}
+        t_hash = ktime.get("pfp::phrase_hash_kernel", 0.0)
+        t_formats = sum(ktime.get(k, 0.0) for k in ("pfp::run_count_kernel", "pfp::run_place_kernel", "pfp::pack5_kernel"))
+        t_merge = st["ms_merge"] + t_formats
+
+        def pass_row(nbytes, ms):
+            if ms <= 0:
+                return None
+            g = nbytes / (ms * 1e-3) / 1e9
+            return dict(algo_bytes=int(nbytes), ms=round(ms, 3), achieved_GBps=round(g, 1), frac=round(g / HBM_PEAK_GBS, 4))
+        passes = {"scan (K1+K2: n + 8P)": pass_row(b_scan, st["ms_scan"]),
+                  "phrase hash (n + wP + 8P)": pass_row(b_hash, t_hash),
+                  "merge ((n+1) + 12|D| + 5(P+1) + 8H [+ SA terms]; incl. run sampling / packing)": pass_row(b_merge, t_merge),
+                  "scan + merge": pass_row(b_scan + b_merge, st["ms_scan"] + t_merge),
+                  "end to end floor (2n)": pass_row(2 * nn, ms_per_step)}
+
         scan_row = next((x for x in rows if x["kernel"] == "pfp::kr_flag_kernel"), None)
         if scan_row is not None:
-            # exact rolling Karp-Rabin: ~20 VALU instructions per text byte (byte extracts, one 40-bit Barrett
-            # reduction, the divisibility test, mask update).  256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T
-            # lane-instructions/s put this kernel's ceiling at ~1.97 TB/s of text, a quarter of the HBM peak.
             scan_row = dict(scan_row, valu_bound_GBps=1966.0, frac_of_valu_bound=round(scan_row["achieved_GBps"] / 1966.0, 4),
-                            note="VALU-bound: ~20 instructions per byte; HBM peak is not reachable for this arithmetic")
-        # the host-buffer entry point (pageable H2D of the text + D2H of the .bwt included): reported, never `value`
+                            note="VALU-bound: ~20 instructions per byte for the exact rolling hash")
+        # the host-buffer entry point (H2D of the text + D2H of the outputs included): reported, never `value`
         host_boundary, host_ok = None, None
-        if world == 1:
+        if world == 1 and not args.no_host_boundary and n <= (2 << 30):
             host_text = text.cpu().numpy()
+            ctx.bigbwt(host_text[: 1 << 20], w, p, flags)          # warm the pinned staging buffers
             t1 = time.perf_counter()
             hb = ctx.bigbwt(host_text, w, p, flags)
             host_s = time.perf_counter() - t1
             host_boundary = dict(MBps=round(n / host_s / 1e6, 1), seconds=round(host_s, 4),
-                                 note="pfp_bigbwt: pageable host text in, host .bwt/.ssa/.esa out (PCIe inclusive)")
+                                 frac_of_device_resident=round((n / host_s / 1e6) / value, 3),
+                                 note="pfp_bigbwt: host text in, host .bwt/.ssa/.esa out (PCIe inclusive)")
             host_ok = bool(np.array_equal(hb["bwt"], bwt[: n + 1].cpu().numpy()))
-            del hb
+            del hb, host_text
         cpu = None
         parity_sample = None
-        if not args.no_cpu_baseline and world == 1:
-            sample_bytes = int(min(n, args.cpu_sample_mb * 1e6))
+        if O is not None:
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            sample_bytes = n if args.cpu_sample_mb <= 0 else int(min(n, args.cpu_sample_mb * 1e6))
             host = text[:sample_bytes].cpu().numpy()
-            cpu, ref_bwt = cpu_baseline(host, w, p, flags, O, sample_bytes)
-            got = ctx.bigbwt(host, w, p, 0)["bwt"]        # same sample through the HIP path: bit-exact?
-            parity_sample = bool(np.array_equal(got, ref_bwt))
+            cpu, ref = cpu_baseline(host, w, p, flags, O, threads)
+            got = ctx.bigbwt(host, w, p, flags)           # the same sample through the HIP path: bit-exact?
+            parity_sample = {k: bool(np.array_equal(got[k], ref[k])) for k in ref if k in got}
         out = {
             "metric": "input MB/s to .bwt (bit-exact vs ref)", "value": round(value, 2), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": wl["desc"], "bytes_per_gpu": n, "w": w, "p": p, "flags": flags,
+            "config": {"workload": wl["desc"], "name": wl_name, "bytes_per_gpu": n, "w": w, "p": p, "flags": flags,
                        "phrases": st["n_phrases"], "words": st["n_words"], "dict_bytes": st["dict_size"],
+                       "outputs_in_timed_step": ["bwt"] + [k for k in ("sa", "ssa", "esa") if k in outbuf],
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{world} shards of one collection: halo + allgatherv of dictionaries and parse over RCCL, "
                                         f"suffix array of the global dictionary sharded by key range, every rank emits the BWT "
-                                        f"range its share of SA(D) produces; SA of the parse replicated") if collection else
+                                        f"range its share of SA(D) produces") if collection else
                                        f"{world} independent texts (one per GPU), no collective")},
             "roofline": roofline,
-            "kernels": rows[:12],
+            "roofline_passes": passes,
+            "kernels": rows[:14],
             "scan_pass_k1": scan_row,
             "cpu_baseline": cpu,
             "host_buffer_boundary": host_boundary,
-            "phases_ms": {k: round(st[k], 3) for k in ("ms_scan", "ms_phrases", "ms_sa_dict", "ms_sa_parse", "ms_merge", "ms_total")},
+            "phases_ms": dict({k: round(st[k], 3) for k in ("ms_scan", "ms_phrases", "ms_sa_dict", "ms_sa_parse", "ms_merge", "ms_total")},
+                              formats=round(t_formats, 3), profiled_step=round(prof_ms, 3)),
             "sa_rounds": {"dict": st["sa_rounds_dict"], "parse": st["sa_rounds_parse"]},
             "merge_stats": {k: st[k] for k in ("hard_groups", "hard_chars", "hard_big_groups", "hard_max_chars", "hard_max_members", "extra_triggers")},
-            "verified": {"bwt_is_permutation_of_text_plus_eos": verified, "bit_exact_vs_reference_on_cpu_sample": parity_sample,
+            "runs": R,
+            "device_memory": {"peak_bytes_in_use": mem["peak"], "held_from_driver": mem["held"]},
+            "verified": {"outputs_match_reference_digests_whole_text": digests,
+                         "bwt_is_permutation_of_text_plus_eos": permutation_ok,
+                         "bit_exact_vs_reference_on_cpu_sample": parity_sample,
                          "host_and_device_entry_points_agree": host_ok},
         }
     if dist is not None:

@@ -46,13 +46,27 @@ inline int bits_for(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b)
 // released by the host can be handed out again at once: every later use is ordered behind every
 // earlier use by the stream itself.  Blocks are cached until pfp_ctx_destroy (steady-state calls
 // do not touch hipMalloc); best-fit reuse within 25 % slack.
+//
+// PFP_POOL_DEBUG=1 (read at pfp_ctx_create) turns the pool into a checker: every request gets its own
+// hipMalloc of exactly the bytes asked for plus a canary band before and after, the body is filled with a
+// poison pattern (a kernel that reads memory nobody wrote sees 0xCD garbage, not the zeros of a fresh
+// mapping or the leftovers of the block's previous life), the bands are verified when the block is
+// released (after a stream sync) and the block goes back to the driver.  A damaged band is reported on
+// stderr with the allocation site and fails every later API call on the context (pfp_debug_check).
 struct pfp_pool {
-  struct Block { void *p; size_t bytes; };
+  struct Block { void *p; size_t bytes; void *base; const char *file; int line; };
+  static constexpr size_t kBand = 1024;            // bytes of canary on either side (debug mode)
+  static constexpr unsigned char kCanary = 0xA5, kPoison = 0xCD;
   std::vector<Block> free_list;
   std::vector<Block> all;
-  size_t total_bytes = 0;
-  void *get(size_t bytes, hipError_t *err) {
+  size_t total_bytes = 0, peak_bytes = 0, live_bytes = 0;
+  bool debug = false;
+  hipStream_t stream = nullptr;
+  std::string corrupt;                             // first canary damage seen (debug mode)
+  uint64_t debug_blocks = 0;
+  void *get(size_t bytes, hipError_t *err, const char *file = "", int line = 0) {
     *err = hipSuccess;
+    if (debug) return get_debug(bytes, err, file, line);
     size_t best = (size_t)-1, bi = (size_t)-1;
     for (size_t i = 0; i < free_list.size(); i++) {
       size_t b = free_list[i].bytes;
@@ -60,6 +74,7 @@ struct pfp_pool {
     }
     if (bi != (size_t)-1) {
       void *p = free_list[bi].p;
+      live_bytes += free_list[bi].bytes; if (live_bytes > peak_bytes) peak_bytes = live_bytes;
       free_list[bi] = free_list.back(); free_list.pop_back();
       return p;
     }
@@ -71,23 +86,65 @@ struct pfp_pool {
       e = hipMalloc(&p, bytes);
     }
     if (e != hipSuccess) { *err = e; (void)hipGetLastError(); return nullptr; }
-    all.push_back({p, bytes}); total_bytes += bytes;
+    all.push_back({p, bytes, p, file, line}); total_bytes += bytes;
+    live_bytes += bytes; if (live_bytes > peak_bytes) peak_bytes = live_bytes;
     return p;
   }
   void put(void *p) {
-    for (auto &b : all) if (b.p == p) { free_list.push_back(b); return; }
+    for (size_t i = 0; i < all.size(); i++)
+      if (all[i].p == p) {
+        live_bytes -= all[i].bytes;
+        if (debug) { put_debug(i); return; }
+        free_list.push_back(all[i]);
+        return;
+      }
+  }
+  void *get_debug(size_t bytes, hipError_t *err, const char *file, int line) {
+    void *base = nullptr;
+    hipError_t e = hipMalloc(&base, bytes + 2 * kBand);
+    if (e != hipSuccess) { *err = e; (void)hipGetLastError(); return nullptr; }
+    unsigned char *b = (unsigned char *)base;
+    (void)hipMemsetAsync(b, kCanary, kBand, stream);
+    (void)hipMemsetAsync(b + kBand, kPoison, bytes, stream);
+    (void)hipMemsetAsync(b + kBand + bytes, kCanary, kBand, stream);
+    all.push_back({b + kBand, bytes, base, file, line});
+    total_bytes += bytes; live_bytes += bytes; if (live_bytes > peak_bytes) peak_bytes = live_bytes;
+    debug_blocks++;
+    return b + kBand;
+  }
+  void put_debug(size_t i) {
+    const Block blk = all[i];
+    all[i] = all.back(); all.pop_back();
+    total_bytes -= blk.bytes;
+    (void)hipStreamSynchronize(stream);
+    std::vector<unsigned char> h(2 * kBand);
+    unsigned char *b = (unsigned char *)blk.base;
+    (void)hipMemcpy(h.data(), b, kBand, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h.data() + kBand, b + kBand + blk.bytes, kBand, hipMemcpyDeviceToHost);
+    for (size_t k = 0; k < 2 * kBand; k++)
+      if (h[k] != kCanary) {
+        char msg[512];
+        const long off = k < kBand ? (long)k - (long)kBand : (long)(k - kBand);
+        snprintf(msg, sizeof msg, "pool debug: canary damaged %s a block of %zu bytes allocated at %s:%d (byte offset %ld %s, value 0x%02x)",
+                 k < kBand ? "BEFORE" : "AFTER", blk.bytes, blk.file, blk.line, off, k < kBand ? "relative to its start" : "past its end", h[k]);
+        fprintf(stderr, "[pfp] %s\n", msg);
+        if (corrupt.empty()) corrupt = msg;
+        break;
+      }
+    (void)hipMemset(blk.base, 0xDD, blk.bytes + 2 * kBand);      // use after release reads 0xDD
+    (void)hipFree(blk.base);
   }
   void trim() {   // caller guarantees the stream is idle
     (void)hipDeviceSynchronize();
     for (auto &f : free_list) {
-      (void)hipFree(f.p);
+      (void)hipFree(f.base);
       for (size_t i = 0; i < all.size(); i++) if (all[i].p == f.p) { total_bytes -= all[i].bytes; all[i] = all.back(); all.pop_back(); break; }
     }
     free_list.clear();
   }
   void destroy() {
-    for (auto &b : all) (void)hipFree(b.p);
-    all.clear(); free_list.clear(); total_bytes = 0;
+    for (auto &b : all) (void)hipFree(b.base);
+    all.clear(); free_list.clear(); total_bytes = 0; live_bytes = 0;
   }
 };
 
@@ -129,6 +186,7 @@ struct pfp_ctx {
   pfp_pool pool;
   pfp_ktrace kt;
   bool debug = false;             // PFP_DEBUG=1: validate every intermediate on the host
+  bool force_wide = false;        // PFP_FORCE_IDX64=1 / pfp_set_index_bits(ctx, 64): 64-bit dictionary positions whatever the size
   uint64_t max_phrase = 1u << 15; // fused chain: split phrases longer than this with extra triggers (0 = off)
   hipStream_t stream = nullptr;
   std::string err;
@@ -140,6 +198,10 @@ struct pfp_ctx {
   void *staged = nullptr;         // pfp::StagedText kept by pfp_stage_text_dev
   void *k1scratch = nullptr;      // scratch of pfp_scan_k1_enqueue
   void *dist = nullptr;           // DistState of the multi-GPU entry points
+  // two pinned staging buffers for chunked, double-buffered host <-> device streams (allocated on first use)
+  static constexpr size_t kPinBytes = 32u << 20;
+  void *pin[2] = {nullptr, nullptr};
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};
 };
 
 namespace pfp {
@@ -151,7 +213,7 @@ struct DBuf {
   size_t n = 0;
   pfp_ctx *ctx = nullptr;
   DBuf() = default;
-  DBuf(pfp_ctx *c, size_t count) { alloc(c, count); }
+  DBuf(pfp_ctx *c, size_t count, const char *file = __builtin_FILE(), int line = __builtin_LINE()) { alloc(c, count, file, line); }
   DBuf(const DBuf &) = delete;
   DBuf &operator=(const DBuf &) = delete;
   DBuf(DBuf &&o) noexcept { *this = std::move(o); }
@@ -160,13 +222,13 @@ struct DBuf {
     return *this;
   }
   ~DBuf() { release(); }
-  void alloc(pfp_ctx *c, size_t count) {
+  void alloc(pfp_ctx *c, size_t count, const char *file = __builtin_FILE(), int line = __builtin_LINE()) {
     release();
     ctx = c; n = count;
     size_t bytes = (count ? count : 1) * sizeof(T);
-    bytes = (bytes + 511) & ~size_t(511);
+    if (!c->pool.debug) bytes = (bytes + 511) & ~size_t(511);      // debug: exactly what was asked for, canaries right behind
     hipError_t e;
-    p = (T *)c->pool.get(bytes, &e);
+    p = (T *)c->pool.get(bytes, &e, file, line);
     if (!p)
       throw Error(e == hipErrorOutOfMemory ? PFP_ENOMEM : PFP_EHIP,
                   std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));

@@ -64,27 +64,38 @@ void build_dictionary_words(pfp_ctx *c, const uint8_t *bytes, const uint64_t *ws
 void dictionary_from_bytes(pfp_ctx *c, Dictionary &D);
 
 // ---------------------------------------------------------------- suffix sorting (sufsort.hip)
-struct SuffixOrder {
+// Index width.  Positions inside the dictionary and slots of its suffix array are `I` = uint32_t while the
+// dictionary is shorter than 4 GiB and uint64_t beyond (the reference makes the same switch between its
+// 32-bit and -DM64 builds, bigbwt:109-151, gsa/gsacak.h:42-60).  Everything that indexes the parse (P <=
+// 2^32-2, bwtparse.c:93), words (d < 2^32) or a distance inside one word stays 32 bits wide in both builds.
+template <class I> struct IdxTraits;
+template <> struct IdxTraits<uint32_t> { using DKey = uint64_t; static constexpr uint32_t kNone = 0xFFFFFFFFu; static constexpr uint32_t kTop = 0x80000000u; };
+template <> struct IdxTraits<uint64_t> { using DKey = unsigned __int128; static constexpr uint64_t kNone = ~0ull; static constexpr uint64_t kTop = 1ull << 63; };
+// true when a dictionary of dsize bytes needs (or PFP_FORCE_IDX64 asks for) the wide build
+inline bool use_wide_index(const pfp_ctx *c, uint64_t dsize) { return c->force_wide || dsize >= 0xFFFFFFF0ull; }
+
+template <class I>
+struct SuffixOrderT {
   uint64_t N = 0;        // slots held here: all NP suffixes, or (key-range sharded sort) one contiguous range of SA(D)
   uint64_t NP = 0;       // positions of the sorted string
   uint64_t slot_base = 0;        // range mode: SA(D) slot of local slot 0
   uint64_t range_emits = 0;      // range mode: BWT positions the range emits (when a count source was given)
   uint64_t klo = 0, khi = ~0ull; // range mode: first-round keys in [klo, khi) (khi == ~0: no upper bound)
   bool range = false, complete = true;   // range mode stops (complete = false) where it would need other ranks' ranks
-  DBuf<uint32_t> sa;     // [N] suffix start positions in sorted order (ties: position order)
-  DBuf<uint32_t> grp;    // [N] grp[t] = first sa slot of slot t's group (equal strings share it)
-  DBuf<uint32_t> rank;   // [N] rank[i] = grp[slot of i]; kNoRank where the sorter never needed it (see RankView)
+  DBuf<I> sa;            // [N] suffix start positions in sorted order (ties: position order)
+  DBuf<I> grp;           // [N] grp[t] = first sa slot of slot t's group (equal strings share it)
+  DBuf<I> rank;          // [NP] rank[i] = grp[slot of i]; kNone where the sorter never needed it (see RankView)
   uint64_t rounds = 0;
   // Dictionary mode keeps the sorted first-round keys: the rank of a suffix that the first round
   // already settled is the lower bound of its packed key among them, found on demand instead of
   // being scattered to rank[] for all N positions (the scatter was 9 ms of 56 at N = 260 M).
   DBuf<uint64_t> skeys;  // [N] packed keys of the first round in sorted order
-  DBuf<uint32_t> tab;    // [T] 0xFFFFFFFF - (first slot whose key has top bits >= T-1-r), r reversed bucket
+  DBuf<I> tab;           // [T] kNone - (first slot whose key has top bits >= T-1-r), r reversed bucket
   DBuf<uint32_t> lut;    // [256] byte -> (alphabetic code << 6) | code length
   const uint8_t *bytes = nullptr;
   int kbits = 0, shift = 0;   // kbits code bits per key (+ 1 flag bit)
   uint32_t T = 0;
-  uint32_t finbit = 0;   // dictionary mode, N < 2^31: rank[] values carry this bit once their suffix is settled
+  I finbit = 0;          // dictionary mode: rank[] values carry this bit once their suffix is settled (0: N too large for a spare bit)
   // When the first-round keys leave 16 bits free, every key carries its suffix's merge record {preceding
   // char, count code} there (SlotPayloadSrc): it arrives at the suffix's slot with the sort, and the merge
   // reads it from skeys instead of gathering 2 bytes per slot at random (4.9 ms of 38 at N = 260 M).
@@ -94,48 +105,55 @@ struct SuffixOrder {
   DBuf<uint8_t> refined;
   uint64_t n_refined = 0;
 };
-struct SlotPayloadSrc { const uint32_t *pos_word, *endpos, *wocc; uint32_t d; int w; };
-constexpr uint32_t kNoRank = 0xFFFFFFFFu;
+using SuffixOrder = SuffixOrderT<uint32_t>;
+using SuffixOrder64 = SuffixOrderT<uint64_t>;
+// slen[i] = characters from position i to the terminator of its word (the terminator not counted)
+struct SlotPayloadSrc { const uint32_t *pos_word, *slen, *wocc; uint32_t d; int w; };
 // device-side view for rank lookups (sufsort.hip: rank_at)
-struct RankView {
-  const uint32_t *rank; const uint64_t *skeys; const uint32_t *tab; const uint32_t *lut; const uint8_t *bytes;
-  uint64_t N; int kbits, shift; uint32_t T, finbit; uint64_t keymask;
+template <class I>
+struct RankViewT {
+  const I *rank; const uint64_t *skeys; const I *tab; const uint32_t *lut; const uint8_t *bytes;
+  uint64_t N; int kbits, shift; uint32_t T; I finbit; uint64_t keymask;
 };
-RankView rank_view(const SuffixOrder &so);
+template <class I> RankViewT<I> rank_view(const SuffixOrderT<I> &so);
 // out[k] = rank of the suffix starting at pos[k]
-void gather_ranks(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint64_t count, uint32_t *d_out);
+template <class I> void gather_ranks(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, uint64_t count, I *d_out);
 // Suffixes of the dictionary as 0x01-terminated strings (gsacak semantics):
-// endpos[i] = position of the terminator of the word containing i (the final 0x00 is its own word).
-void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out,
+// slen[i] = distance from i to the terminator of the word containing i (the final 0x00 is its own word).
+template <class I>
+void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *slen, SuffixOrderT<I> &out,
                         const SlotPayloadSrc *pay = nullptr);
 // multi-GPU: rank `part` of `parts` sorts the suffixes whose first-round key lies in its share of the key
 // space (splitters from a deterministic key sample: every rank derives the same ones, no exchange);
 // groups never straddle shares, and pivot rounds compare strings, not ranks, so a share is finished
 // without its neighbours.  out.complete == false: a group was left that only doubling could settle.
-void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, uint32_t part,
-                              uint32_t parts, SuffixOrder &out, const SlotPayloadSrc *pay = nullptr,
+template <class I>
+void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *slen, uint32_t part,
+                              uint32_t parts, SuffixOrderT<I> &out, const SlotPayloadSrc *pay = nullptr,
                               const SlotPayloadSrc *count = nullptr);
 // range mode: out[j] = 1 + SA(D) slot of the suffix starting at pos[j] if it belongs to this share, else 0
-void gather_slots_range(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint64_t count, uint32_t *d_out);
+template <class I>
+void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, uint64_t count, uint64_t *d_out);
 // plain suffix array of an integer string with unique smallest last symbol (sacak_int)
 // max_sym: largest symbol value (spare key bits then describe runs of equal symbols)
 void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym = 0xFFFFFFFFu);
 // plain suffix array of a byte string with s[N-1]==0 unique smallest (sacak)
-void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrder &out);
+template <class I> void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrderT<I> &out);
 
 // ---------------------------------------------------------------- stage 2+3 (merge.hip)
-struct DictIndex {        // per-position / per-word helper arrays over the dictionary
+struct DictIndex {        // per-position / per-word helper arrays over the dictionary (the same in both index widths)
   DBuf<uint32_t> pos_word;   // [dsize] word containing position i (d for the final 0x00)
-  DBuf<uint32_t> endpos;     // [dsize] position of that word's terminator
-  DBuf<uint32_t> wend;       // [d+1] terminator position of word j (wend[d] = dsize-1)
+  DBuf<uint32_t> slen;       // [dsize] distance from i to that word's terminator
+  DBuf<uint64_t> wend;       // [d+1] terminator position of word j (wend[d] = dsize-1)
   DBuf<uint32_t> lexrank;    // [d] 0-based lexicographic rank of word j
 };
 void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix);      // needs D.woff / D.wlen
 // D.bytes/D.dsize given (words + 0x01, final 0x00): fills D.d, D.woff, D.wlen; at most max_words words expected
 void word_table_from_bytes(pfp_ctx *c, Dictionary &D, uint64_t max_words);
-void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrder &so, DictIndex &ix);
-void compute_lexrank_from_slots(pfp_ctx *c, const Dictionary &D, const uint32_t *d_wslot_all, uint32_t parts, DictIndex &ix);
-uint64_t count_slot_outputs(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, int w);
+template <class I> void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrderT<I> &so, DictIndex &ix);
+// d_wslot_all: `parts` arrays of d entries (u64), 1 + SA(D) slot of every word's first suffix or 0
+void compute_lexrank_from_slots(pfp_ctx *c, const Dictionary &D, const uint64_t *d_wslot_all, uint32_t parts, DictIndex &ix);
+template <class I> uint64_t count_slot_outputs(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrderT<I> &so, int w);
 
 struct ParseBWT {         // outputs of bwtparse.c in HBM
   uint64_t P = 0;
@@ -155,7 +173,8 @@ struct BwtOutputs {
   uint64_t hard_groups = 0, hard_chars = 0, hard_big_groups = 0, hard_max_chars = 0, hard_max_members = 0;
 };
 // emits BWT positions [out_lo,out_hi) into out.d_bwt[0..) / out.d_sa[0..) (default: everything)
-void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, const ParseBWT &pb,
+template <class I>
+void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrderT<I> &so, const ParseBWT &pb,
                const uint32_t *occ_lex, int w, int flags, uint64_t expect_n_out, BwtOutputs &out, uint64_t out_lo = 0,
                uint64_t out_hi = ~0ull, uint64_t pos_base = 0, uint64_t n_out_global = 0);
 
@@ -165,13 +184,22 @@ void unpack5_dev(pfp_ctx *c, const uint8_t *in5, uint64_t cnt, uint64_t *vals);
 // pairs (pos,sa) packed as 10 bytes each; returns pair count; out buffer allocated inside
 uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const uint64_t *sa, uint64_t n_out, bool run_end,
                          DBuf<uint8_t> &out10);
+// the same in two steps over a slice of the BWT (multi-GPU): count the boundaries, then place the pairs.
+// left / right = the BWT byte just before / after the slice, -1 at the ends of the whole BWT.
+struct RunSampler {
+  pfp_ctx *c; const uint8_t *bwt; uint64_t cnt; int left, right; bool run_end;
+  uint64_t ntile = 0, pairs = 0;
+  DBuf<uint32_t> tile_cnt; DBuf<uint64_t> tile_off;
+  RunSampler(pfp_ctx *c, const uint8_t *bwt, uint64_t cnt, int left, int right, bool run_end);   // counts (one sync)
+  void place(const uint64_t *sa, uint64_t pos_base, uint8_t *out10);                               // sa[i] belongs to bwt[i]
+};
 
 
 // ---------------------------------------------------------------- PFP_DEBUG=1 (validate.hip)
 void validate_scan(pfp_ctx *c, const DBuf<uint64_t> &ends, uint64_t n_ends, uint64_t n, int w);
 void validate_dictionary(pfp_ctx *c, const Dictionary &D, int w);
 void validate_index(pfp_ctx *c, const Dictionary &D, const DictIndex &ix);
-void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, SuffixOrder &so, bool dict_mode, const char *what);
+template <class I> void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, SuffixOrderT<I> &so, bool dict_mode, const char *what);
 void validate_int_sa(pfp_ctx *c, const uint32_t *sym, const SuffixOrder &so);
 void validate_lexrank(pfp_ctx *c, const Dictionary &D, const DictIndex &ix);
 void validate_parse_bwt(pfp_ctx *c, const ParseBWT &pb);

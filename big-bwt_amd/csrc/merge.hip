@@ -28,36 +28,36 @@ static constexpr int TB = 256;
 // its bytes (an N-long scan and two N-long passes before).
 __global__ __launch_bounds__(256) void dict_index_fill_kernel(uint32_t d, const uint64_t *__restrict__ woff,
                                                               const uint32_t *__restrict__ wlen, uint64_t dsize,
-                                                              uint32_t *__restrict__ pos_word, uint32_t *__restrict__ endpos,
-                                                              uint32_t *__restrict__ wend) {
+                                                              uint32_t *__restrict__ pos_word, uint32_t *__restrict__ slen,
+                                                              uint64_t *__restrict__ wend) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t j = t >> 3;
   const uint32_t l8 = (uint32_t)(t & 7);
   if (j > d) return;
   if (j == d) {      // the final 0x00 is its own word
-    if (l8 == 0) { pos_word[dsize - 1] = d; endpos[dsize - 1] = (uint32_t)(dsize - 1); wend[d] = (uint32_t)(dsize - 1); }
+    if (l8 == 0) { pos_word[dsize - 1] = d; slen[dsize - 1] = 0; wend[d] = dsize - 1; }
     return;
   }
   const uint64_t s0 = woff[j], e = s0 + wlen[j];     // e: the word's 0x01
-  if (l8 == 0) wend[j] = (uint32_t)e;
-  for (uint64_t i = s0 + l8; i <= e; i += 8) { pos_word[i] = (uint32_t)j; endpos[i] = (uint32_t)e; }
+  if (l8 == 0) wend[j] = e;
+  for (uint64_t i = s0 + l8; i <= e; i += 8) { pos_word[i] = (uint32_t)j; slen[i] = (uint32_t)(e - i); }
 }
 
 void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix) {
   const uint64_t N = D.dsize;
   PFP_REQUIRE(D.woff.p && D.wlen.p, PFP_EINVAL, "dictionary without a word table");
   ix.pos_word.alloc(c, N);
-  ix.endpos.alloc(c, N);
+  ix.slen.alloc(c, N);
   ix.wend.alloc(c, D.d + 1);
   KScope ks(c, "pfp::dict_index_fill_kernel", N * 8);
   hipLaunchKernelGGL(dict_index_fill_kernel, dim3(cdiv(((uint64_t)D.d + 1) * 8, TB)), dim3(TB), 0, c->stream, (uint32_t)D.d,
-                     D.woff.p, D.wlen.p, N, ix.pos_word.p, ix.endpos.p, ix.wend.p);
+                     D.woff.p, D.wlen.p, N, ix.pos_word.p, ix.slen.p, ix.wend.p);
   PFP_HIP(hipGetLastError());
 }
 
 // word table of a dictionary given as bytes (words + 0x01, closed by 0x00): terminator positions by
 // compaction of the 0x01 bytes, then starts and lengths
-__global__ void words_from_ends_kernel(uint32_t d, const uint32_t *__restrict__ ends, uint64_t dsize, uint64_t *__restrict__ woff,
+__global__ void words_from_ends_kernel(uint32_t d, const uint64_t *__restrict__ ends, uint64_t dsize, uint64_t *__restrict__ woff,
                                        uint32_t *__restrict__ wlen) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j == 0) woff[d] = dsize - 1;
@@ -67,8 +67,8 @@ __global__ void words_from_ends_kernel(uint32_t d, const uint32_t *__restrict__ 
   wlen[j] = (uint32_t)(ends[j] - s0);
 }
 void word_table_from_bytes(pfp_ctx *c, Dictionary &D, uint64_t max_words) {
-  DBuf<uint32_t> ends(c, max_words + 1), cnt(c, 1);
-  select_byte_index_u32(c, D.bytes.p, kEndOfWord, ends.p, cnt.p, D.dsize);
+  DBuf<uint64_t> ends(c, max_words + 1), cnt(c, 1);
+  select_byte_index<uint64_t>(c, D.bytes.p, kEndOfWord, ends.p, cnt.p, D.dsize);
   D.d = read_scalar(c, cnt.p);
   PFP_REQUIRE(D.d <= max_words, PFP_EFORMAT, "more words in the dictionary bytes than announced");
   D.woff.alloc(c, D.d + 1); D.wlen.alloc(c, std::max<uint64_t>(D.d, 1));
@@ -91,67 +91,77 @@ __global__ void lexrank_from_order_kernel(uint32_t d, const uint32_t *__restrict
 }
 
 // multi-GPU: every share of the suffix array reported 1 + slot for the words it holds, 0 for the others
-__global__ void combine_word_slots_kernel(uint32_t d, uint32_t parts, const uint32_t *__restrict__ wslot_all,
-                                          uint32_t *__restrict__ key, uint32_t *__restrict__ missing) {
+__global__ void combine_word_slots_kernel(uint32_t d, uint32_t parts, const uint64_t *__restrict__ wslot_all,
+                                          uint64_t *__restrict__ key, uint32_t *__restrict__ missing) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= d) return;
-  uint32_t v = 0;
-  for (uint32_t r = 0; r < parts; r++) { const uint32_t x = wslot_all[(uint64_t)r * d + j]; v = x > v ? x : v; }
+  uint64_t v = 0;
+  for (uint32_t r = 0; r < parts; r++) { const uint64_t x = wslot_all[(uint64_t)r * d + j]; v = x > v ? x : v; }
   if (v == 0) atomicAdd(missing, 1u);
   key[j] = v - 1;
 }
-void compute_lexrank_from_slots(pfp_ctx *c, const Dictionary &D, const uint32_t *d_wslot_all, uint32_t parts, DictIndex &ix) {
+void compute_lexrank_from_slots(pfp_ctx *c, const Dictionary &D, const uint64_t *d_wslot_all, uint32_t parts, DictIndex &ix) {
   const uint32_t d = (uint32_t)D.d;
   ix.lexrank.alloc(c, d);
-  DBuf<uint32_t> key(c, d), val(c, d), keyo(c, d), valo(c, d), missing(c, 1);
+  DBuf<uint64_t> key(c, d), keyo(c, d);
+  DBuf<uint32_t> val(c, d), valo(c, d), missing(c, 1);
   missing.zero();
   hipLaunchKernelGGL(combine_word_slots_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, parts, d_wslot_all, key.p, missing.p);
   PFP_REQUIRE(read_scalar(c, missing.p) == 0, PFP_EFORMAT, "a dictionary word was claimed by no share of the suffix array");
   hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, val.p);
-  sort_pairs_u32_u32(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
+  sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
   hipLaunchKernelGGL(lexrank_from_order_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
   PFP_HIP(hipGetLastError());
 }
 
 // number of BWT positions the slots of `so` emit (sum of the occurrence counts of their words)
-__global__ __launch_bounds__(256) void slot_output_count_kernel(uint64_t n, const uint32_t *__restrict__ sa,
+template <class I>
+__global__ __launch_bounds__(256) void slot_output_count_kernel(uint64_t n, const I *__restrict__ sa,
                                                                 const uint32_t *__restrict__ pos_word,
-                                                                const uint32_t *__restrict__ endpos,
+                                                                const uint32_t *__restrict__ slen,
                                                                 const uint32_t *__restrict__ wocc, uint32_t d, int w,
                                                                 unsigned long long *__restrict__ total) {
   __shared__ unsigned long long ws[4];
   unsigned long long cnt = 0;
   for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (uint64_t)gridDim.x * 256) {
-    const uint32_t i = sa[t], wd = pos_word[i];
-    if (wd < d && (endpos[i] - i) > (uint32_t)w) cnt += wocc[wd];
+    const I i = sa[t];
+    const uint32_t wd = pos_word[i];
+    if (wd < d && slen[i] > (uint32_t)w) cnt += wocc[wd];
   }
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) { const unsigned long long t2 = ws[0] + ws[1] + ws[2] + ws[3]; if (t2) atomicAdd(total, t2); }
 }
-uint64_t count_slot_outputs(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, int w) {
+template <class I>
+uint64_t count_slot_outputs(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrderT<I> &so, int w) {
   DBuf<unsigned long long> total(c, 1);
   total.zero();
   if (so.N)
-    hipLaunchKernelGGL(slot_output_count_kernel, dim3((int)std::min<uint64_t>(cdiv64(so.N, 256), (uint64_t)c->n_cu * 16)), dim3(256),
-                       0, c->stream, so.N, so.sa.p, ix.pos_word.p, ix.endpos.p, D.wocc.p, (uint32_t)D.d, w, total.p);
+    hipLaunchKernelGGL(slot_output_count_kernel<I>, dim3((int)std::min<uint64_t>(cdiv64(so.N, 256), (uint64_t)c->n_cu * 16)), dim3(256),
+                       0, c->stream, so.N, so.sa.p, ix.pos_word.p, ix.slen.p, D.wocc.p, (uint32_t)D.d, w, total.p);
   PFP_HIP(hipGetLastError());
   PFP_HIP(hipMemcpyAsync(c->h_scalars, total.p, 8, hipMemcpyDeviceToHost, c->stream));
   sync(c);
   return c->h_scalars[0];
 }
+template uint64_t count_slot_outputs<uint32_t>(pfp_ctx *, const Dictionary &, const DictIndex &, const SuffixOrderT<uint32_t> &, int);
+template uint64_t count_slot_outputs<uint64_t>(pfp_ctx *, const Dictionary &, const DictIndex &, const SuffixOrderT<uint64_t> &, int);
 
-void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrder &so, DictIndex &ix) {
+template <class I>
+void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrderT<I> &so, DictIndex &ix) {
   const uint32_t d = (uint32_t)D.d;
   ix.lexrank.alloc(c, d);
-  DBuf<uint32_t> key(c, d), val(c, d), keyo(c, d), valo(c, d);
-  gather_ranks(c, so, D.woff.p, d, key.p);
+  DBuf<I> key(c, d), keyo(c, d);
+  DBuf<uint32_t> val(c, d), valo(c, d);
+  gather_ranks<I>(c, so, D.woff.p, d, key.p);
   hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, val.p);
-  sort_pairs_u32_u32(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
+  sort_pairs<I, uint32_t>(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
   hipLaunchKernelGGL(lexrank_from_order_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
   PFP_HIP(hipGetLastError());
 }
+template void compute_lexrank<uint32_t>(pfp_ctx *, const Dictionary &, SuffixOrderT<uint32_t> &, DictIndex &);
+template void compute_lexrank<uint64_t>(pfp_ctx *, const Dictionary &, SuffixOrderT<uint64_t> &, DictIndex &);
 
 // ------------------------------------------------------------------ stage 2: BWT of the parse
 
@@ -210,12 +220,12 @@ void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t 
 // 8 bytes {prev char, count code, 0, 0, word id} so that the slot pass still does ONE gather.
 template <class REC>
 __global__ void pprec_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t d, int w,
-                             const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ endpos,
+                             const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ slen,
                              const uint32_t *__restrict__ wocc, REC *__restrict__ pp) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   uint32_t wd = pos_word[i];
-  bool valid = wd < d && (endpos[i] - (uint32_t)i) > (uint32_t)w;
+  bool valid = wd < d && slen[i] > (uint32_t)w;
   uint32_t pc = (i == 0) ? kEndOfWord : b[i - 1];
   uint32_t occ = valid ? wocc[wd] : 0u;
   uint32_t lo = valid ? (pc | ((occ < 255u ? occ : 255u) << 8)) : 0u;
@@ -225,8 +235,9 @@ __global__ void pprec_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t
 
 // per SA(D) slot: count and preceding char (0 = emits nothing), 8 slots per thread; with SA output
 // also the start of the word's inverted list
-template <class REC>
-__global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const uint32_t *__restrict__ sa,
+template <class I> struct alignas(16) Idx8 { I v[8]; };
+template <class REC, class I>
+__global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const I *__restrict__ sa,
                                                           const REC *__restrict__ pp,
                                                           const uint32_t *__restrict__ pos_word,
                                                           const uint32_t *__restrict__ wocc,
@@ -235,13 +246,15 @@ __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const uint
                                                           uint32_t *__restrict__ ist) {
   uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
   if (t0 >= N) return;
-  uint32_t idx[8], c8[8], p8[8], w8[8];
+  I idx[8];
+  uint32_t c8[8], p8[8], w8[8];
   const int nk = (N - t0) >= 8 ? 8 : (int)(N - t0);
   if (nk == 8) {
-    uint4 s0 = *reinterpret_cast<const uint4 *>(sa + t0), s1 = *reinterpret_cast<const uint4 *>(sa + t0 + 4);
-    idx[0] = s0.x; idx[1] = s0.y; idx[2] = s0.z; idx[3] = s0.w; idx[4] = s1.x; idx[5] = s1.y; idx[6] = s1.z; idx[7] = s1.w;
+    const Idx8<I> v8 = *reinterpret_cast<const Idx8<I> *>(sa + t0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) idx[k] = v8.v[k];
   } else {
-    for (int k = 0; k < 8; k++) idx[k] = k < nk ? sa[t0 + k] : 0u;
+    for (int k = 0; k < 8; k++) idx[k] = k < nk ? sa[t0 + k] : (I)0;
   }
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -268,11 +281,12 @@ __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const uint
 // The same per-slot outputs when the records travelled in the top 16 bits of the first-round keys
 // (SuffixOrder::paybits): a streaming read of skeys; only slots that later rounds re-ordered
 // (refined[t]) fetch their record, and a count code of 255 its word's count.
-__global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const uint32_t *__restrict__ sa,
+template <class I>
+__global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const I *__restrict__ sa,
                                                            const uint64_t *__restrict__ skeys,
                                                            const uint8_t *__restrict__ refined, const uint8_t *__restrict__ b,
                                                            const uint32_t *__restrict__ pos_word,
-                                                           const uint32_t *__restrict__ endpos,
+                                                           const uint32_t *__restrict__ slen,
                                                            const uint32_t *__restrict__ wocc, uint32_t d, int w,
                                                            uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc) {
   uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
@@ -287,9 +301,10 @@ __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const uin
     if (k < nk) {
       rec = (uint32_t)(skeys[t0 + k] >> 48);
       if ((rf >> (8 * k)) & 0xffu) {
-        const uint32_t i = sa[t0 + k], wd = pos_word[i];
+        const I i = sa[t0 + k];
+        const uint32_t wd = pos_word[i];
         rec = 0;
-        if (wd < d && (endpos[i] - i) > (uint32_t)w) {
+        if (wd < d && slen[i] > (uint32_t)w) {
           const uint32_t occ = wocc[wd];
           rec = (i == 0 ? (uint32_t)kEndOfWord : (uint32_t)b[i - 1]) | ((occ < 255u ? occ : 255u) << 8);
         }
@@ -311,11 +326,12 @@ __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const uin
 
 // a group is "hard" when its members disagree on the preceding char (pfbwt.cpp:524-536), or, with
 // SA output, whenever it has more than one member (pfbwt.cpp:568, 612)
-__global__ void group_flags_kernel(uint64_t N, const uint32_t *__restrict__ grp, const uint8_t *__restrict__ pc,
+template <class I>
+__global__ void group_flags_kernel(uint64_t N, const I *__restrict__ grp, const uint8_t *__restrict__ pc,
                                    int any_multi_is_hard, uint8_t *__restrict__ hard) {
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N || pc[t] == 0) return;
-  uint32_t g = grp[t];
+  I g = grp[t];
   if (g == t) return;
   if (any_multi_is_hard || pc[t] != pc[g]) hard[g] = 1;
 }
@@ -328,11 +344,13 @@ __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank,
   if (j < d) wistart[j] = istart_lex[lexrank[j]] + 1;   // +1: ilist[0] is the EOS symbol (pfbwt.cpp:389)
 }
 
-struct MergeArgs {
+template <class I>
+struct MergeArgsT {
   uint64_t N, n_out; uint32_t d; int w; int want_sa; int dbg_mode;
   uint64_t pos_base, n_out_global;   // global BWT position of local position 0; global n+1 (== n_out unless the slots are one rank's range)
   uint64_t out_lo, out_hi;   // this call emits BWT positions [out_lo,out_hi) only (multi-GPU slices); bwt/out_sa are indexed by global position
-  const uint32_t *sa, *endpos, *grp, *ist, *pos_word, *wistart;
+  const I *sa, *grp;
+  const uint32_t *slen, *ist, *pos_word, *wistart;
   const uint8_t *pc, *hard;
   const uint64_t *tbase; const uint32_t *loc;    // output offset of slot t = tbase[t >> 11] + loc[t] (slot_off)
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
@@ -342,13 +360,15 @@ struct MergeArgs {
 // 32-bit offset inside the tile: 4 bytes per slot to write and read instead of 8, and the N-long scan
 // becomes one streaming tile kernel plus a scan over N/2048 sums.
 constexpr int kOffTileLog = 11;
-__device__ __forceinline__ uint64_t slot_off(const MergeArgs &a, uint64_t t) { return a.tbase[t >> kOffTileLog] + a.loc[t]; }
+template <class I>
+__device__ __forceinline__ uint64_t slot_off(const MergeArgsT<I> &a, uint64_t t) { return a.tbase[t >> kOffTileLog] + a.loc[t]; }
 
 
 __device__ __forceinline__ uint8_t fix_char(uint8_t ch) { return ch == kDollar ? 0 : ch; }  // pfbwt.cpp:126
 // start of slot t's word in ilist: stored per slot when SA values are wanted, looked up otherwise
 // (BWT only needs it for whole words and hard groups)
-__device__ __forceinline__ uint32_t slot_ist(const MergeArgs &a, uint64_t t) {
+template <class I>
+__device__ __forceinline__ uint32_t slot_ist(const MergeArgsT<I> &a, uint64_t t) {
   return a.ist ? a.ist[t] : a.wistart[a.pos_word[a.sa[t]]];
 }
 
@@ -370,7 +390,8 @@ struct ExpandLds {
   uint8_t lpc[kSlots], lcls[kSlots];
 };
 
-__device__ __forceinline__ void expand_stage(const MergeArgs &a, ExpandLds &L, uint64_t t0, int ns, uint64_t base) {
+template <class I>
+__device__ __forceinline__ void expand_stage(const MergeArgsT<I> &a, ExpandLds &L, uint64_t t0, int ns, uint64_t base) {
   for (int s = threadIdx.x; s <= ns; s += 256) L.loff[s] = slot_off(a, t0 + s) - base;
   for (int s = threadIdx.x; s < ns; s += 256) {
     uint8_t ch = a.pc[t0 + s];
@@ -381,7 +402,8 @@ __device__ __forceinline__ void expand_stage(const MergeArgs &a, ExpandLds &L, u
 }
 
 // 16 output bytes starting at block-relative offset x0 (< Ltot)
-__device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
+template <class I>
+__device__ __forceinline__ void expand_16(const MergeArgsT<I> &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
                                           uint64_t x0, uint64_t Ltot) {
   if (base + x0 + 16 <= a.out_lo || base + x0 >= a.out_hi) return;     // outside this rank's slice
   int lo = 0, hi = ns;                    // loff[lo] <= x0 < loff[hi]
@@ -422,20 +444,22 @@ __device__ __forceinline__ void expand_16(const MergeArgs &a, const ExpandLds &L
 // SA value of block-relative output position x (fill and full-word entries; hard groups write their
 // own).  One lane per position, so that the 8-byte stores of a wave are 512 contiguous bytes - the
 // 16-positions-per-thread layout of expand_16 would put every lane's store in a different 128-byte line.
-__device__ __forceinline__ void expand_sa_1(const MergeArgs &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
+template <class I>
+__device__ __forceinline__ void expand_sa_1(const MergeArgsT<I> &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
                                             uint64_t x) {
   if (base + x < a.out_lo || base + x >= a.out_hi) return;
   int lo = 0, hi = ns;                    // loff[lo] <= x < loff[hi]
   while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (L.loff[mid] <= x) lo = mid; else hi = mid; }
   const uint8_t cl = L.lcls[lo];
   if (cl != CLS_FILL && cl != CLS_FULL) return;
-  const uint32_t i = a.sa[t0 + lo];
+  const I i = a.sa[t0 + lo];
   const uint64_t pos = a.ilist[slot_ist(a, t0 + lo) + (uint32_t)(x - L.loff[lo])];
   a.out_sa[base + x] = (cl == CLS_FULL && a.pos_base + base + x == 0) ? a.n_out_global - 1
-                                                                      : a.bwsai[pos] - (uint64_t)(a.endpos[i] - i);
+                                                                      : a.bwsai[pos] - (uint64_t)a.slen[i];
 }
 
-__global__ __launch_bounds__(256) void expand_kernel(MergeArgs a, uint32_t *__restrict__ heavy, uint32_t *__restrict__ nheavy,
+template <class I>
+__global__ __launch_bounds__(256) void expand_kernel(MergeArgsT<I> a, uint32_t *__restrict__ heavy, uint32_t *__restrict__ nheavy,
                                                      uint32_t heavy_cap) {
   __shared__ ExpandLds L;
   const uint64_t t0 = (uint64_t)blockIdx.x * kSlots;
@@ -453,7 +477,8 @@ __global__ __launch_bounds__(256) void expand_kernel(MergeArgs a, uint32_t *__re
     for (uint64_t x = threadIdx.x; x < mine; x += 256) expand_sa_1(a, L, t0, ns, base, x);
 }
 
-__global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgs a, const uint32_t *__restrict__ heavy, uint32_t nheavy) {
+template <class I>
+__global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgsT<I> a, const uint32_t *__restrict__ heavy, uint32_t nheavy) {
   __shared__ ExpandLds L;
   for (uint32_t q = 0; q < nheavy; q++) {
     const uint64_t t0 = (uint64_t)heavy[q] * kSlots;
@@ -492,8 +517,8 @@ struct HardLds {
   uint8_t lq[kHardLds];
   uint32_t lmoff[kHardMem + 1], lmist[kHardMem], lmsl[kHardMem];
   uint8_t lmch[kHardMem], lmg[kHardMem];
-  uint64_t gbase[64];
-  uint32_t ghead[64], geoff[65], gk0[65];
+  uint64_t gbase[64], ghead[64];
+  uint32_t geoff[65], gk0[65];
 };
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
@@ -504,27 +529,28 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(v, o, 64); v = x > v ? x : v; }
   return v;
 }
-__global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, const uint32_t *__restrict__ heads,
-                                                          const uint32_t *__restrict__ nheads_p,
+template <class I>
+__global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgsT<I> a, const I *__restrict__ heads,
+                                                          const uint64_t *__restrict__ nheads_p,
                                                           unsigned long long *__restrict__ stats,
                                                           BigGroup *__restrict__ big, uint32_t big_cap,
                                                           BigGroup *__restrict__ mid, uint32_t mid_cap) {
   __shared__ HardLds S[4];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   HardLds &L = S[wv];
-  const uint32_t nH = *nheads_p;
-  const uint32_t nbatch = (nH + 63) / 64;
+  const uint64_t nH = *nheads_p;
+  const uint64_t nbatch = (nH + 63) / 64;
   unsigned long long my_chars = 0, my_groups = 0;
-  for (uint32_t b = blockIdx.x * 4 + wv; b < nbatch; b += gridDim.x * 4) {
+  for (uint64_t b = blockIdx.x * 4 + wv; b < nbatch; b += gridDim.x * 4) {
     // ---- A: one group per lane
-    const uint32_t hidx = b * 64 + lane;
+    const uint64_t hidx = b * 64 + lane;
     uint64_t g = 0, base = 0;
     uint32_t k = 0, E = 0;
     bool live = false;
     if (hidx < nH) {
       g = heads[hidx];
       uint32_t kk = 0;
-      while (g + kk < a.N && a.grp[g + kk] == (uint32_t)g && a.pc[g + kk] != 0) kk++;
+      while (g + kk < a.N && a.grp[g + kk] == (I)g && a.pc[g + kk] != 0) kk++;
       base = slot_off(a, g);
       const uint64_t Eg = slot_off(a, g + kk) - base;
       if (kk && !(base + Eg <= a.out_lo || base >= a.out_hi)) {      // inside this rank's slice
@@ -558,7 +584,7 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, const uin
       const uint32_t M = __shfl(pk, lastl, 64), Eb = __shfl(pE, lastl, 64);
       if (fit) {
         const int gi = __popcll(take & ((1ull << lane) - 1ull));
-        L.ghead[gi] = (uint32_t)g; L.gbase[gi] = base; L.geoff[gi] = pE - E; L.gk0[gi] = pk - k;
+        L.ghead[gi] = g; L.gbase[gi] = base; L.geoff[gi] = pE - E; L.gk0[gi] = pk - k;
       }
       if (lane == 0) { L.geoff[nG] = Eb; L.gk0[nG] = M; }
       wave_lds_sync();
@@ -566,11 +592,11 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, const uin
       for (uint32_t q = lane; q < M; q += 64) {
         int lo = 0, hi = nG;                       // gk0[lo] <= q < gk0[hi]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.gk0[mid] <= q) lo = mid; else hi = mid; }
-        const uint64_t t = (uint64_t)L.ghead[lo] + (q - L.gk0[lo]);
+        const uint64_t t = L.ghead[lo] + (q - L.gk0[lo]);
         L.lmoff[q] = L.geoff[lo] + (uint32_t)(slot_off(a, t) - L.gbase[lo]);
         L.lmist[q] = slot_ist(a, t);
         uint32_t sl = 0;
-        if (a.want_sa) { const uint32_t i = a.sa[t]; sl = a.endpos[i] - i; }
+        if (a.want_sa) sl = a.slen[a.sa[t]];
         L.lmsl[q] = sl;
         L.lmch[q] = fix_char(a.pc[t]);
         L.lmg[q] = (uint8_t)lo;
@@ -626,7 +652,8 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgs a, const uin
 // hard_groups_kernel so that its 10 KB of sort buffers per wave do not halve that kernel's occupancy
 // (they did: 11 -> 20 ms on the 64-copy workload).  The member search is by position here (a member table
 // would not fit for k > 256): every occurrence finds its member by bisection over the slots' offsets.
-__global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgs a, const BigGroup *__restrict__ mid, uint32_t nmid) {
+template <class I>
+__global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgsT<I> a, const BigGroup *__restrict__ mid, uint32_t nmid) {
   __shared__ uint64_t skey[4][kHardLds];       // (position << 16 | occurrence index)
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint64_t *K = skey[wv];
@@ -665,7 +692,7 @@ __global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgs a, const BigGr
       while (hi - lo > 1) { const uint32_t mdl = (lo + hi) >> 1; if (slot_off(a, g + mdl) - base <= e) lo = mdl; else hi = mdl; }
       const uint64_t t = g + lo;
       a.bwt[o] = fix_char(a.pc[t]);
-      if (a.want_sa) { const uint32_t i = a.sa[t]; a.out_sa[o] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i); }
+      if (a.want_sa) a.out_sa[o] = a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]];
     }
     wave_lds_sync();
   }
@@ -673,7 +700,8 @@ __global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgs a, const BigGr
 
 // large hard groups: one thread per occurrence, rank = own index + lower_bound in every other
 // member's inverted list
-__global__ __launch_bounds__(256) void hard_big_kernel(MergeArgs a, const BigGroup *__restrict__ big, uint32_t nbig,
+template <class I>
+__global__ __launch_bounds__(256) void hard_big_kernel(MergeArgsT<I> a, const BigGroup *__restrict__ big, uint32_t nbig,
                                                        const uint64_t *__restrict__ estart, uint64_t total) {
   for (uint64_t ge = (uint64_t)blockIdx.x * 256 + threadIdx.x; ge < total; ge += (uint64_t)gridDim.x * 256) {
     uint32_t lo = 0, hi = nbig;               // estart[lo] <= ge < estart[hi]
@@ -696,7 +724,7 @@ __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgs a, const BigGro
     }
     if (base + r >= a.out_lo && base + r < a.out_hi) {
       a.bwt[base + r] = fix_char(a.pc[t]);
-      if (a.want_sa) { const uint32_t i = a.sa[t]; a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)(a.endpos[i] - i); }
+      if (a.want_sa) a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]];
     }
   }
 }
@@ -732,7 +760,8 @@ __global__ __launch_bounds__(256) void slot_loc_kernel(const uint32_t *__restric
   }
 }
 
-void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrder &so, const ParseBWT &pb,
+template <class I>
+void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrderT<I> &so, const ParseBWT &pb,
                const uint32_t *occ_lex, int w, int flags, uint64_t expect_n_out, BwtOutputs &out, uint64_t out_lo,
                uint64_t out_hi, uint64_t pos_base, uint64_t n_out_global) {
   // NP dictionary positions; N suffix-array slots held by `so` (all of them, or - multi-GPU, key-range
@@ -760,39 +789,41 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   hard.zero();
   if (from_keys) {
     KScope ks(c, "pfp::slot_gather_kernel", N * (8 + 1 + 5));
-    hipLaunchKernelGGL(slot_payload_kernel, dim3(cdiv(cdiv64(N, 8), 256)), dim3(256), 0, c->stream, N, so.sa.p, so.skeys.p,
-                       so.refined.p, D.bytes.p, ix.pos_word.p, ix.endpos.p, D.wocc.p, d, w, cnt.p, pc.p);
+    hipLaunchKernelGGL(slot_payload_kernel<I>, dim3(cdiv(cdiv64(N, 8), 256)), dim3(256), 0, c->stream, N, so.sa.p, so.skeys.p,
+                       so.refined.p, D.bytes.p, ix.pos_word.p, ix.slen.p, D.wocc.p, d, w, cnt.p, pc.p);
   } else {
   { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + (flags ? 8 : 2)));
     if (flags) hipLaunchKernelGGL(pprec_kernel<uint64_t>, dim3(cdiv(NP, TB)), dim3(TB), 0, c->stream, D.bytes.p, NP, d, w,
-                                  ix.pos_word.p, ix.endpos.p, D.wocc.p, pp64.p);
+                                  ix.pos_word.p, ix.slen.p, D.wocc.p, pp64.p);
     else hipLaunchKernelGGL(pprec_kernel<uint16_t>, dim3(cdiv(NP, TB)), dim3(TB), 0, c->stream, D.bytes.p, NP, d, w,
-                            ix.pos_word.p, ix.endpos.p, D.wocc.p, pp16.p); }
-  { KScope ks(c, "pfp::slot_gather_kernel", N * (4 + 5 + (flags ? 12 : 2)));
+                            ix.pos_word.p, ix.slen.p, D.wocc.p, pp16.p); }
+  { KScope ks(c, "pfp::slot_gather_kernel", N * (sizeof(I) + 5 + (flags ? 12 : 2)));
     const dim3 grid(cdiv(cdiv64(N, 8), 256));
-    if (flags) hipLaunchKernelGGL(slot_gather_kernel<uint64_t>, grid, dim3(256), 0, c->stream, N, so.sa.p, pp64.p,
+    if (flags) hipLaunchKernelGGL((slot_gather_kernel<uint64_t, I>), grid, dim3(256), 0, c->stream, N, so.sa.p, pp64.p,
                                   ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, ist.p);
-    else hipLaunchKernelGGL(slot_gather_kernel<uint16_t>, grid, dim3(256), 0, c->stream, N, so.sa.p, pp16.p,
+    else hipLaunchKernelGGL((slot_gather_kernel<uint16_t, I>), grid, dim3(256), 0, c->stream, N, so.sa.p, pp16.p,
                             ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, (uint32_t *)nullptr); }
   }
+  pp16.release(); pp64.release();
   ovf.zero();
   PFP_HIP(hipMemsetAsync(tsum.p + ntile, 0, 8, c->stream));
   { KScope ks(c, "pfp::slot_loc_kernel", N * 8);
     hipLaunchKernelGGL(slot_loc_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, cnt.p, N, loc.p, tsum.p, ovf.p); }
   exclusive_sum_u64(c, tsum.p, tbase.p, ntile + 1);
   { KScope ks(c, "pfp::group_flags_kernel", N * 5);
-  hipLaunchKernelGGL(group_flags_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.grp.p, pc.p, flags ? 1 : 0, hard.p); }
+  hipLaunchKernelGGL(group_flags_kernel<I>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.grp.p, pc.p, flags ? 1 : 0, hard.p); }
   PFP_REQUIRE(read_scalar(c, ovf.p) == 0, PFP_ELIMIT, "2048 consecutive suffix-array slots emit 2^32 or more BWT positions");
   const uint64_t n_out = read_scalar(c, tbase.p + ntile);
   PFP_REQUIRE(expect_n_out == 0 || n_out == expect_n_out, PFP_EFORMAT,
               "merge: sum of occurrence counts (" + std::to_string(n_out) + ") != text length + 1 (" +
                   std::to_string(expect_n_out) + ")");
   out.n_out = n_out;
-  MergeArgs a{};
+  cnt.release();
+  MergeArgsT<I> a{};
   a.N = N; a.n_out = n_out; a.d = d; a.w = w; a.want_sa = flags ? 1 : 0;
   a.pos_base = pos_base; a.n_out_global = n_out_global ? n_out_global : n_out;
   { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
-  a.sa = so.sa.p; a.endpos = ix.endpos.p; a.grp = so.grp.p; a.ist = flags ? ist.p : nullptr;
+  a.sa = so.sa.p; a.slen = ix.slen.p; a.grp = so.grp.p; a.ist = flags ? ist.p : nullptr;
   a.pos_word = ix.pos_word.p; a.wistart = wistart.p;
   a.pc = pc.p; a.hard = hard.p; a.tbase = tbase.p; a.loc = loc.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p;
@@ -811,17 +842,19 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     DBuf<uint32_t> heavy(c, nblk), nheavy(c, 1);
     nheavy.zero();
     { KScope ks(c, "pfp::expand_kernel", N * 14 + n_out * (flags ? 17 : 1));
-    hipLaunchKernelGGL(expand_kernel, dim3(nblk), dim3(256), 0, c->stream, a, heavy.p, nheavy.p, nblk); }
+    hipLaunchKernelGGL(expand_kernel<I>, dim3(nblk), dim3(256), 0, c->stream, a, heavy.p, nheavy.p, nblk); }
     const uint32_t nh = read_scalar(c, nheavy.p);
     KScope ks2(c, "pfp::expand_heavy_kernel", 0);   // bytes are accounted in expand_kernel's n_out term
-    if (nh) hipLaunchKernelGGL(expand_heavy_kernel, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, heavy.p, nh);
+    if (nh) hipLaunchKernelGGL(expand_heavy_kernel<I>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, heavy.p, nh);
   }
-  // hard[] marks exactly the heads of the hard groups (group_flags_kernel): compact them once
-  DBuf<uint32_t> heads(c, N / 2 + 2), nheads(c, 1);
-  select_index_u32(c, hard.p, heads.p, nheads.p, N);
+  // hard[] marks exactly the heads of the hard groups (group_flags_kernel): count, then compact them once
+  const uint64_t n_heads = count_flags(c, hard.p, N);
+  DBuf<I> heads(c, n_heads + 1);
+  DBuf<uint64_t> nheads(c, 1);
+  select_index<I>(c, hard.p, heads.p, nheads.p, N);
   for (;;) {
     { KScope ks(c, "pfp::hard_groups_kernel", N * 5);
-      hipLaunchKernelGGL(hard_groups_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->stream, a, heads.p, nheads.p, hstats.p, big.p,
+      hipLaunchKernelGGL(hard_groups_kernel<I>, dim3(c->n_cu * 8), dim3(256), 0, c->stream, a, heads.p, nheads.p, hstats.p, big.p,
                          big_cap, mid.p, mid_cap); }
     PFP_HIP(hipGetLastError());
     PFP_HIP(hipMemcpyAsync(c->h_scalars, hstats.p, 40, hipMemcpyDeviceToHost, c->stream));
@@ -836,12 +869,12 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   out.hard_big_groups = c->h_scalars[2]; out.hard_max_chars = 0; out.hard_max_members = c->h_scalars[4];
   const uint32_t nmid = (uint32_t)std::min<uint64_t>(c->h_scalars[3], mid_cap);
   PFP_REQUIRE(c->h_scalars[3] <= mid_cap, PFP_EHIP, "more sorted-path hard groups than the output can hold");
+  const uint32_t nbig = (uint32_t)c->h_scalars[2];
   if (nmid) {
     KScope ks(c, "pfp::hard_sort_kernel", (uint64_t)nmid * (kHardSortMin + 1) * (flags ? 21 : 5));      // lower bound: ilist entry + char (+ SA) per occurrence
-    hipLaunchKernelGGL(hard_sort_kernel, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, mid.p, nmid);
+    hipLaunchKernelGGL(hard_sort_kernel<I>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, mid.p, nmid);
     PFP_HIP(hipGetLastError());
   }
-  const uint32_t nbig = (uint32_t)c->h_scalars[2];
   if (nbig) {
     // occurrences of the queued groups, laid end to end
     std::vector<BigGroup> hb(nbig);
@@ -853,22 +886,35 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     PFP_HIP(hipMemcpyAsync(estart.p, es.data(), (nbig + 1) * 8, hipMemcpyHostToDevice, c->stream));
     const uint64_t total = es[nbig];
     const int nb = (int)std::min<uint64_t>(cdiv64(total, 256), (uint64_t)c->n_cu * 32);
-    hipLaunchKernelGGL(hard_big_kernel, dim3(nb), dim3(256), 0, c->stream, a, big.p, nbig, estart.p, total);
+    hipLaunchKernelGGL(hard_big_kernel<I>, dim3(nb), dim3(256), 0, c->stream, a, big.p, nbig, estart.p, total);
     PFP_HIP(hipGetLastError());
     sync(c);
   }
 }
+template void merge_bwt<uint32_t>(pfp_ctx *, const Dictionary &, const DictIndex &, const SuffixOrderT<uint32_t> &, const ParseBWT &,
+                                  const uint32_t *, int, int, uint64_t, BwtOutputs &, uint64_t, uint64_t, uint64_t, uint64_t);
+template void merge_bwt<uint64_t>(pfp_ctx *, const Dictionary &, const DictIndex &, const SuffixOrderT<uint64_t> &, const ParseBWT &,
+                                  const uint32_t *, int, int, uint64_t, BwtOutputs &, uint64_t, uint64_t, uint64_t, uint64_t);
 
 // ------------------------------------------------------------------ output packing
 
-// utils.c:112-129: low 5 bytes, little endian
-__global__ void pack5_kernel(const uint64_t *__restrict__ v, uint64_t cnt, uint8_t *__restrict__ out) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cnt) return;
-  uint64_t x = v[i];
-  uint8_t *o = out + 5 * i;
-#pragma unroll
-  for (int b = 0; b < 5; b++) o[b] = (uint8_t)(x >> (8 * b));
+// utils.c:112-129: low 5 bytes, little endian.  One thread per 16 OUTPUT bytes (3.2 values): it reads the
+// (up to) four values its chunk overlaps - neighbouring lanes read overlapping, consecutive values - lays
+// their 5-byte fields end to end and cuts its 16 bytes out; every store is one aligned-size 16-byte store.
+__global__ __launch_bounds__(256) void pack5_kernel(const uint64_t *__restrict__ v, uint64_t cnt, uint8_t *__restrict__ out) {
+  const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t total = cnt * 5, b0 = q * 16;
+  if (b0 >= total) return;
+  const uint64_t v0 = b0 / 5;
+  const uint32_t s = (uint32_t)(b0 - v0 * 5) * 8;
+  const uint64_t M = 0xFFFFFFFFFFull;
+  const uint64_t a = v[v0] & M, b = v0 + 1 < cnt ? v[v0 + 1] & M : 0, c2 = v0 + 2 < cnt ? v[v0 + 2] & M : 0,
+                 d = v0 + 3 < cnt ? v[v0 + 3] & M : 0;
+  const uint64_t lo = a | (b << 40), mid = (b >> 24) | (c2 << 16) | (d << 56), hi = d >> 8;
+  const uint64_t olo = s ? (lo >> s) | (mid << (64 - s)) : lo, ohi = s ? (mid >> s) | (hi << (64 - s)) : mid;
+  if (b0 + 16 <= total) st16u(out + b0, make_uint4((uint32_t)olo, (uint32_t)(olo >> 32), (uint32_t)ohi, (uint32_t)(ohi >> 32)));
+  else
+    for (uint64_t k = 0; b0 + k < total; k++) out[b0 + k] = (uint8_t)((k < 8 ? olo >> (8 * k) : ohi >> (8 * (k - 8))) & 0xff);
 }
 __global__ void unpack5_kernel(const uint8_t *__restrict__ in, uint64_t cnt, uint64_t *__restrict__ v) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -881,7 +927,8 @@ __global__ void unpack5_kernel(const uint8_t *__restrict__ in, uint64_t cnt, uin
 }
 void pack5_dev(pfp_ctx *c, const uint64_t *vals, uint64_t cnt, uint8_t *out5) {
   if (!cnt) return;
-  hipLaunchKernelGGL(pack5_kernel, dim3(cdiv(cnt, TB)), dim3(TB), 0, c->stream, vals, cnt, out5);
+  KScope ks(c, "pfp::pack5_kernel", cnt * 13);
+  hipLaunchKernelGGL(pack5_kernel, dim3((unsigned)cdiv64(cdiv64(cnt * 5, 16), TB)), dim3(TB), 0, c->stream, vals, cnt, out5);
   PFP_HIP(hipGetLastError());
 }
 void unpack5_dev(pfp_ctx *c, const uint8_t *in5, uint64_t cnt, uint64_t *vals) {
@@ -892,53 +939,101 @@ void unpack5_dev(pfp_ctx *c, const uint8_t *in5, uint64_t cnt, uint64_t *vals) {
 
 // run boundaries: .ssa = <j,SA[j]> for BWT[j] != BWT[j-1] incl. j=0 (pfbwt.cpp:169-174,184-189);
 //                 .esa = <j,SA[j]> for BWT[j] != BWT[j+1] incl. j=n (pfbwt.cpp:175-179,225-229)
-__global__ void run_flags_kernel(const uint8_t *__restrict__ bwt, uint64_t base, uint64_t cnt, uint64_t n_out,
-                                 int run_end, uint8_t *__restrict__ flag) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cnt) return;
-  uint64_t x = base + i;
-  bool f = run_end ? (x + 1 == n_out || bwt[x] != bwt[x + 1]) : (x == 0 || bwt[x] != bwt[x - 1]);
-  flag[i] = f ? 1 : 0;
+// Two streaming passes over the BWT bytes of a slice [pos_base, pos_base+cnt) (16 positions per thread from
+// one unaligned 16-byte load, the neighbour byte shifted in): boundaries counted per tile of 4096
+// positions, tile offsets scanned, then every thread places its pairs <position, SA value> as 10 bytes.
+// left / right: the BWT byte just outside the slice, or -1 at the ends of the whole BWT (then the
+// edge position is a boundary by definition).
+constexpr int kRunTile = 4096;
+__device__ __forceinline__ void run_mask16(const uint8_t *__restrict__ bwt, uint64_t base, uint64_t cnt, int left, int right,
+                                           int run_end, uint32_t m[4]) {
+  m[0] = m[1] = m[2] = m[3] = 0;
+  if (base >= cnt) return;
+  if (base + 17 <= cnt && base >= 1) {          // interior: both neighbours of all 16 positions are inside the slice
+    const uint4 x = ld16u(bwt + base);
+    const uint4 y = run_end ? ld16u(bwt + base + 1) : ld16u(bwt + base - 1);
+    m[0] = nonzero_bytes(x.x ^ y.x); m[1] = nonzero_bytes(x.y ^ y.y); m[2] = nonzero_bytes(x.z ^ y.z); m[3] = nonzero_bytes(x.w ^ y.w);
+    return;
+  }
+  for (int k = 0; k < 16; k++) {
+    const uint64_t i = base + k;
+    if (i >= cnt) break;
+    const int b = bwt[i];
+    int nb;
+    if (run_end) nb = i + 1 < cnt ? (int)bwt[i + 1] : right;
+    else nb = i ? (int)bwt[i - 1] : left;
+    if (nb < 0 || nb != b) m[k >> 2] |= 1u << (8 * (k & 3));
+  }
 }
-__global__ void write_pairs_kernel(const uint32_t *__restrict__ idx, uint32_t cnt, uint64_t base,
-                                   const uint64_t *__restrict__ sa, uint8_t *__restrict__ out10) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cnt) return;
-  uint64_t x = base + idx[i], v = sa[x];
-  uint8_t *o = out10 + 10 * (uint64_t)i;
+__global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restrict__ bwt, uint64_t cnt, int left, int right,
+                                                        int run_end, uint32_t *__restrict__ tile_cnt) {
+  __shared__ uint32_t ws[4];
+  const uint64_t base = (uint64_t)blockIdx.x * kRunTile + (uint64_t)threadIdx.x * 16;
+  uint32_t m[4];
+  run_mask16(bwt, base, cnt, left, right, run_end, m);
+  uint32_t c = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
+__global__ __launch_bounds__(256) void run_place_kernel(const uint8_t *__restrict__ bwt, const uint64_t *__restrict__ sa,
+                                                        uint64_t cnt, uint64_t pos_base, int left, int right, int run_end,
+                                                        const uint64_t *__restrict__ tile_off, uint8_t *__restrict__ out10) {
+  __shared__ uint32_t ws[4];
+  const uint64_t base = (uint64_t)blockIdx.x * kRunTile + (uint64_t)threadIdx.x * 16;
+  uint32_t m[4];
+  run_mask16(bwt, base, cnt, left, right, run_end, m);
+  const uint32_t c = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+  uint32_t inc = c;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+  if (lane == 63) ws[wv] = inc;
+  __syncthreads();
+  if (!c) return;
+  uint64_t o = tile_off[blockIdx.x] + inc - c;
+  for (int q = 0; q < wv; q++) o += ws[q];
 #pragma unroll
-  for (int b = 0; b < 5; b++) { o[b] = (uint8_t)(x >> (8 * b)); o[5 + b] = (uint8_t)(v >> (8 * b)); }
+  for (int k = 0; k < 16; k++)
+    if ((m[k >> 2] >> (8 * (k & 3))) & 1u) {
+      const uint64_t x = pos_base + base + k, v = sa[base + k];
+      uint8_t *dst = out10 + 10 * o;
+      reinterpret_cast<U64u *>(dst)->v = (x & 0xFFFFFFFFFFull) | (v << 40);       // 5 bytes of x, 3 low bytes of v
+      reinterpret_cast<U16u *>(dst + 8)->v = (uint16_t)(v >> 24);                  // bytes 3, 4 of v
+      o++;
+    }
+}
+
+RunSampler::RunSampler(pfp_ctx *c_, const uint8_t *bwt_, uint64_t cnt_, int left_, int right_, bool run_end_)
+    : c(c_), bwt(bwt_), cnt(cnt_), left(left_), right(right_), run_end(run_end_) {
+  ntile = cdiv64(cnt, kRunTile);
+  tile_cnt.alloc(c, ntile + 1);
+  tile_off.alloc(c, ntile + 1);
+  PFP_HIP(hipMemsetAsync(tile_cnt.p + ntile, 0, 4, c->stream));
+  if (ntile) {
+    KScope ks(c, "pfp::run_count_kernel", cnt);
+    hipLaunchKernelGGL(run_count_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, bwt, cnt, left, right, run_end ? 1 : 0,
+                       tile_cnt.p);
+  }
+  exclusive_sum_u32_u64(c, tile_cnt.p, tile_off.p, ntile + 1);
+  PFP_HIP(hipGetLastError());
+  pairs = read_scalar(c, tile_off.p + ntile);
+}
+void RunSampler::place(const uint64_t *sa, uint64_t pos_base, uint8_t *out10) {
+  if (!ntile || !pairs) return;
+  KScope ks(c, "pfp::run_place_kernel", cnt + pairs * 18);
+  hipLaunchKernelGGL(run_place_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, bwt, sa, cnt, pos_base, left, right,
+                     run_end ? 1 : 0, tile_off.p, out10);
+  PFP_HIP(hipGetLastError());
 }
 
 uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const uint64_t *sa, uint64_t n_out, bool run_end,
                          DBuf<uint8_t> &out10) {
-  const uint64_t CH = 1ull << 30;
-  std::vector<DBuf<uint8_t>> parts;
-  std::vector<uint64_t> counts;
-  uint64_t total = 0;
-  for (uint64_t base = 0; base < n_out; base += CH) {
-    uint64_t cnt = std::min(CH, n_out - base);
-    DBuf<uint8_t> flag(c, cnt);
-    DBuf<uint32_t> idx(c, cnt), nsel(c, 1);
-    hipLaunchKernelGGL(run_flags_kernel, dim3(cdiv(cnt, TB)), dim3(TB), 0, c->stream, bwt, base, cnt, n_out,
-                       run_end ? 1 : 0, flag.p);
-    select_index_u32(c, flag.p, idx.p, nsel.p, cnt);
-    uint32_t k = read_scalar(c, nsel.p);
-    DBuf<uint8_t> part(c, (size_t)k * 10);
-    if (k) hipLaunchKernelGGL(write_pairs_kernel, dim3(cdiv(k, TB)), dim3(TB), 0, c->stream, idx.p, k, base, sa, part.p);
-    parts.push_back(std::move(part));
-    counts.push_back(k);
-    total += k;
-  }
-  out10.alloc(c, total * 10);
-  uint64_t o = 0;
-  for (size_t i = 0; i < parts.size(); i++) {
-    if (counts[i]) PFP_HIP(hipMemcpyAsync(out10.p + o, parts[i].p, counts[i] * 10, hipMemcpyDeviceToDevice, c->stream));
-    o += counts[i] * 10;
-  }
-  sync(c);
-  PFP_HIP(hipGetLastError());
-  return total;
+  RunSampler rs(c, bwt, n_out, -1, -1, run_end);
+  out10.alloc(c, rs.pairs * 10 + 16);
+  rs.place(sa, 0, out10.p);
+  return rs.pairs;
 }
 
 }  // namespace pfp

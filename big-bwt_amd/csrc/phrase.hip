@@ -316,7 +316,8 @@ static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, u
   sync(c);
   uint32_t toolong; memcpy(&toolong, c->h_scalars + 1, 4);
   D.dsize = c->h_scalars[0] + 1;
-  PFP_REQUIRE(!toolong && D.dsize < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary of 4 GiB or more needs the 64-bit index build");
+  PFP_REQUIRE(!toolong, PFP_ELIMIT, "a phrase of 4 GiB or more");
+  PFP_REQUIRE(D.dsize < (1ull << 40), PFP_ELIMIT, "dictionary of 2^40 bytes or more");
   D.bytes.alloc(c, D.dsize + 64);
   PFP_HIP(hipMemsetAsync(D.bytes.p + (D.dsize - 1), 0, 65, c->stream));
   PFP_HIP(hipMemsetAsync(counters.p + 3, 0, 4, c->stream));

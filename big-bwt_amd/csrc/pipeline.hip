@@ -6,6 +6,9 @@
 #include "devutil.hpp"
 #include <cstdlib>
 #include <new>
+#include <fcntl.h>
+#include <unistd.h>
+#include <cerrno>
 
 using namespace pfp;
 
@@ -69,16 +72,51 @@ __global__ __launch_bounds__(256) void dict_permute_kernel(uint32_t d, const uin
   }
 }
 
+// suffix order of the dictionary in the index width the dictionary's size asks for (use_wide_index)
+struct DictOrder {
+  bool wide = false;
+  SuffixOrderT<uint32_t> so32;
+  SuffixOrderT<uint64_t> so64;
+  template <class I> SuffixOrderT<I> &get() {
+    if constexpr (sizeof(I) == 8) return so64; else return so32;
+  }
+  uint64_t rounds() const { return wide ? so64.rounds : so32.rounds; }
+};
+// f(I{}) with I = uint64_t (wide) or uint32_t
+template <class F> static void with_width(bool wide, F &&f) {
+  if (wide) f(uint64_t{}); else f(uint32_t{});
+}
+
 struct Chain {
   StagedText tx;
   DBuf<uint64_t> ends;
   uint64_t n_ends = 0, n_used = 0;
   Dictionary D;
   DictIndex ix;
-  SuffixOrder so;
+  DictOrder ord;
   DBuf<uint32_t> occ_lex, word_at_rank, sym;
   ParseBWT pb;
 };
+
+// narrowing / widening copy of an index array to the host (the staged gsacak.h entry points fix their SA width)
+template <class A, class B>
+__global__ void convert_kernel(const A *__restrict__ in, uint64_t n, B *__restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (B)in[i];
+}
+template <class A, class B>
+static void fetch_converted(pfp_ctx *c, const A *d_in, uint64_t n, B *h_out) {
+  if constexpr (sizeof(A) == sizeof(B)) {
+    d2h(c, (A *)h_out, d_in, n);
+    sync(c);
+  } else {
+    DBuf<B> tmp(c, n);
+    hipLaunchKernelGGL((convert_kernel<A, B>), dim3(cdiv(n, TB)), dim3(TB), 0, c->stream, d_in, n, tmp.p);
+    PFP_HIP(hipGetLastError());
+    d2h(c, h_out, tmp.p, n);
+    sync(c);
+  }
+}
 
 static void check_args(int w, uint64_t p, int flags) {
   PFP_REQUIRE(w >= 4, PFP_EINVAL, "Windows size must be at least 4 (newscan.cpp:537)");
@@ -110,10 +148,15 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
   {
     PhaseTimer t(c, &st.ms_sa_dict);
     // BWT only: the merge records ride in the spare bits of the first-round keys (SuffixOrder::paybits)
-    const SlotPayloadSrc pay{ch.ix.pos_word.p, ch.ix.endpos.p, ch.D.wocc.p, (uint32_t)ch.D.d, w};
-    sort_dict_suffixes(c, ch.D.bytes.p, ch.D.dsize, ch.ix.endpos.p, ch.so, want_sai ? nullptr : &pay);
-    if (c->debug) validate_suffix_order(c, ch.D.bytes.p, ch.so, true, "dict SA");
-    compute_lexrank(c, ch.D, ch.so, ch.ix);
+    const SlotPayloadSrc pay{ch.ix.pos_word.p, ch.ix.slen.p, ch.D.wocc.p, (uint32_t)ch.D.d, w};
+    ch.ord.wide = use_wide_index(c, ch.D.dsize);      // 32- or 64-bit dictionary positions (bigbwt:130-151)
+    with_width(ch.ord.wide, [&](auto tag) {
+      using I = decltype(tag);
+      auto &so = ch.ord.get<I>();
+      sort_dict_suffixes<I>(c, ch.D.bytes.p, ch.D.dsize, ch.ix.slen.p, so, want_sai ? nullptr : &pay);
+      if (c->debug) validate_suffix_order<I>(c, ch.D.bytes.p, so, true, "dict SA");
+      compute_lexrank<I>(c, ch.D, so, ch.ix);
+    });
     if (c->debug) validate_lexrank(c, ch.D, ch.ix);
     const uint32_t d = (uint32_t)ch.D.d;
     ch.occ_lex.alloc(c, d); ch.word_at_rank.alloc(c, d);
@@ -125,7 +168,7 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
     PFP_HIP(hipGetLastError());
   }
   st.n = ch.n_used; st.n_phrases = ch.D.P; st.n_words = ch.D.d; st.dict_size = ch.D.dsize;
-  st.sa_rounds_dict = ch.so.rounds; st.hash_reseeds = ch.D.reseeds;
+  st.sa_rounds_dict = ch.ord.rounds(); st.hash_reseeds = ch.D.reseeds; st.index_bits = ch.ord.wide ? 64 : 32;
 }
 
 static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, int flags, uint8_t *d_bwt,
@@ -144,13 +187,59 @@ static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, 
     PhaseTimer t(c, &st.ms_merge);
     BwtOutputs bo;
     bo.d_bwt = d_bwt; bo.d_sa = d_sa;
-    merge_bwt(c, ch.D, ch.ix, ch.so, ch.pb, ch.occ_lex.p, w, flags, ch.n_used + 1, bo);
+    with_width(ch.ord.wide, [&](auto tag) {
+      using I = decltype(tag);
+      merge_bwt<I>(c, ch.D, ch.ix, ch.ord.get<I>(), ch.pb, ch.occ_lex.p, w, flags, ch.n_used + 1, bo);
+    });
     st.hard_groups = bo.hard_groups; st.hard_chars = bo.hard_chars;
     st.hard_big_groups = bo.hard_big_groups; st.hard_max_chars = bo.hard_max_chars; st.hard_max_members = bo.hard_max_members;
   }
   sync(c);
   st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   *n_used = ch.n_used;
+}
+
+static void ensure_pinned(pfp_ctx *c) {
+  for (int k = 0; k < 2; k++) {
+    if (!c->pin[k]) PFP_HIP(hipHostMalloc(&c->pin[k], pfp_ctx::kPinBytes, hipHostMallocDefault));
+    if (!c->pin_ev[k]) PFP_HIP(hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming));
+  }
+}
+// Device -> host stream in chunks through the two pinned buffers: while chunk i crosses PCIe, `sink`
+// consumes chunk i-1 on the host (file write, copy into the caller's buffer).
+template <class Sink>
+static void stream_d2h(pfp_ctx *c, const uint8_t *d_src, uint64_t nbytes, Sink &&sink) {
+  ensure_pinned(c);
+  const uint64_t CH = pfp_ctx::kPinBytes;
+  uint64_t prev_off = 0, prev_len = 0;
+  int k = 0;
+  for (uint64_t off = 0; off < nbytes || prev_len; off += CH) {
+    const uint64_t len = off < nbytes ? std::min<uint64_t>(CH, nbytes - off) : 0;
+    if (len) {
+      PFP_HIP(hipMemcpyAsync(c->pin[k], d_src + off, len, hipMemcpyDeviceToHost, c->stream));
+      PFP_HIP(hipEventRecord(c->pin_ev[k], c->stream));
+    }
+    if (prev_len) {
+      PFP_HIP(hipEventSynchronize(c->pin_ev[k ^ 1]));
+      sink((const uint8_t *)c->pin[k ^ 1], prev_off, prev_len);
+    }
+    prev_off = off; prev_len = len;
+    k ^= 1;
+  }
+}
+// Host -> device the same way: `fill` writes chunk i into a pinned buffer while chunk i-1 crosses PCIe.
+template <class Fill>
+static void stream_h2d(pfp_ctx *c, uint8_t *d_dst, uint64_t nbytes, Fill &&fill) {
+  ensure_pinned(c);
+  const uint64_t CH = pfp_ctx::kPinBytes;
+  int k = 0;
+  for (uint64_t off = 0; off < nbytes; off += CH, k ^= 1) {
+    const uint64_t len = std::min<uint64_t>(CH, nbytes - off);
+    if (off >= 2 * CH) PFP_HIP(hipEventSynchronize(c->pin_ev[k]));      // the copy that last used this buffer is done
+    fill((uint8_t *)c->pin[k], off, len);
+    PFP_HIP(hipMemcpyAsync(d_dst + off, c->pin[k], len, hipMemcpyHostToDevice, c->stream));
+    PFP_HIP(hipEventRecord(c->pin_ev[k], c->stream));
+  }
 }
 
 template <class T>
@@ -196,7 +285,8 @@ static void fetch_outputs(pfp_ctx *c, const uint8_t *d_bwt, const uint64_t *d_sa
 
 // ======================================================================== extern "C"
 
-#define PFP_TRY(ctx) try {
+#define PFP_TRY(ctx) try {                                                                \
+  if ((ctx) && !(ctx)->pool.corrupt.empty()) throw ::pfp::Error(PFP_EHIP, (ctx)->pool.corrupt);
 #define PFP_CATCH(ctx)                                                                    \
   }                                                                                       \
   catch (const pfp::Error &e) { if (ctx) (ctx)->err = e.what(); (void)hipGetLastError(); return e.code; } \
@@ -239,9 +329,12 @@ int pfp_ctx_create(pfp_ctx **out, int device) {
     PFP_HIP(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     PFP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->pool.stream = c->stream;
+    { const char *pd = getenv("PFP_POOL_DEBUG"); c->pool.debug = pd && pd[0] && pd[0] != '0'; }
     PFP_HIP(hipHostMalloc((void **)&c->h_scalars, 16 * sizeof(uint64_t), hipHostMallocDefault));
     const char *dbg = getenv("PFP_DEBUG");
     c->debug = dbg && dbg[0] && dbg[0] != '0';
+    { const char *fw = getenv("PFP_FORCE_IDX64"); c->force_wide = fw && fw[0] && fw[0] != '0'; }
     (void)hipGetLastError();
   } catch (const pfp::Error &e) {
     (void)hipGetLastError();
@@ -267,11 +360,26 @@ void pfp_ctx_destroy(pfp_ctx *c) {
   c->kt.destroy();
   c->pool.destroy();
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+  for (int k = 0; k < 2; k++) {
+    if (c->pin[k]) (void)hipHostFree(c->pin[k]);
+    if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
 const char *pfp_last_error(const pfp_ctx *c) { return c ? c->err.c_str() : "null context"; }
+int pfp_debug_check(pfp_ctx *c) {
+  if (!c) return PFP_EINVAL;
+  if (c->pool.corrupt.empty()) return PFP_OK;
+  c->err = c->pool.corrupt;
+  return PFP_EHIP;
+}
+int pfp_get_mem_stats(const pfp_ctx *c, uint64_t out[4]) {
+  if (!c || !out) return PFP_EINVAL;
+  out[0] = c->pool.total_bytes; out[1] = c->pool.peak_bytes; out[2] = c->pool.live_bytes; out[3] = c->pool.debug ? c->pool.debug_blocks : 0;
+  return PFP_OK;
+}
 void *pfp_ctx_stream(pfp_ctx *c) { return c ? (void *)c->stream : nullptr; }
 void pfp_free(void *p) { free(p); }
 void pfp_set_profiling(pfp_ctx *c, int on) { if (c) c->profiling = on != 0; }
@@ -300,6 +408,11 @@ int pfp_get_kernel_trace(pfp_ctx *c, pfp_kernel_stat *out, int cap) {
   return k;
 }
 void pfp_set_max_phrase(pfp_ctx *c, uint64_t max_phrase) { if (c) c->max_phrase = max_phrase; }
+int pfp_set_index_bits(pfp_ctx *c, int bits) {
+  if (!c || (bits != 0 && bits != 64)) return PFP_EINVAL;
+  c->force_wide = bits == 64;
+  return PFP_OK;
+}
 int pfp_get_stats(const pfp_ctx *c, pfp_stats *st) {
   if (!c || !st) return PFP_EINVAL;
   *st = c->stats;
@@ -403,23 +516,56 @@ int pfp_sacak_int(pfp_ctx *c, const uint32_t *s, uint32_t *SA, uint64_t n, uint6
   PFP_CATCH(c)
 }
 
+}  // extern "C"
+// suffix array of a byte string ending in a unique 0 into a host array of OUT-wide entries
+template <class OUT>
+static void sacak_any(pfp_ctx *c, const uint8_t *s, OUT *SA, uint64_t n) {
+  PFP_REQUIRE(n >= 1, PFP_EINVAL, "empty string");
+  PFP_REQUIRE(s[n - 1] == 0, PFP_EFORMAT, "sacak: last symbol must be 0");
+  PFP_REQUIRE(sizeof(OUT) == 8 || n < 0xFFFFFFF0ull, PFP_ELIMIT, "text of 4 GiB or more needs the 64-bit entry point (simplebwt64)");
+  DBuf<uint8_t> ds(c, n + 64);
+  h2d(c, ds.p, s, n);
+  PFP_HIP(hipMemsetAsync(ds.p + n, 0, 64, c->stream));
+  with_width(use_wide_index(c, n), [&](auto tag) {
+    using I = decltype(tag);
+    SuffixOrderT<I> so;
+    sort_byte_suffixes<I>(c, ds.p, n, so);
+    fetch_converted<I, OUT>(c, so.sa.p, n, SA);
+  });
+}
+extern "C" {
 int pfp_sacak(pfp_ctx *c, const uint8_t *s, uint32_t *SA, uint64_t n) {
   if (!c || !s || !SA) return PFP_EINVAL;
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
+  sacak_any<uint32_t>(c, s, SA, n);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+int pfp_sacak64(pfp_ctx *c, const uint8_t *s, uint64_t *SA, uint64_t n) {
+  if (!c || !s || !SA) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  sacak_any<uint64_t>(c, s, SA, n);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+int pfp_sacak_int64(pfp_ctx *c, const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k) {
+  if (!c || !s || !SA) return PFP_EINVAL;   // -DM64: uint_t SA entries, int_text stays 32 bits (gsacak.h:42-60)
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
   PFP_REQUIRE(n >= 1, PFP_EINVAL, "empty string");
-  PFP_REQUIRE(s[n - 1] == 0, PFP_EFORMAT, "sacak: last symbol must be 0");
-  DBuf<uint8_t> ds(c, n + 64);
+  PFP_REQUIRE(s[n - 1] == 0, PFP_EFORMAT, "sacak_int: last symbol must be 0");
+  DBuf<uint32_t> ds(c, n);
   h2d(c, ds.p, s, n);
-  PFP_HIP(hipMemsetAsync(ds.p + n, 0, 64, c->stream));
   SuffixOrder so;
-  sort_byte_suffixes(c, ds.p, n, so);
-  d2h(c, SA, so.sa.p, n);
-  sync(c);
+  sort_int_suffixes(c, ds.p, n, so, k ? (uint32_t)std::min<uint64_t>(k - 1, 0xFFFFFFFFull) : 0xFFFFFFFFu);
+  fetch_converted<uint32_t, uint64_t>(c, so.sa.p, n, SA);
   return PFP_OK;
   PFP_CATCH(c)
 }
 
+}  // extern "C"
 // dictionary given as bytes: fill D.{bytes,dsize,d,woff,wlen} and the index
 static void dictionary_from_host(pfp_ctx *c, const uint8_t *s, uint64_t n, Dictionary &D, DictIndex &ix) {
   PFP_REQUIRE(n >= 2 && s[n - 1] == kEndOfDict && s[n - 2] == kEndOfWord, PFP_EFORMAT,
@@ -432,15 +578,32 @@ static void dictionary_from_host(pfp_ctx *c, const uint8_t *s, uint64_t n, Dicti
   build_dict_index(c, D, ix);
 }
 
+template <class OUT>
+static void gsacak_any(pfp_ctx *c, const uint8_t *s, OUT *SA, uint64_t n) {
+  PFP_REQUIRE(sizeof(OUT) == 8 || n < 0xFFFFFFF0ull, PFP_ELIMIT, "collection of 4 GiB or more needs the 64-bit entry point (gsacak.h -DM64)");
+  Dictionary D; DictIndex ix;
+  dictionary_from_host(c, s, n, D, ix);
+  with_width(use_wide_index(c, n), [&](auto tag) {
+    using I = decltype(tag);
+    SuffixOrderT<I> so;
+    sort_dict_suffixes<I>(c, D.bytes.p, n, ix.slen.p, so);
+    fetch_converted<I, OUT>(c, so.sa.p, n, SA);
+  });
+}
+extern "C" {
 int pfp_gsacak(pfp_ctx *c, const uint8_t *s, uint32_t *SA, uint64_t n) {
   if (!c || !s || !SA) return PFP_EINVAL;   // gsacak.c:2503
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
-  Dictionary D; DictIndex ix; SuffixOrder so;
-  dictionary_from_host(c, s, n, D, ix);
-  sort_dict_suffixes(c, D.bytes.p, n, ix.endpos.p, so);
-  d2h(c, SA, so.sa.p, n);
-  sync(c);
+  gsacak_any<uint32_t>(c, s, SA, n);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+int pfp_gsacak64(pfp_ctx *c, const uint8_t *s, uint64_t *SA, uint64_t n) {
+  if (!c || !s || !SA) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  gsacak_any<uint64_t>(c, s, SA, n);
   return PFP_OK;
   PFP_CATCH(c)
 }
@@ -493,7 +656,7 @@ int pfp_merge(pfp_ctx *c, const uint8_t *dict, uint64_t dict_size, const uint32_
   PFP_REQUIRE(dict_size > 1 + (uint64_t)w, PFP_EFORMAT, "invalid dictionary file (pfbwt.cpp:332)");
   PFP_REQUIRE(ilist[0] == 1, PFP_EFORMAT, "ilist[0] != 1 (pfbwt.cpp:377)");
   PFP_REQUIRE(dict[0] == kDollar, PFP_EFORMAT, "dictionary must start with Dollar (pfbwt.cpp:125)");
-  Dictionary D; DictIndex ix; SuffixOrder so;
+  Dictionary D; DictIndex ix; DictOrder ord;
   dictionary_from_host(c, dict, dict_size, D, ix);
   PFP_REQUIRE(D.d == n_words, PFP_EFORMAT, "occ entries != dictionary words (pfbwt.cpp:357)");
   // expected output size: every suffix longer than w of every word, once per occurrence
@@ -512,10 +675,15 @@ int pfp_merge(pfp_ctx *c, const uint8_t *dict, uint64_t dict_size, const uint32_
   D.wocc.alloc(c, D.d);
   h2d(c, D.wocc.p, occ, D.d);
   if (c->debug) validate_index(c, D, ix);
-  const SlotPayloadSrc pay{ix.pos_word.p, ix.endpos.p, D.wocc.p, (uint32_t)D.d, w};
-  sort_dict_suffixes(c, D.bytes.p, D.dsize, ix.endpos.p, so, flags ? nullptr : &pay);
-  if (c->debug) validate_suffix_order(c, D.bytes.p, so, true, "dict SA");
-  compute_lexrank(c, D, so, ix);
+  const SlotPayloadSrc pay{ix.pos_word.p, ix.slen.p, D.wocc.p, (uint32_t)D.d, w};
+  ord.wide = use_wide_index(c, D.dsize);      // pfbwt[NT].x or pfbwt[NT]64.x (bigbwt:130-151)
+  with_width(ord.wide, [&](auto tag) {
+    using I = decltype(tag);
+    auto &so = ord.get<I>();
+    sort_dict_suffixes<I>(c, D.bytes.p, D.dsize, ix.slen.p, so, flags ? nullptr : &pay);
+    if (c->debug) validate_suffix_order<I>(c, D.bytes.p, so, true, "dict SA");
+    compute_lexrank<I>(c, D, so, ix);
+  });
   if (c->debug) validate_lexrank(c, D, ix);
   DBuf<uint32_t> occ_lex(c, D.d);
   hipLaunchKernelGGL(occ_lex_kernel, dim3(cdiv(D.d, TB)), dim3(TB), 0, c->stream, (uint32_t)D.d, ix.lexrank.p, D.wocc.p,
@@ -536,9 +704,67 @@ int pfp_merge(pfp_ctx *c, const uint8_t *dict, uint64_t dict_size, const uint32_
   if (flags) d_sa.alloc(c, expect + 1);
   BwtOutputs bo;
   bo.d_bwt = d_bwt.p; bo.d_sa = flags ? d_sa.p : nullptr;
-  merge_bwt(c, D, ix, so, pb, occ_lex.p, w, flags, expect, bo);
+  with_width(ord.wide, [&](auto tag) {
+    using I = decltype(tag);
+    merge_bwt<I>(c, D, ix, ord.get<I>(), pb, occ_lex.p, w, flags, expect, bo);
+  });
   c->stats.hard_groups = bo.hard_groups; c->stats.hard_chars = bo.hard_chars;
   fetch_outputs(c, d_bwt.p, d_sa.p, expect, flags, out);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// ---------------------------------------------------------------- output formats of device-resident results
+int pfp_pack5_dev(pfp_ctx *c, const void *d_vals, uint64_t count, void *d_out5) {
+  if (!c || ((!d_vals || !d_out5) && count)) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  pack5_dev(c, (const uint64_t *)d_vals, count, (uint8_t *)d_out5);
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_sample_runs_dev(pfp_ctx *c, const void *d_bwt, const void *d_sa, uint64_t count, uint64_t pos_base, int left_byte,
+                        int right_byte, int run_end, void *d_out10, uint64_t cap_pairs, uint64_t *n_pairs) {
+  if (!c || !n_pairs || (count && !d_bwt) || (d_out10 && count && !d_sa)) return PFP_EINVAL;
+  *n_pairs = 0;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  PFP_REQUIRE(left_byte >= -1 && left_byte <= 255 && right_byte >= -1 && right_byte <= 255, PFP_EINVAL, "neighbour bytes are -1 or 0..255");
+  PFP_REQUIRE(pos_base + count <= (1ull << 40), PFP_ELIMIT, "positions do not fit 5 bytes");
+  RunSampler rs(c, (const uint8_t *)d_bwt, count, left_byte, right_byte, run_end != 0);
+  *n_pairs = rs.pairs;
+  if (!d_out10) return PFP_OK;                  // count only
+  PFP_REQUIRE(rs.pairs <= cap_pairs, PFP_ELIMIT, "output buffer holds " + std::to_string(cap_pairs) + " pairs, the slice has " +
+                                                     std::to_string(rs.pairs) + " run boundaries");
+  rs.place((const uint64_t *)d_sa, pos_base, (uint8_t *)d_out10);
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// pfthreads.hpp:369-376: every worker pwrite()s its range of the output file at its offset
+int pfp_pwrite_dev(pfp_ctx *c, const char *path, uint64_t file_offset, const void *d_src, uint64_t nbytes) {
+  if (!c || !path || (!d_src && nbytes)) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  const int fd = open(path, O_WRONLY | O_CREAT, 0644);
+  PFP_REQUIRE(fd >= 0, PFP_EINVAL, std::string("cannot open ") + path + ": " + strerror(errno));
+  bool ok = true;
+  std::string werr;
+  try {
+    stream_d2h(c, (const uint8_t *)d_src, nbytes, [&](const uint8_t *h, uint64_t off, uint64_t len) {
+      uint64_t done = 0;
+      while (ok && done < len) {
+        const ssize_t w = pwrite(fd, h + done, len - done, (off_t)(file_offset + off + done));
+        if (w <= 0) { ok = false; werr = strerror(errno); break; }
+        done += (uint64_t)w;
+      }
+    });
+  } catch (...) { close(fd); throw; }
+  sync(c);
+  PFP_REQUIRE(close(fd) == 0 && ok, PFP_EINVAL, std::string("error writing ") + path + ": " + werr);
   return PFP_OK;
   PFP_CATCH(c)
 }
@@ -600,7 +826,7 @@ struct DistState {
   Dictionary L;                 // local dictionary + local parse
   Dictionary G;                 // global dictionary (identical on every rank)
   DictIndex ix;
-  SuffixOrder so;
+  DictOrder ord;
   DBuf<uint32_t> occ_lex;
   uint64_t local_total = 0;     // BWT positions the held slots emit
   bool want_sai = false;
@@ -623,9 +849,10 @@ __global__ void dist_sym_kernel(uint64_t P, const uint32_t *__restrict__ lpid, u
   if (k < P) sym[k] = lexrank[gid_of_union[word_base + lpid[k]]] + 1;
 }
 
-__global__ void add_one_kernel(uint32_t n, const uint32_t *__restrict__ in, uint32_t *__restrict__ out) {
+template <class I>
+__global__ void add_one_kernel(uint32_t n, const I *__restrict__ in, uint64_t *__restrict__ out) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) out[j] = in[j] + 1;
+  if (j < n) out[j] = (uint64_t)in[j] + 1;
 }
 
 extern "C" {
@@ -728,31 +955,38 @@ int pfp_dist_global_sort(pfp_ctx *c, const void *d_union, uint64_t union_bytes, 
   PFP_REQUIRE(U.d == n_union, PFP_EFORMAT, "the union holds a different number of words than occ entries");
   ds->G = Dictionary();
   ds->ix = DictIndex();
-  ds->so = SuffixOrder();
+  ds->ord = DictOrder();
   build_dictionary_words(c, U.bytes.p, U.woff.p, U.wlen.p, n_union, (const uint32_t *)d_union_occ, union_bytes, ds->G);
   build_dict_index(c, ds->G, ds->ix);
   const uint32_t d = (uint32_t)ds->G.d;
-  const SlotPayloadSrc pay{ds->ix.pos_word.p, ds->ix.endpos.p, ds->G.wocc.p, d, ds->w};
+  const SlotPayloadSrc pay{ds->ix.pos_word.p, ds->ix.slen.p, ds->G.wocc.p, d, ds->w};
   const SlotPayloadSrc *payp = ds->want_sai ? nullptr : &pay;      // no sa info was parsed: the merge will be BWT only
-  if (parts == 1) {
-    sort_dict_suffixes(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, ds->so, payp);
-    if (c->debug) validate_suffix_order(c, ds->G.bytes.p, ds->so, true, "global dict SA");
-    DBuf<uint32_t> slots(c, d);
-    gather_ranks(c, ds->so, ds->G.woff.p, d, slots.p);
-    hipLaunchKernelGGL(add_one_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, slots.p, (uint32_t *)d_wslot_out);
-    ds->local_total = 0;
-  } else {
-    sort_dict_suffixes_range(c, ds->G.bytes.p, ds->G.dsize, ds->ix.endpos.p, part, parts, ds->so, payp, &pay);
-    gather_slots_range(c, ds->so, ds->G.woff.p, d, (uint32_t *)d_wslot_out);
-    ds->local_total = ds->so.complete ? ds->so.range_emits : 0;
-    if (c->debug && ds->so.complete)
-      PFP_REQUIRE(count_slot_outputs(c, ds->G, ds->ix, ds->so, ds->w) == ds->local_total, PFP_EHIP,
-                  "emit count by position differs from the count by slot");
-  }
+  ds->ord.wide = use_wide_index(c, ds->G.dsize);
+  uint64_t info_rounds = 0, info_complete = 1, info_N = 0, info_base = 0;
+  with_width(ds->ord.wide, [&](auto tag) {
+    using I = decltype(tag);
+    auto &so = ds->ord.get<I>();
+    if (parts == 1) {
+      sort_dict_suffixes<I>(c, ds->G.bytes.p, ds->G.dsize, ds->ix.slen.p, so, payp);
+      if (c->debug) validate_suffix_order<I>(c, ds->G.bytes.p, so, true, "global dict SA");
+      DBuf<I> slots(c, d);
+      gather_ranks<I>(c, so, ds->G.woff.p, d, slots.p);
+      hipLaunchKernelGGL(add_one_kernel<I>, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, slots.p, (uint64_t *)d_wslot_out);
+      ds->local_total = 0;
+    } else {
+      sort_dict_suffixes_range<I>(c, ds->G.bytes.p, ds->G.dsize, ds->ix.slen.p, part, parts, so, payp, &pay);
+      gather_slots_range<I>(c, so, ds->G.woff.p, d, (uint64_t *)d_wslot_out);
+      ds->local_total = so.complete ? so.range_emits : 0;
+      if (c->debug && so.complete)
+        PFP_REQUIRE(count_slot_outputs<I>(c, ds->G, ds->ix, so, ds->w) == ds->local_total, PFP_EHIP,
+                    "emit count by position differs from the count by slot");
+    }
+    info_rounds = so.rounds; info_complete = so.complete ? 1 : 0; info_N = so.N; info_base = so.slot_base;
+  });
   PFP_HIP(hipGetLastError());
   sync(c);
-  out_info[0] = ds->G.d; out_info[1] = ds->G.dsize; out_info[2] = ds->so.rounds; out_info[3] = ds->so.complete ? 1 : 0;
-  out_info[4] = ds->so.N; out_info[5] = ds->so.slot_base; out_info[6] = ds->local_total; out_info[7] = 0;
+  out_info[0] = ds->G.d; out_info[1] = ds->G.dsize; out_info[2] = info_rounds; out_info[3] = info_complete;
+  out_info[4] = info_N; out_info[5] = info_base; out_info[6] = ds->local_total; out_info[7] = ds->ord.wide ? 64 : 32;
   return PFP_OK;
   PFP_CATCH(c)
 }
@@ -764,7 +998,7 @@ int pfp_dist_global_finish(pfp_ctx *c, const void *d_wslot_all, uint32_t parts, 
   DistState *ds = dist_of(c);
   const uint32_t d = (uint32_t)ds->G.d;
   PFP_REQUIRE(d >= 1, PFP_EINVAL, "pfp_dist_global_sort has not run");
-  compute_lexrank_from_slots(c, ds->G, (const uint32_t *)d_wslot_all, parts, ds->ix);
+  compute_lexrank_from_slots(c, ds->G, (const uint64_t *)d_wslot_all, parts, ds->ix);
   if (c->debug) validate_lexrank(c, ds->G, ds->ix);
   ds->occ_lex.alloc(c, d);
   hipLaunchKernelGGL(occ_lex_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ds->ix.lexrank.p, ds->G.wocc.p,
@@ -782,8 +1016,8 @@ int pfp_dist_global(pfp_ctx *c, const void *d_union, uint64_t union_bytes, const
                     uint64_t my_word_base, void *d_sym_out, uint64_t out_info[3]) {
   if (!c || !c->dist || !d_union || !d_union_occ || !d_sym_out || !out_info) return PFP_EINVAL;
   uint64_t info[8];
-  uint32_t *wslot = nullptr;
-  if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void **)&wslot, (n_union ? n_union : 1) * 4) != hipSuccess) return PFP_ENOMEM;
+  uint64_t *wslot = nullptr;
+  if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void **)&wslot, (n_union ? n_union : 1) * 8) != hipSuccess) return PFP_ENOMEM;
   int rc = pfp_dist_global_sort(c, d_union, union_bytes, d_union_occ, n_union, 0, 1, wslot, info);
   if (rc == PFP_OK) rc = pfp_dist_global_finish(c, wslot, 1, my_word_base, d_sym_out);
   (void)hipFree(wslot);
@@ -805,15 +1039,21 @@ int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last
   if (c->debug) validate_parse_bwt(c, pb);
   BwtOutputs bo;
   bo.d_bwt = (uint8_t *)d_bwt_slice; bo.d_sa = (uint64_t *)d_sa_slice;
-  if (ds->so.range) {
-    // the held slots are one contiguous range of SA(D): they emit exactly [out_lo, out_hi)
-    PFP_REQUIRE(ds->so.complete, PFP_EINVAL, "this share of the suffix array is incomplete: redo pfp_dist_global_sort with parts = 1");
-    PFP_REQUIRE(out_hi - out_lo == ds->local_total, PFP_EINVAL, "output range does not match this share's occurrence count");
-    if (ds->so.N == 0) { sync(c); return PFP_OK; }      // an empty share of the key space emits nothing
-    merge_bwt(c, ds->G, ds->ix, ds->so, pb, ds->occ_lex.p, ds->w, flags, ds->local_total, bo, 0, ~0ull, out_lo, n_total + 1);
-  } else {
-    merge_bwt(c, ds->G, ds->ix, ds->so, pb, ds->occ_lex.p, ds->w, flags, n_total + 1, bo, out_lo, out_hi);
-  }
+  bool empty_share = false;
+  with_width(ds->ord.wide, [&](auto tag) {
+    using I = decltype(tag);
+    auto &so = ds->ord.get<I>();
+    if (so.range) {
+      // the held slots are one contiguous range of SA(D): they emit exactly [out_lo, out_hi)
+      PFP_REQUIRE(so.complete, PFP_EINVAL, "this share of the suffix array is incomplete: redo pfp_dist_global_sort with parts = 1");
+      PFP_REQUIRE(out_hi - out_lo == ds->local_total, PFP_EINVAL, "output range does not match this share's occurrence count");
+      if (so.N == 0) { empty_share = true; return; }      // an empty share of the key space emits nothing
+      merge_bwt<I>(c, ds->G, ds->ix, so, pb, ds->occ_lex.p, ds->w, flags, ds->local_total, bo, 0, ~0ull, out_lo, n_total + 1);
+    } else {
+      merge_bwt<I>(c, ds->G, ds->ix, so, pb, ds->occ_lex.p, ds->w, flags, n_total + 1, bo, out_lo, out_hi);
+    }
+  });
+  (void)empty_share;
   sync(c);
   return PFP_OK;
   PFP_CATCH(c)

@@ -2,6 +2,8 @@
 #include "prims.hpp"
 #include "devutil.hpp"
 #include <rocprim/rocprim.hpp>
+#include <algorithm>
+#include <utility>
 
 namespace pfp {
 
@@ -14,27 +16,52 @@ namespace pfp {
     PFP_HIP(call_with_temp);                                    \
   } while (0)
 
-void sort_pairs_u64_u32(pfp_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
-                        size_t n, int bb, int eb) {
+template <class K, class V> static const char *sort_name() {
+  if (sizeof(K) == 8 && sizeof(V) == 4) return "rocprim::radix_sort_pairs<u64,u32>";
+  if (sizeof(K) == 4 && sizeof(V) == 4) return "rocprim::radix_sort_pairs<u32,u32>";
+  if (sizeof(K) == 8 && sizeof(V) == 8) return "rocprim::radix_sort_pairs<u64,u64>";
+  return "rocprim::radix_sort_pairs<u128,u64>";
+}
+template <class K, class V>
+void sort_pairs(pfp_ctx *c, const K *kin, K *kout, const V *vin, V *vout, size_t n, int bb, int eb) {
   if (!n) return;
   const uint64_t passes = (uint64_t)(eb - bb + 7) / 8;
-  KScope ks(c, "rocprim::radix_sort_pairs<u64,u32>", n * 8 + passes * n * 24);
+  KScope ks(c, sort_name<K, V>(), n * sizeof(K) + passes * n * 2 * (sizeof(K) + sizeof(V)));
   PRIM2(rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, (unsigned)bb, (unsigned)eb, c->stream));
 }
-void sort_pairs_u32_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
-                        size_t n, int bb, int eb) {
+template <class K, class V>
+void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &valt, size_t n, int bb, int eb) {
   if (!n) return;
+  PFP_REQUIRE(k.n >= n && kalt.n >= n && v.n >= n && valt.n >= n, PFP_EINVAL, "sort_pairs_db: a buffer is shorter than n");
   const uint64_t passes = (uint64_t)(eb - bb + 7) / 8;
-  KScope ks(c, "rocprim::radix_sort_pairs<u32,u32>", n * 4 + passes * n * 16);
-  PRIM2(rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, (unsigned)bb, (unsigned)eb, c->stream));
+  KScope ks(c, sort_name<K, V>(), n * sizeof(K) + passes * n * 2 * (sizeof(K) + sizeof(V)));
+  rocprim::double_buffer<K> dk(k.p, kalt.p);
+  rocprim::double_buffer<V> dv(v.p, valt.p);
+  PRIM2(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream));
+  if (dk.current() != k.p) std::swap(k, kalt);
+  if (dv.current() != v.p) std::swap(v, valt);
 }
-void segsort_pairs_u32_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n,
-                           size_t nseg, const uint32_t *seg_begin, const uint32_t *seg_end, int bb, int eb) {
+template void sort_pairs<uint64_t, uint32_t>(pfp_ctx *, const uint64_t *, uint64_t *, const uint32_t *, uint32_t *, size_t, int, int);
+template void sort_pairs<uint32_t, uint32_t>(pfp_ctx *, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, size_t, int, int);
+template void sort_pairs<uint64_t, uint64_t>(pfp_ctx *, const uint64_t *, uint64_t *, const uint64_t *, uint64_t *, size_t, int, int);
+template void sort_pairs_db<uint64_t, uint32_t>(pfp_ctx *, DBuf<uint64_t> &, DBuf<uint64_t> &, DBuf<uint32_t> &, DBuf<uint32_t> &, size_t, int, int);
+template void sort_pairs_db<uint64_t, uint64_t>(pfp_ctx *, DBuf<uint64_t> &, DBuf<uint64_t> &, DBuf<uint64_t> &, DBuf<uint64_t> &, size_t, int, int);
+template void sort_pairs_db<u128, uint64_t>(pfp_ctx *, DBuf<u128> &, DBuf<u128> &, DBuf<uint64_t> &, DBuf<uint64_t> &, size_t, int, int);
+
+template <class V>
+void segsort_pairs_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, const V *vin, V *vout, size_t n,
+                       size_t nseg, const uint32_t *seg_begin, const uint32_t *seg_end, int bb, int eb) {
   if (!n || !nseg) return;
-  KScope ks(c, "rocprim::segmented_radix_sort_pairs<u32,u32>", n * 16 + nseg * 8);
+  PFP_REQUIRE(n < 0xFFFFFFFFull, PFP_ELIMIT, "segmented sort of 2^32 or more elements");
+  KScope ks(c, "rocprim::segmented_radix_sort_pairs<u32,u32>", n * (8 + 2 * sizeof(V)) + nseg * 8);
   PRIM2(rocprim::segmented_radix_sort_pairs(tmp, tb, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, seg_begin, seg_end,
                                             (unsigned)bb, (unsigned)eb, c->stream));
 }
+template void segsort_pairs_u32<uint32_t>(pfp_ctx *, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, size_t, size_t,
+                                          const uint32_t *, const uint32_t *, int, int);
+template void segsort_pairs_u32<uint64_t>(pfp_ctx *, const uint32_t *, uint32_t *, const uint64_t *, uint64_t *, size_t, size_t,
+                                          const uint32_t *, const uint32_t *, int, int);
+
 void exclusive_sum_u32(pfp_ctx *c, const uint32_t *in, uint32_t *out, size_t n) {
   if (!n) return;
   KScope ks(c, "rocprim::scan<u32>", n * 8);
@@ -56,11 +83,14 @@ void inclusive_sum_u32(pfp_ctx *c, const uint32_t *in, uint32_t *out, size_t n) 
   KScope ks(c, "rocprim::scan<u32>", n * 8);
   PRIM2(rocprim::inclusive_scan(tmp, tb, in, out, n, rocprim::plus<uint32_t>(), c->stream));
 }
-void inclusive_max_u32(pfp_ctx *c, const uint32_t *in, uint32_t *out, size_t n) {
+template <class T>
+void inclusive_max(pfp_ctx *c, const T *in, T *out, size_t n) {
   if (!n) return;
-  KScope ks(c, "rocprim::scan<u32>", n * 8);
-  PRIM2(rocprim::inclusive_scan(tmp, tb, in, out, n, rocprim::maximum<uint32_t>(), c->stream));
+  KScope ks(c, sizeof(T) == 4 ? "rocprim::scan<u32>" : "rocprim::scan<u64>", n * 2 * sizeof(T));
+  PRIM2(rocprim::inclusive_scan(tmp, tb, in, out, n, rocprim::maximum<T>(), c->stream));
 }
+template void inclusive_max<uint32_t>(pfp_ctx *, const uint32_t *, uint32_t *, size_t);
+template void inclusive_max<uint64_t>(pfp_ctx *, const uint64_t *, uint64_t *, size_t);
 struct EqU8 { uint8_t v; __host__ __device__ uint32_t operator()(uint8_t x) const { return x == v ? 1u : 0u; } };
 void inclusive_count_eq_u8(pfp_ctx *c, const uint8_t *bytes, uint8_t value, uint32_t *out, size_t n) {
   if (!n) return;
@@ -77,17 +107,17 @@ void select_flagged_u32(pfp_ctx *c, const uint32_t *in, const uint8_t *flags, ui
 // ~95 G flags/s (2.8 ms for the 260 M hard-group flags of the 253 MB workload); the flags are bytes, so a
 // workgroup can count and place 4096 of them from 16-byte loads: two streaming passes over n bytes.
 constexpr int kSelTile = 4096;
-// eq < 0: flag = byte != 0;  eq >= 0: flag = byte == eq
+// eq < 0: flag = byte != 0;  eq >= 0: flag = byte == eq.  Unaligned 16-byte loads (any base address).
 __device__ __forceinline__ void load_sel16(const uint8_t *__restrict__ flags, uint64_t base, uint64_t n, int eq, uint32_t w[4]) {
-  if (eq < 0) { load_flags16(flags, base, n, w); return; }
-  const uint32_t V = 0x01010101u * (uint32_t)eq;
+  const uint32_t V = eq < 0 ? 0u : 0x01010101u * (uint32_t)eq, X = eq < 0 ? 0u : 0x01010101u;
   if (base + 16 <= n) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(flags + base);
-    w[0] = nonzero_bytes(v.x ^ V) ^ 0x01010101u; w[1] = nonzero_bytes(v.y ^ V) ^ 0x01010101u;
-    w[2] = nonzero_bytes(v.z ^ V) ^ 0x01010101u; w[3] = nonzero_bytes(v.w ^ V) ^ 0x01010101u;
+    const uint4 v = ld16u(flags + base);
+    w[0] = nonzero_bytes(v.x ^ V) ^ X; w[1] = nonzero_bytes(v.y ^ V) ^ X;
+    w[2] = nonzero_bytes(v.z ^ V) ^ X; w[3] = nonzero_bytes(v.w ^ V) ^ X;
   } else {
     w[0] = w[1] = w[2] = w[3] = 0;
-    for (int k = 0; k < 16; k++) if (base + k < n && flags[base + k] == (uint8_t)eq) w[k >> 2] |= 1u << (8 * (k & 3));
+    for (int k = 0; k < 16; k++)
+      if (base + k < n && (eq < 0 ? flags[base + k] != 0 : flags[base + k] == (uint8_t)eq)) w[k >> 2] |= 1u << (8 * (k & 3));
   }
 }
 __global__ __launch_bounds__(256) void flag_count_kernel(const uint8_t *__restrict__ flags, uint64_t n, int eq,
@@ -102,8 +132,9 @@ __global__ __launch_bounds__(256) void flag_count_kernel(const uint8_t *__restri
   __syncthreads();
   if (threadIdx.x == 0) blocksum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
+template <class I>
 __global__ __launch_bounds__(256) void flag_place_kernel(const uint8_t *__restrict__ flags, uint64_t n, int eq,
-                                                         const uint32_t *__restrict__ blockoff, uint32_t *__restrict__ out) {
+                                                         const uint64_t *__restrict__ blockoff, I *__restrict__ out) {
   __shared__ uint32_t ws[4];
   const uint64_t base = (uint64_t)blockIdx.x * kSelTile + (uint64_t)threadIdx.x * 16;
   uint32_t w[4];
@@ -114,39 +145,57 @@ __global__ __launch_bounds__(256) void flag_place_kernel(const uint8_t *__restri
   for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
   if (lane == 63) ws[wv] = inc;
   __syncthreads();
-  uint32_t pos = blockoff[blockIdx.x] + inc - cnt;
+  uint64_t pos = blockoff[blockIdx.x] + inc - cnt;
   for (int q = 0; q < wv; q++) pos += ws[q];
   if (!cnt) return;
 #pragma unroll
   for (int k = 0; k < 16; k++)
-    if ((w[k >> 2] >> (8 * (k & 3))) & 1u) out[pos++] = (uint32_t)(base + k);
+    if ((w[k >> 2] >> (8 * (k & 3))) & 1u) out[pos++] = (I)(base + k);
 }
-static void select_bytes(pfp_ctx *c, const uint8_t *flags, int eq, uint32_t *out, uint32_t *d_count, size_t n);
-void select_index_u32(pfp_ctx *c, const uint8_t *flags, uint32_t *out, uint32_t *d_count, size_t n) {
-  if (!n) { PFP_HIP(hipMemsetAsync(d_count, 0, 4, c->stream)); return; }
-  if ((reinterpret_cast<uintptr_t>(flags) & 15) != 0) {      // unaligned view: library path
-    rocprim::counting_iterator<uint32_t> it(0);
-    PRIM2(rocprim::select(tmp, tb, it, flags, out, d_count, n, c->stream));
-    return;
-  }
-  select_bytes(c, flags, -1, out, d_count, n);
-}
-// indices of the bytes equal to `value` (16-byte aligned buffer)
-void select_byte_index_u32(pfp_ctx *c, const uint8_t *bytes, uint8_t value, uint32_t *out, uint32_t *d_count, size_t n) {
-  if (!n) { PFP_HIP(hipMemsetAsync(d_count, 0, 4, c->stream)); return; }
-  PFP_REQUIRE((reinterpret_cast<uintptr_t>(bytes) & 15) == 0, PFP_EINVAL, "select_byte_index_u32: unaligned buffer");
-  select_bytes(c, bytes, (int)value, out, d_count, n);
-}
-static void select_bytes(pfp_ctx *c, const uint8_t *flags, int eq, uint32_t *out, uint32_t *d_count, size_t n) {
+template <class I>
+static void select_bytes(pfp_ctx *c, const uint8_t *flags, int eq, I *out, uint64_t *d_count, size_t n) {
+  if (!n) { PFP_HIP(hipMemsetAsync(d_count, 0, 8, c->stream)); return; }
   const size_t nblk = (n + kSelTile - 1) / kSelTile;
-  DBuf<uint32_t> bsum(c, nblk + 1), boff(c, nblk + 1);
+  DBuf<uint32_t> bsum(c, nblk + 1);
+  DBuf<uint64_t> boff(c, nblk + 1);
   PFP_HIP(hipMemsetAsync(bsum.p + nblk, 0, 4, c->stream));
   KScope ks(c, "pfp::select_flags_kernel", n * 2);
   hipLaunchKernelGGL(flag_count_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, flags, (uint64_t)n, eq, bsum.p);
-  exclusive_sum_u32(c, bsum.p, boff.p, nblk + 1);
-  hipLaunchKernelGGL(flag_place_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, flags, (uint64_t)n, eq, boff.p, out);
+  exclusive_sum_u32_u64(c, bsum.p, boff.p, nblk + 1);
+  hipLaunchKernelGGL(flag_place_kernel<I>, dim3((unsigned)nblk), dim3(256), 0, c->stream, flags, (uint64_t)n, eq, boff.p, out);
   PFP_HIP(hipGetLastError());
-  PFP_HIP(hipMemcpyAsync(d_count, boff.p + nblk, 4, hipMemcpyDeviceToDevice, c->stream));
+  PFP_HIP(hipMemcpyAsync(d_count, boff.p + nblk, 8, hipMemcpyDeviceToDevice, c->stream));
+}
+template <class I> void select_index(pfp_ctx *c, const uint8_t *flags, I *out, uint64_t *d_count, size_t n) {
+  select_bytes<I>(c, flags, -1, out, d_count, n);
+}
+template <class I> void select_byte_index(pfp_ctx *c, const uint8_t *bytes, uint8_t value, I *out, uint64_t *d_count, size_t n) {
+  select_bytes<I>(c, bytes, (int)value, out, d_count, n);
+}
+template void select_index<uint32_t>(pfp_ctx *, const uint8_t *, uint32_t *, uint64_t *, size_t);
+template void select_index<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t *, uint64_t *, size_t);
+template void select_byte_index<uint32_t>(pfp_ctx *, const uint8_t *, uint8_t, uint32_t *, uint64_t *, size_t);
+template void select_byte_index<uint64_t>(pfp_ctx *, const uint8_t *, uint8_t, uint64_t *, uint64_t *, size_t);
+
+__global__ __launch_bounds__(256) void sum_u32_kernel(const uint32_t *__restrict__ a, uint64_t n, unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long ws[4];
+  unsigned long long x = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) x += a[i];
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+uint64_t count_flags(pfp_ctx *c, const uint8_t *flags, size_t n) {
+  if (!n) return 0;
+  const size_t nblk = (n + kSelTile - 1) / kSelTile;
+  DBuf<uint32_t> bsum(c, nblk);
+  DBuf<unsigned long long> tot(c, 1);
+  tot.zero();
+  hipLaunchKernelGGL(flag_count_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, flags, (uint64_t)n, -1, bsum.p);
+  hipLaunchKernelGGL(sum_u32_kernel, dim3((unsigned)std::min<size_t>((nblk + 255) / 256, 256)), dim3(256), 0, c->stream, bsum.p, (uint64_t)nblk, tot.p);
+  PFP_HIP(hipGetLastError());
+  return read_scalar(c, (const uint64_t *)tot.p);
 }
 
 }  // namespace pfp

@@ -28,11 +28,11 @@ namespace pfp {
 enum : int { MODE_DICT = 0, MODE_PLAIN = 1 };
 
 struct SufGeom {
-  int mode; uint64_t N; const uint32_t *endpos;   // endpos[i] = position of the terminator of i's word
+  int mode; uint64_t N; const uint32_t *slen;   // slen[i] = distance from i to the terminator of i's word
 };
 // length of the suffix string starting at i, terminator included
-__device__ __forceinline__ uint64_t suf_len(const SufGeom &g, uint32_t i) {
-  if (g.mode == MODE_DICT) return (uint64_t)g.endpos[i] - i + 1;
+__device__ __forceinline__ uint64_t suf_len(const SufGeom &g, uint64_t i) {
+  if (g.mode == MODE_DICT) return (uint64_t)g.slen[i] + 1;
   return g.N - i;
 }
 
@@ -169,16 +169,17 @@ __device__ __forceinline__ uint64_t packed_key_at(const uint8_t *__restrict__ s,
 // singleton or a set of identical strings.  An unresolved tie whose continuations are settled is
 // itself a set of identical strings (their sorted prefixes reach the terminator), which is how
 // write_back retires groups without gathering the suffix length of every member every round.
-__device__ __forceinline__ uint32_t rank_at(const RankView &L, uint64_t j, bool &settled) {
-  const uint32_t r = L.rank[j];
-  if (L.skeys == nullptr || r != kNoRank) { settled = (r & L.finbit) != 0; return r & ~L.finbit; }
+template <class I>
+__device__ __forceinline__ I rank_at(const RankViewT<I> &L, uint64_t j, bool &settled) {
+  const I r = L.rank[j];
+  if (L.skeys == nullptr || r != IdxTraits<I>::kNone) { settled = (r & L.finbit) != 0; return r & ~L.finbit; }
   settled = true;
   const uint64_t k = packed_key_at(L.bytes, j, L.kbits, L.lut);
   const uint32_t b = (uint32_t)(k >> L.shift);
-  uint32_t lo = 0xFFFFFFFFu - L.tab[L.T - 1 - b];
-  uint32_t hi = (b + 1 < L.T) ? 0xFFFFFFFFu - L.tab[L.T - 2 - b] : (uint32_t)L.N;
+  I lo = IdxTraits<I>::kNone - L.tab[L.T - 1 - b];
+  I hi = (b + 1 < L.T) ? IdxTraits<I>::kNone - L.tab[L.T - 2 - b] : (I)L.N;
   while (lo < hi) {
-    const uint32_t mid = lo + ((hi - lo) >> 1);
+    const I mid = lo + ((hi - lo) >> 1);
     if ((L.skeys[mid] & L.keymask) < k) lo = mid + 1; else hi = mid;
   }
   return lo;
@@ -188,7 +189,7 @@ __device__ __forceinline__ uint32_t rank_at(const RankView &L, uint64_t j, bool 
 // nothing, <= w long, pfbwt.cpp:151), high byte = occurrences of its word, 255 = "255 or more"
 __device__ __forceinline__ uint32_t slot_record(const uint8_t *__restrict__ b, uint64_t i, const SlotPayloadSrc &P) {
   const uint32_t wd = P.pos_word[i];
-  if (!(wd < P.d && (P.endpos[i] - (uint32_t)i) > (uint32_t)P.w)) return 0u;
+  if (!(wd < P.d && P.slen[i] > (uint32_t)P.w)) return 0u;
   const uint32_t pc = (i == 0) ? kEndOfWord : b[i - 1];
   const uint32_t occ = P.wocc[wd];
   return pc | ((occ < 255u ? occ : 255u) << 8);
@@ -203,7 +204,7 @@ struct KeyStreamLds { uint32_t off[257]; uint32_t bs[200]; uint32_t wsum[4]; };
 // workgroup-cooperative: returns the key (code bits << 1 | terminator flag) of position B0 + threadIdx.x
 // for threadIdx.x < kKeyPos and position < N; every thread of the workgroup must call it
 __device__ __forceinline__ uint64_t block_stream_key(KeyStreamLds &L, const uint8_t *__restrict__ s, uint64_t N,
-                                                     const KeyCode &kp, const uint32_t *__restrict__ endpos, uint64_t B0) {
+                                                     const KeyCode &kp, const uint32_t *__restrict__ slen, uint64_t B0) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint64_t pos = B0 + t;
   if (t < 200) L.bs[t] = 0;
@@ -230,8 +231,7 @@ __device__ __forceinline__ uint64_t block_stream_key(KeyStreamLds &L, const uint
   }
   __syncthreads();
   if (t >= kKeyPos || pos >= N) return 0;
-  const uint32_t eo = endpos[pos];              // terminator of this position's word
-  const uint32_t toterm = eo - (uint32_t)pos + 1;                 // characters up to and including it
+  const uint32_t toterm = slen[pos] + 1;        // characters up to and including the terminator of this position's word
   const uint32_t nch = toterm < 32u ? toterm : 32u;
   const uint32_t avail = L.off[t + nch] - p;
   const uint32_t kb = (uint32_t)kp.kbits;
@@ -245,17 +245,18 @@ __device__ __forceinline__ uint64_t block_stream_key(KeyStreamLds &L, const uint
   const uint32_t term = (toterm <= 32u && L.off[t + toterm] - p <= kb) ? 1u : 0u;
   return (k << 1) | term;
 }
+template <class I>
 __global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
-                                                               const uint32_t *__restrict__ endpos, SlotPayloadSrc P,
+                                                               const uint32_t *__restrict__ slen, SlotPayloadSrc P,
                                                                int paybits, uint64_t *__restrict__ key,
-                                                               uint32_t *__restrict__ val) {
+                                                               I *__restrict__ val) {
   __shared__ KeyStreamLds L;
   const uint64_t B0 = (uint64_t)blockIdx.x * kKeyPos;
-  uint64_t k = block_stream_key(L, s, N, kp, endpos, B0);
+  uint64_t k = block_stream_key(L, s, N, kp, slen, B0);
   const uint64_t pos = B0 + threadIdx.x;
   if (threadIdx.x >= kKeyPos || pos >= N) return;
   if (paybits) k |= (uint64_t)slot_record(s, pos, P) << 48;
-  key[pos] = k; val[pos] = (uint32_t)pos;
+  key[pos] = k; val[pos] = (I)pos;
 }
 // PFP_DEBUG: the bit-stream keys against the character-by-character ones
 __global__ void check_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp, const uint64_t *__restrict__ key,
@@ -264,12 +265,13 @@ __global__ void check_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, Key
   if (i >= N) return;
   if ((key[i] & keymask) != packed_key_at(s, i, kp.kbits, kp.lut)) atomicAdd(bad, 1ull);
 }
+template <class I>
 __global__ void init_keys_bytes_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
-                                       uint32_t *__restrict__ val) {
+                                       I *__restrict__ val) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   key[i] = __builtin_bswap64(ld8u(s + i));         // buffer is zero padded past N
-  val[i] = (uint32_t)i;
+  val[i] = (I)i;
 }
 __global__ void init_keys_int_kernel(const uint32_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
                                      uint32_t *__restrict__ val) {
@@ -312,36 +314,40 @@ __global__ void init_keys_int_run_kernel(const uint32_t *__restrict__ s, uint32_
   key[i] = (a << (64 - sb)) | (b << (64 - 2 * sb)) | e;
   val[i] = i;
 }
-__global__ void iota32_kernel(uint32_t *p, uint64_t n) {
+template <class I>
+__global__ void iota_kernel(I *p, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = (uint32_t)i;
+  if (i < n) p[i] = (I)i;
 }
 
 // key of an unresolved suffix: (its group's head slot, 1 + rank of the suffix h further on).
 // The suffix position and its group travel with the active list (active_place_kernel), so the only
 // random access is rank[i+h].  In dictionary mode an unresolved suffix is always longer than the
 // sorted prefix h (otherwise write_back would have retired it), so i+h stays inside its word.
-__global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ act_i,
-                                  const uint32_t *__restrict__ act_grp, RankView L, int nb,
-                                  uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+template <class I>
+__global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const I *__restrict__ act_i,
+                                  const I *__restrict__ act_grp, RankViewT<I> L, int nb,
+                                  typename IdxTraits<I>::DKey *__restrict__ key, I *__restrict__ val) {
+  using K = typename IdxTraits<I>::DKey;
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
-  const uint32_t i = act_i[a];
-  const uint64_t grp = act_grp[a];
+  const I i = act_i[a];
+  const K grp = act_grp[a];
   bool settled = false;
   const uint64_t nxt = (g.mode == MODE_DICT || (uint64_t)i + h < g.N) ? (uint64_t)rank_at(L, (uint64_t)i + h, settled) + 1 : 0;
-  key[a] = (grp << nb) | nxt;
-  val[a] = i | (settled ? L.finbit : 0u);
+  key[a] = (grp << nb) | (K)nxt;
+  val[a] = i | (settled ? L.finbit : (I)0);
 }
 
 // segmented variant of a doubling round: the unresolved suffixes are already grouped (the active
 // list is in slot order), so only the 32-bit "next" key has to be sorted, inside every group
-__global__ void group_starts_kernel(uint64_t m, const uint32_t *__restrict__ act_grp, uint8_t *__restrict__ gs) {
+template <class I>
+__global__ void group_starts_kernel(uint64_t m, const I *__restrict__ act_grp, uint8_t *__restrict__ gs) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a < m) gs[a] = (a == 0 || act_grp[a] != act_grp[a - 1]) ? 1 : 0;
 }
 __global__ void build_keys32_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ act_i,
-                                    RankView L, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+                                    RankViewT<uint32_t> L, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const uint32_t i = act_i[a];
@@ -357,13 +363,14 @@ __global__ void seg_end_kernel(uint32_t ng, uint32_t m, const uint32_t *__restri
   for (int o = 32; o > 0; o >>= 1) { uint32_t v = __shfl_down(len, o, 64); len = v > len ? v : len; }
   if ((threadIdx.x & 63) == 0 && len) atomicMax(maxlen, len);
 }
+template <class I>
 __global__ void heads32_kernel(uint64_t m, const uint8_t *__restrict__ gs, const uint32_t *__restrict__ key,
-                               const uint32_t *__restrict__ aslot, uint8_t *__restrict__ hd, uint32_t *__restrict__ hv) {
+                               const I *__restrict__ aslot, uint8_t *__restrict__ hd, I *__restrict__ hv) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   bool h = gs[a] || key[a] != key[a - 1];
   hd[a] = h ? 1 : 0;
-  hv[a] = h ? aslot[a] : 0u;
+  hv[a] = h ? aslot[a] : (I)0;
 }
 
 // Compaction of the active list: kept suffixes and kept group heads counted per 256 list positions
@@ -385,13 +392,14 @@ __global__ __launch_bounds__(256) void active_count_kernel(const uint8_t *__rest
   for (int o = 8; o > 0; o >>= 1) { ck += __shfl_down(ck, o, 16); ch += __shfl_down(ch, o, 16); }
   if ((threadIdx.x & 15) == 0 && base < m) { tile_keep[t >> 4] = ck; tile_heads[t >> 4] = ch; }
 }
+template <class I>
 __global__ __launch_bounds__(256) void active_place_kernel(const uint8_t *__restrict__ keep, uint64_t m,
                                                            const uint32_t *__restrict__ tile_keep,
-                                                           const uint32_t *__restrict__ tile_off,
-                                                           const uint32_t *__restrict__ aslot, const uint32_t *__restrict__ val,
-                                                           const uint32_t *__restrict__ newhead, uint32_t finbit,
-                                                           uint32_t *__restrict__ aslot2, uint32_t *__restrict__ act_i,
-                                                           uint32_t *__restrict__ act_grp) {
+                                                           const I *__restrict__ tile_off,
+                                                           const I *__restrict__ aslot, const I *__restrict__ val,
+                                                           const I *__restrict__ newhead, I finbit,
+                                                           I *__restrict__ aslot2, I *__restrict__ act_i,
+                                                           I *__restrict__ act_grp) {
   __shared__ uint32_t ws[4];
   if (tile_keep[blockIdx.x] == 0) return;       // nothing kept in these 256 positions (most tiles after the first round)
   const uint64_t a = (uint64_t)blockIdx.x * kTile + threadIdx.x;
@@ -401,18 +409,19 @@ __global__ __launch_bounds__(256) void active_place_kernel(const uint8_t *__rest
   if (lane == 0) ws[wv] = (uint32_t)__popcll(mask);
   __syncthreads();
   if (!k) return;
-  uint32_t pos = tile_off[blockIdx.x] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  I pos = tile_off[blockIdx.x] + (I)__popcll(mask & ((1ull << lane) - 1ull));
   for (int q = 0; q < wv; q++) pos += ws[q];
-  aslot2[pos] = aslot ? aslot[a] : (uint32_t)a; act_i[pos] = val[a] & ~finbit; act_grp[pos] = newhead[a];      // no list yet: slot == index
+  aslot2[pos] = aslot ? aslot[a] : (I)a; act_i[pos] = val[a] & ~finbit; act_grp[pos] = newhead[a];      // no list yet: slot == index
 }
 
-__global__ void heads_kernel(uint64_t m, const uint64_t *__restrict__ key, const uint32_t *__restrict__ aslot,
-                             uint8_t *__restrict__ hd, uint32_t *__restrict__ hv) {
+template <class I, class K>
+__global__ void heads_kernel(uint64_t m, const K *__restrict__ key, const I *__restrict__ aslot,
+                             uint8_t *__restrict__ hd, I *__restrict__ hv) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   bool h = (a == 0) || key[a] != key[a - 1];
   hd[a] = h ? 1 : 0;
-  hv[a] = h ? aslot[a] : 0u;
+  hv[a] = h ? aslot[a] : (I)0;
 }
 
 // First round of dictionary mode (slot == index): group heads, and the bucket table of the sorted
@@ -420,65 +429,67 @@ __global__ void heads_kernel(uint64_t m, const uint64_t *__restrict__ key, const
 // Per workgroup of 256 slots also the index of its last head (0 = none, slot 0 is always a head): a
 // max-scan over those 4 bytes per 256 slots gives every workgroup of write_back0 its carry-in, and
 // the head of each slot is found from the head flags with ballots - no N-long scan of head indices.
+template <class I>
 __global__ __launch_bounds__(256) void heads0_kernel(uint64_t m, const uint64_t *__restrict__ key, uint64_t keymask, int shift,
-                                                     uint32_t T, uint8_t *__restrict__ hd, uint32_t *__restrict__ tile_last,
-                                                     uint32_t *__restrict__ tab) {
-  __shared__ uint32_t wl[4];
+                                                     uint32_t T, uint8_t *__restrict__ hd, I *__restrict__ tile_last,
+                                                     I *__restrict__ tab) {
+  __shared__ I wl[4];
   const uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   bool h = false;
   if (a < m) {
     const uint64_t k = key[a] & keymask, kprev = a ? (key[a - 1] & keymask) : ~k;
     h = k != kprev;
     hd[a] = h ? 1 : 0;
-    if (a == 0 || (k >> shift) != (kprev >> shift)) tab[T - 1 - (uint32_t)(k >> shift)] = 0xFFFFFFFFu - (uint32_t)a;
+    if (a == 0 || (k >> shift) != (kprev >> shift)) tab[T - 1 - (uint32_t)(k >> shift)] = IdxTraits<I>::kNone - (I)a;
   }
   const unsigned long long mask = __ballot(h);
   if ((threadIdx.x & 63) == 0)
-    wl[threadIdx.x >> 6] = mask ? (uint32_t)(blockIdx.x * 256ull + (threadIdx.x & ~63) + (63 - __clzll((long long)mask))) : 0u;
+    wl[threadIdx.x >> 6] = mask ? (I)(blockIdx.x * 256ull + (threadIdx.x & ~63) + (63 - __clzll((long long)mask))) : (I)0;
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t v = wl[0];
+    I v = wl[0];
     for (int q = 1; q < 4; q++) v = wl[q] > v ? wl[q] : v;
     tile_last[blockIdx.x] = v;
   }
 }
-__global__ void fill_u32_kernel(uint32_t *p, uint64_t n, uint32_t v) {
+template <class I>
+__global__ void fill_kernel(I *p, uint64_t n, I v) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
 // First round of dictionary mode: sa and grp are the sorted values / scanned heads themselves
 // (streaming copies); rank[] is written only for the suffixes that stay unresolved.
-__global__ __launch_bounds__(256) void write_back0_kernel(uint64_t m, const uint32_t *__restrict__ val,
-                                                          const uint32_t *__restrict__ tile_scan,
+template <class I>
+__global__ __launch_bounds__(256) void write_back0_kernel(uint64_t m, const I *__restrict__ val,
+                                                          const I *__restrict__ tile_scan,
                                                           const uint8_t *__restrict__ hd, const uint64_t *__restrict__ key0,
-                                                          uint32_t *__restrict__ sa, uint32_t *__restrict__ rank,
-                                                          uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
-  __shared__ uint32_t wl[4];
+                                                          I *__restrict__ rank,
+                                                          I *__restrict__ grp, uint8_t *__restrict__ keep) {
+  __shared__ I wl[4];
   const uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // all loads first: nothing below the barrier waits on memory except the carry-in
   const bool in = a < m;
   const bool h = in && hd[a];
   const bool hnext = in && (a + 1 == m || hd[a + 1]);
-  const uint32_t i = in ? val[a] : 0u;
+  const I i = in ? val[a] : (I)0;
   const uint32_t flagbit = in ? (uint32_t)(key0[a] & 1ull) : 0u;
-  const uint32_t carry = blockIdx.x ? tile_scan[blockIdx.x - 1] : 0u;
+  const I carry = blockIdx.x ? tile_scan[blockIdx.x - 1] : (I)0;
   const unsigned long long mask = __ballot(h);
-  const uint32_t wbase = (uint32_t)(blockIdx.x * 256ull + (threadIdx.x & ~63));
-  if (lane == 0) wl[wv] = mask ? wbase + (63 - __clzll((long long)mask)) : 0u;
+  const I wbase = (I)(blockIdx.x * 256ull + (threadIdx.x & ~63));
+  if (lane == 0) wl[wv] = mask ? wbase + (63 - __clzll((long long)mask)) : (I)0;
   __syncthreads();
   if (!in) return;
   // head of slot a: the last head flag at or before it - in its wave, else in an earlier wave of the
   // workgroup, else the carry-in (last head of all earlier workgroups)
   const unsigned long long upto = mask & (~0ull >> (63 - lane));
-  uint32_t head;
+  I head;
   if (upto) head = wbase + (63 - __clzll((long long)upto));
   else {
     head = carry;
     for (int q = 0; q < wv; q++) head = wl[q] > head ? wl[q] : head;
   }
-  sa[a] = i;
-  grp[a] = head;
+  grp[a] = head;       // sa[] is the sorted value array itself (moved into place by the host)
   const bool single = h && hnext;
   const bool fin = !single && flagbit;       // the terminator is inside the key: the tied strings are identical
   const bool k = !single && !fin;
@@ -488,8 +499,9 @@ __global__ __launch_bounds__(256) void write_back0_kernel(uint64_t m, const uint
 
 // dense fallback after the first round: many suffixes stay unresolved, so most lookups would need
 // the search; scatter the settled ranks once instead (the pre-lazy behaviour)
-__global__ void scatter_settled_kernel(uint64_t N, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ grp,
-                                       const uint8_t *__restrict__ keep, uint32_t finbit, uint32_t *__restrict__ rank) {
+template <class I>
+__global__ void scatter_settled_kernel(uint64_t N, const I *__restrict__ sa, const I *__restrict__ grp,
+                                       const uint8_t *__restrict__ keep, I finbit, I *__restrict__ rank) {
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < N && !keep[t]) rank[sa[t]] = grp[t] | finbit;
 }
@@ -510,16 +522,17 @@ __global__ void scatter_settled_kernel(uint64_t N, const uint32_t *__restrict__ 
 constexpr int kPivBits = 23;
 constexpr uint32_t kPivEq = 1u << 21;
 constexpr uint32_t kPivCapMax = 8192;
+template <class I>
 __global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t m, uint64_t from, uint32_t cap,
-                                        const uint32_t *__restrict__ act_i, const uint32_t *__restrict__ act_grp,
-                                        const uint32_t *__restrict__ sa, uint32_t finbit, uint64_t *__restrict__ key,
-                                        uint32_t *__restrict__ key32, uint32_t *__restrict__ val) {
+                                        const I *__restrict__ act_i, const I *__restrict__ act_grp,
+                                        const I *__restrict__ sa, I finbit, uint64_t *__restrict__ key,
+                                        uint32_t *__restrict__ key32, I *__restrict__ val) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
-  const uint32_t i = act_i[a], grp = act_grp[a];
-  const uint32_t piv = sa[grp];
+  const I i = act_i[a], grp = act_grp[a];
+  const I piv = sa[grp];
   uint32_t ok = kPivEq;
-  uint32_t settled = finbit;
+  I settled = finbit;
   if (i != piv) {
     settled = 0;
     const uint8_t *pa = s + i + from, *pp = s + piv + from;
@@ -565,8 +578,9 @@ __global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t 
 }
 // a member of P's class without the settled bit (equal to P for cap bytes, unknown beyond): nobody in
 // that class may settle this round
+template <class I>
 __global__ void pivot_veto_kernel(uint64_t m, const uint64_t *__restrict__ key, const uint32_t *__restrict__ key32,
-                                  const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead, uint32_t finbit,
+                                  const I *__restrict__ val, const I *__restrict__ newhead, I finbit,
                                   uint8_t *__restrict__ veto) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
@@ -578,16 +592,17 @@ __global__ void pivot_veto_kernel(uint64_t m, const uint64_t *__restrict__ key, 
 // sorted_len = prefix length that is sorted after this round.
 // Round 0 (key0 != nullptr) decides "whole string inside the sorted prefix" from the packed key
 // itself (some field holds the terminator code 1): no gather.
-__global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, const uint32_t *__restrict__ aslot,
-                                  const uint32_t *__restrict__ val, const uint32_t *__restrict__ newhead,
-                                  const uint8_t *__restrict__ hd, uint32_t finbit, const uint64_t *__restrict__ prevkey,
-                                  int prevshift, const uint32_t *__restrict__ prevgrp, const uint8_t *__restrict__ veto,
-                                  const uint8_t *__restrict__ lazy_bytes, uint32_t *__restrict__ sa,
-                                  uint32_t *__restrict__ rank, uint32_t *__restrict__ grp, uint8_t *__restrict__ keep) {
+template <class I, class K>
+__global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, const I *__restrict__ aslot,
+                                  const I *__restrict__ val, const I *__restrict__ newhead,
+                                  const uint8_t *__restrict__ hd, I finbit, const K *__restrict__ prevkey,
+                                  int prevshift, const I *__restrict__ prevgrp, const uint8_t *__restrict__ veto,
+                                  const uint8_t *__restrict__ lazy_bytes, I *__restrict__ sa,
+                                  I *__restrict__ rank, I *__restrict__ grp, uint8_t *__restrict__ keep) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
-  const uint32_t iv = val[a], i = iv & ~finbit;
-  const uint32_t slot = aslot[a];
+  const I iv = val[a], i = iv & ~finbit;
+  const I slot = aslot[a];
   sa[slot] = i;
   grp[slot] = newhead[a];       // slot-side copy of the group head: the merge never gathers rank[]
   bool single = hd[a] && (a + 1 == m || hd[a + 1]);
@@ -599,26 +614,28 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
   const bool k = !single && !fin;
   // rank[i] already holds the old group head: a suffix that stays unresolved in a group that kept
   // its head needs no write - the scattered 4-byte store is the expensive access of this kernel
-  const uint32_t old = prevkey ? (uint32_t)(prevkey[a] >> prevshift) : (prevgrp ? prevgrp[a] : ~newhead[a]);
+  const I old = prevkey ? (I)(prevkey[a] >> prevshift) : (prevgrp ? prevgrp[a] : ~newhead[a]);
   // Pivot rounds (lazy_bytes != null) do not read rank[], so the rank of a suffix that settles there is
   // written only if somebody will ask for it - the whole words, whose ranks order the dictionary
   // (compute_lexrank); every other settled rank is filled in by repair_ranks_kernel if a doubling
   // round follows after all.  One byte read replaces the scattered 4-byte store.
   bool wr = k ? old != newhead[a] : true;
   if (!k && lazy_bytes) wr = i == 0 || lazy_bytes[i - 1] == kEndOfWord;
-  if (wr) rank[i] = newhead[a] | (k ? 0u : finbit);
+  if (wr) rank[i] = newhead[a] | (k ? (I)0 : finbit);
   keep[a] = k ? 1 : 0;
 }
 
 // ranks that pivot rounds left unwritten: every slot re-ordered after the first round that is not in
 // the active list any more holds a settled suffix
-__global__ void mark_slots_kernel(uint64_t m, const uint32_t *__restrict__ aslot, uint8_t *__restrict__ flag) {
+template <class I>
+__global__ void mark_slots_kernel(uint64_t m, const I *__restrict__ aslot, uint8_t *__restrict__ flag) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a < m) flag[aslot[a]] = 1;
 }
+template <class I>
 __global__ void repair_ranks_kernel(uint64_t N, const uint8_t *__restrict__ refined, const uint8_t *__restrict__ active,
-                                    const uint32_t *__restrict__ sa, const uint32_t *__restrict__ grp, uint32_t finbit,
-                                    uint32_t *__restrict__ rank) {
+                                    const I *__restrict__ sa, const I *__restrict__ grp, I finbit,
+                                    I *__restrict__ rank) {
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < N && refined[t] && !active[t]) rank[sa[t]] = grp[t] | finbit;
 }
@@ -631,95 +648,137 @@ static const uint32_t kPivotCap = []() { const char *e = getenv("PFP_PIVOT_CAP")
 // the first round leaves more than N/kLazyRatio suffixes unresolved -> scatter all ranks after all
 static const uint64_t kLazyRatio = []() { const char *e = getenv("PFP_LAZY_RATIO"); return e ? (uint64_t)atoll(e) : 8ull; }();
 
-RankView rank_view(const SuffixOrder &so) {
-  return RankView{so.rank.p, so.skeys.p, so.tab.p, so.lut.p, so.bytes, so.N, so.kbits, so.shift, so.T, so.finbit, so.keymask};
+template <class I>
+RankViewT<I> rank_view(const SuffixOrderT<I> &so) {
+  return RankViewT<I>{so.rank.p, so.skeys.p, so.tab.p, so.lut.p, so.bytes, so.N, so.kbits, so.shift, so.T, so.finbit, so.keymask};
 }
+template RankViewT<uint32_t> rank_view(const SuffixOrderT<uint32_t> &);
+template RankViewT<uint64_t> rank_view(const SuffixOrderT<uint64_t> &);
 
-static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> &val, uint64_t h0, SuffixOrder &out,
+template <class I>
+static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, uint64_t h0, SuffixOrderT<I> &out,
                      int key0_bits = 64, bool dict_keys = false, uint64_t n_elems = ~0ull) {
   // precondition: key/val hold the initial (prefix key, position) pairs of the N suffixes to sort: all
   // NP positions, or (range mode, n_elems given) the ones of this rank's key range
+  using K = typename IdxTraits<I>::DKey;        // key of a doubling round: (group head, 1 + rank of the continuation)
+  constexpr bool kWide = sizeof(I) == 8;
   const uint64_t NP = g.N;
   const bool range_mode = n_elems != ~0ull;
   const uint64_t N = range_mode ? n_elems : NP;
   const int TB = 256;
   out.N = N; out.NP = NP; out.range = range_mode; out.complete = true;
   out.rounds = 0;
-  out.sa.alloc(c, N); out.rank.alloc(c, NP); out.grp.alloc(c, N + 8);
-  if (N == 0) return;
-  DBuf<uint64_t> keyo(c, N);
-  DBuf<uint32_t> valo(c, N), aslot(c, N), aslot2(c, N), hv(c, N), newhead(c, N), act_i(c, N), act_grp(c, N);
-  DBuf<uint8_t> hd(c, N + 1), keep(c, N);
-  sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, N, 0, key0_bits);
-  if (!dict_keys) hipLaunchKernelGGL(iota32_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, aslot.p, N);
-  uint64_t m = N, h = h0;
-  out.rounds = 0;
-  bool first = true;
+  if (N == 0) { out.sa.alloc(c, 1); out.grp.alloc(c, 8); out.rank.alloc(c, 1); return; }
   const bool lazy = dict_keys;      // dictionary mode: out.lut/bytes/kbits are set by the caller
+  // ---- first round: one device-wide sort of all N (key, position) pairs, ping-ponging between the two buffer
+  //      pairs (no third copy inside the library); afterwards keyo/valo hold the sorted pairs
+  DBuf<uint64_t> keyo(c, N);
+  DBuf<I> valo(c, N);
+  sort_pairs_db(c, key, keyo, val, valo, N, 0, key0_bits);
+  std::swap(key, keyo); std::swap(val, valo);
+  if (lazy) { key.release(); val.release(); }      // dictionary mode: later rounds sort the (much smaller) unresolved set
+  // active list (slot, suffix, group) of the unresolved suffixes and per-round scratch, `cap` elements each;
+  // dictionary mode allocates them when the first round has told how many suffixes stay unresolved
+  DBuf<I> aslot, aslot2, hv, newhead, act_i, act_grp;
+  uint64_t list_cap = 0;
+  auto alloc_lists = [&](uint64_t cap) {
+    aslot.alloc(c, cap); aslot2.alloc(c, cap); hv.alloc(c, cap); newhead.alloc(c, cap); act_i.alloc(c, cap); act_grp.alloc(c, cap);
+    list_cap = cap;
+  };
+  DBuf<uint8_t> hd(c, N + 1), keep(c, N);
+  out.grp.alloc(c, N + 8);
+  out.rank.alloc(c, NP);
+  if (!lazy) {
+    out.sa.alloc(c, N);
+    alloc_lists(N);
+    hipLaunchKernelGGL(iota_kernel<I>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, aslot.p, N);
+  }
+  uint64_t m = N, h = h0;
+  bool first = true;
   if (lazy) {
     const int tb = std::min(key0_bits, std::max(8, std::min(24, bits_for(N) - 5)));
     out.shift = key0_bits - tb;
     out.T = 1u << tb;
     out.tab.alloc(c, out.T);
-    hipLaunchKernelGGL(fill_u32_kernel, dim3(cdiv(out.T, TB)), dim3(TB), 0, c->stream, out.tab.p, (uint64_t)out.T,
-                       0xFFFFFFFFu - (uint32_t)N);
-    PFP_HIP(hipMemsetAsync(out.rank.p, 0xff, NP * 4, c->stream));
+    hipLaunchKernelGGL(fill_kernel<I>, dim3(cdiv(out.T, TB)), dim3(TB), 0, c->stream, out.tab.p, (uint64_t)out.T,
+                       (I)(IdxTraits<I>::kNone - (I)N));
+    PFP_HIP(hipMemsetAsync(out.rank.p, 0xff, NP * sizeof(I), c->stream));
   }
   const int nb = bits_for(N);           // key of a later round = (group head << nb) | (1 + rank of the continuation)
   const int keybits = 2 * nb;
   static const bool no_finflag = getenv("PFP_NO_FINFLAG") != nullptr;      // tests: force the length-gather path
-  out.finbit = (g.mode == MODE_DICT && N < (1ull << 31) && !no_finflag) ? 0x80000000u : 0u;
+  out.finbit = (g.mode == MODE_DICT && (kWide || N < (1ull << 31)) && !no_finflag) ? IdxTraits<I>::kTop : (I)0;
   static const bool use_segsort = []() { const char *e = getenv("PFP_SEGSORT"); return !(e && e[0] == '0'); }();
   DBuf<uint8_t> gs;
   DBuf<uint32_t> k32, k32o, segb, sege, nseg_d;
+  DBuf<uint64_t> nsel_d;
+  DBuf<K> dkey, dkeyo;          // wide build: 128-bit doubling keys (the 32-bit build keeps them in key/keyo)
   bool seg_round = false;       // the keys of this round live in k32o (segmented path) instead of keyo
   bool pivot_round = false;     // the keys of this round are pivot order keys (build_keys_pivot_kernel)
+  bool dbl_round = false;       // the keys of this round are doubling keys (type K)
   bool pivot_ok = true;
   bool lazy_pending = false;    // dictionary mode: rank[] of the suffixes settled by the first round not scattered (yet)
   DBuf<uint8_t> veto, keep0;
   static const bool lazy_pivot_ranks = getenv("PFP_EAGER_PIVOT_RANKS") == nullptr;
   bool ranks_stale = false;     // pivot rounds skipped rank[] of settled suffixes that are not whole words
-  auto repair_ranks = [&](uint64_t m_active, const uint32_t *aslot_list) {
+  auto repair_ranks = [&](uint64_t m_active, const I *aslot_list) {
     if (!ranks_stale) return;
     DBuf<uint8_t> act(c, N);
     act.zero();
-    if (m_active) hipLaunchKernelGGL(mark_slots_kernel, dim3(cdiv(m_active, TB)), dim3(TB), 0, c->stream, m_active, aslot_list, act.p);
+    if (m_active) hipLaunchKernelGGL(mark_slots_kernel<I>, dim3(cdiv(m_active, TB)), dim3(TB), 0, c->stream, m_active, aslot_list, act.p);
     KScope ks(c, "pfp::write_back_kernel", N * 6);
-    hipLaunchKernelGGL(repair_ranks_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, keep0.p, act.p, out.sa.p, out.grp.p,
+    hipLaunchKernelGGL(repair_ranks_kernel<I>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, keep0.p, act.p, out.sa.p, out.grp.p,
                        out.finbit, out.rank.p);
     ranks_stale = false;
   };
-  DBuf<uint32_t> tile_keep, tile_heads, tile_off, tile_hoff;
+  auto seg_setup = [&](uint64_t mm, uint32_t &ng, uint32_t &maxlen) {      // segments = groups of the (grouped) active list
+    if (!gs.p) { gs.alloc(c, list_cap); k32.alloc(c, list_cap); k32o.alloc(c, list_cap); segb.alloc(c, list_cap + 1); sege.alloc(c, list_cap + 1);
+                 nseg_d.alloc(c, 2); nsel_d.alloc(c, 1); }
+    hipLaunchKernelGGL(group_starts_kernel<I>, dim3(cdiv(mm, TB)), dim3(TB), 0, c->stream, mm, act_grp.p, gs.p);
+    select_index<uint32_t>(c, gs.p, segb.p, nsel_d.p, mm);
+    PFP_HIP(hipMemsetAsync(nseg_d.p + 1, 0, 4, c->stream));
+    ng = (uint32_t)read_scalar(c, nsel_d.p);
+    hipLaunchKernelGGL(seg_end_kernel, dim3(cdiv(ng, TB)), dim3(TB), 0, c->stream, ng, (uint32_t)mm, segb.p, sege.p, nseg_d.p + 1);
+    maxlen = read_scalar(c, nseg_d.p + 1);
+  };
+  DBuf<uint32_t> tile_keep, tile_heads;
+  DBuf<I> tile_off, tile_hoff;
   uint32_t piv_cap = kPivotCap;  // bytes compared per member in the next pivot round
   bool long_cap_tried = false;
   for (;;) {
+    DBuf<I> tile_last, tile_scan;      // first round of dictionary mode: last head per 256 slots, and its running maximum
     if (first && lazy) {
+      tile_last.alloc(c, cdiv64(m, 256)); tile_scan.alloc(c, cdiv64(m, 256));
       { KScope ks(c, "pfp::heads_kernel", m * 13);
-        hipLaunchKernelGGL(heads0_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, out.keymask, out.shift, out.T,
-                           hd.p, hv.p /* last head per 256 slots */, out.tab.p); }
-      inclusive_max_u32(c, out.tab.p, out.tab.p, out.T);
-      inclusive_max_u32(c, hv.p, newhead.p /* carry-in per 256 slots */, cdiv64(m, 256));
+        hipLaunchKernelGGL(heads0_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, out.keymask, out.shift, out.T,
+                           hd.p, tile_last.p, out.tab.p); }
+      inclusive_max<I>(c, out.tab.p, out.tab.p, out.T);
+      inclusive_max<I>(c, tile_last.p, tile_scan.p, cdiv64(m, 256));
     } else if (seg_round) {
       KScope ks(c, "pfp::heads_kernel", m * 14);
-      hipLaunchKernelGGL(heads32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, gs.p, k32o.p, aslot.p, hd.p, hv.p);
+      hipLaunchKernelGGL(heads32_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, gs.p, k32o.p, aslot.p, hd.p, hv.p);
+    } else if (dbl_round && kWide) {
+      KScope ks(c, "pfp::heads_kernel", m * 25);
+      hipLaunchKernelGGL((heads_kernel<I, K>), dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, dkeyo.p, aslot.p, hd.p, hv.p);
     } else {
       KScope ks(c, "pfp::heads_kernel", m * 17);
-      hipLaunchKernelGGL(heads_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p);
+      hipLaunchKernelGGL((heads_kernel<I, uint64_t>), dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p);
     }
     const bool round0 = first && lazy;
     first = false;
-    if (!round0) inclusive_max_u32(c, hv.p, newhead.p, m);
+    if (!round0) inclusive_max<I>(c, hv.p, newhead.p, m);
     if (round0) {
-      { KScope ks(c, "pfp::write_back_kernel", m * (4 + 4 + 1 + 8 + 4 + 4 + 1));
-        hipLaunchKernelGGL(write_back0_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, valo.p, newhead.p, hd.p, keyo.p,
-                           out.sa.p, out.rank.p, out.grp.p, keep.p); }
-      // the sorted keys stay with the result; later rounds sort the (smaller) active set elsewhere
+      { KScope ks(c, "pfp::write_back_kernel", m * (4 + 4 + 1 + 8 + 4 + 1));
+        hipLaunchKernelGGL(write_back0_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, valo.p, tile_scan.p, hd.p, keyo.p,
+                           out.rank.p, out.grp.p, keep.p); }
+      // the sorted keys and the sorted positions stay with the result; later rounds sort the (smaller) active set elsewhere
       out.skeys = std::move(keyo);
+      out.sa = std::move(valo);
     } else {
       if (pivot_round) {
         if (!veto.p) veto.alloc(c, N);
         veto.zero();
-        hipLaunchKernelGGL(pivot_veto_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p,
+        hipLaunchKernelGGL(pivot_veto_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p,
                            seg_round ? k32o.p : (const uint32_t *)nullptr, valo.p, newhead.p, out.finbit, veto.p);
       }
       // previous group head of the element now at a: the high part of its sort key, or (segmented
@@ -727,14 +786,20 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       // of plain mode has neither: everything is written.
       const bool have_prev = out.rounds > 0;
       KScope ks(c, "pfp::write_back_kernel", m * (13 + 4 + 13));
-      hipLaunchKernelGGL(write_back_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p,
-                         newhead.p, hd.p, out.finbit, (have_prev && !seg_round) ? keyo.p : (const uint64_t *)nullptr,
-                         pivot_round ? kPivBits : nb, (have_prev && seg_round) ? act_grp.p : (const uint32_t *)nullptr,
-                         pivot_round ? veto.p : (const uint8_t *)nullptr,
-                         (pivot_round && lazy_pivot_ranks) ? out.bytes : (const uint8_t *)nullptr, out.sa.p, out.rank.p, out.grp.p,
-                         keep.p);
+      const uint8_t *vetop = pivot_round ? veto.p : (const uint8_t *)nullptr;
+      const uint8_t *lazyb = (pivot_round && lazy_pivot_ranks) ? out.bytes : (const uint8_t *)nullptr;
+      const I *prevgrp = (have_prev && seg_round) ? act_grp.p : (const I *)nullptr;
+      if (dbl_round && kWide && !seg_round)
+        hipLaunchKernelGGL((write_back_kernel<I, K>), dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p, hd.p,
+                           out.finbit, have_prev ? dkeyo.p : (const K *)nullptr, nb, prevgrp, vetop, lazyb, out.sa.p, out.rank.p,
+                           out.grp.p, keep.p);
+      else
+        hipLaunchKernelGGL((write_back_kernel<I, uint64_t>), dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p,
+                           hd.p, out.finbit, (have_prev && !seg_round) ? keyo.p : (const uint64_t *)nullptr, pivot_round ? kPivBits : nb,
+                           prevgrp, vetop, lazyb, out.sa.p, out.rank.p, out.grp.p, keep.p);
       if (pivot_round && lazy_pivot_ranks) ranks_stale = true;
     }
+    uint64_t m2 = 0, ngrp = 0;
     {
       // kept suffixes / kept group heads per tile -> offsets -> placement
       const uint64_t ntile = cdiv64(m, kTile);
@@ -745,18 +810,29 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
       KScope ks(c, "pfp::compact3_kernel", m * 2 + 0);      // label kept from the kernel this replaced (profiles compare rounds)
       hipLaunchKernelGGL(active_count_kernel, dim3((unsigned)cdiv64(ntile, 16)), dim3(256), 0, c->stream, keep.p, hd.p, m,
                          tile_keep.p, tile_heads.p);
-      exclusive_sum_u32(c, tile_keep.p, tile_off.p, ntile + 1);
-      exclusive_sum_u32(c, tile_heads.p, tile_hoff.p, ntile + 1);
-      hipLaunchKernelGGL(active_place_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, keep.p, m, tile_keep.p, tile_off.p,
-                         round0 ? (const uint32_t *)nullptr : aslot.p, valo.p, round0 ? out.grp.p : newhead.p, out.finbit, aslot2.p,
-                         act_i.p, act_grp.p);
+      exclusive_sum_u32_to<I>(c, tile_keep.p, tile_off.p, ntile + 1);
+      exclusive_sum_u32_to<I>(c, tile_heads.p, tile_hoff.p, ntile + 1);
+      PFP_HIP(hipMemcpyAsync(c->h_scalars, tile_off.p + ntile, sizeof(I), hipMemcpyDeviceToHost, c->stream));
+      PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, tile_hoff.p + ntile, sizeof(I), hipMemcpyDeviceToHost, c->stream));
+      if (round0) {      // the lists are sized by what the first round left unresolved
+        sync(c);
+        I t0, t1;
+        memcpy(&t0, c->h_scalars, sizeof(I)); memcpy(&t1, c->h_scalars + 1, sizeof(I));
+        m2 = t0; ngrp = t1;
+        if (m2) alloc_lists(m2);
+      }
+      if (!round0 || m2)
+        hipLaunchKernelGGL(active_place_kernel<I>, dim3((unsigned)ntile), dim3(256), 0, c->stream, keep.p, m, tile_keep.p, tile_off.p,
+                           round0 ? (const I *)nullptr : aslot.p, round0 ? out.sa.p : valo.p, round0 ? out.grp.p : newhead.p, out.finbit,
+                           aslot2.p, act_i.p, act_grp.p);
       PFP_HIP(hipGetLastError());
-      PFP_HIP(hipMemcpyAsync(c->h_scalars, tile_off.p + ntile, 4, hipMemcpyDeviceToHost, c->stream));
-      PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, tile_hoff.p + ntile, 4, hipMemcpyDeviceToHost, c->stream));
     }
-    sync(c);
-    uint32_t m2, ngrp;
-    memcpy(&m2, c->h_scalars, 4); memcpy(&ngrp, c->h_scalars + 1, 4);
+    if (!round0) {
+      sync(c);
+      I t0, t1;
+      memcpy(&t0, c->h_scalars, sizeof(I)); memcpy(&t1, c->h_scalars + 1, sizeof(I));
+      m2 = t0; ngrp = t1;
+    }
     if (round0 && m2) {
       // whether the settled ranks get scattered after all is decided when (if) a doubling round
       // first needs them: pivot rounds read the strings, not rank[]
@@ -773,90 +849,91 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
 
     static const bool trace_rounds = getenv("PFP_TRACE_ROUNDS") != nullptr;
     if (trace_rounds)
-      fprintf(stderr, "[pfp] doubling N=%llu round=%llu h=%llu m=%llu -> %u unresolved in %u groups%s\n", (unsigned long long)N,
-              (unsigned long long)out.rounds, (unsigned long long)h, (unsigned long long)m, m2, ngrp,
-              seg_round ? " (seg)" : (pivot_round ? " (pivot)" : ""));
+      fprintf(stderr, "[pfp] doubling N=%llu round=%llu h=%llu m=%llu -> %llu unresolved in %llu groups%s\n", (unsigned long long)N,
+              (unsigned long long)out.rounds, (unsigned long long)h, (unsigned long long)m, (unsigned long long)m2,
+              (unsigned long long)ngrp, seg_round ? " (seg)" : (pivot_round ? " (pivot)" : ""));
     // a pivot round that did not at least halve the unresolved set: what is left are members equal to
     // their pivot for the whole comparison window.  While they are few, one more round with the longest
     // window settles the long phrases' variants; after that the rest is doubling's business.
-    if (pivot_round && (uint64_t)m2 * 2 > m) {
-      if (!long_cap_tried && (uint64_t)m2 * 64 < N) { long_cap_tried = true; piv_cap = kPivCapMax - 16; }
+    if (pivot_round && m2 * 2 > m) {
+      if (!long_cap_tried && m2 * 64 < N) { long_cap_tried = true; piv_cap = kPivCapMax - 16; }
       else pivot_ok = false;
     }
-    const bool was_pivot = pivot_round;
-    std::swap(aslot.p, aslot2.p);
+    std::swap(aslot, aslot2);
     m = m2;
     if (m == 0) break;
     PFP_REQUIRE(h < 2 * NP, PFP_EHIP, "suffix sort failed to converge");
-    if (!keyo.p) keyo.alloc(c, m);
+    if (!keyo.p || keyo.n < m) keyo.alloc(c, m);
+    if (!key.p || key.n < m) key.alloc(c, m);
+    if (!valo.p || valo.n < m) valo.alloc(c, m);
+    if (!val.p || val.n < m) val.alloc(c, m);
     // Rounds after the first: the unresolved suffixes are already grouped, only the 32-bit "next"
     // key has to be ordered inside every group.  When the groups are many and of moderate size (a
     // dictionary of near-identical variants) a segmented sort moves 16 B per suffix instead of the
     // 7 x 24 B of a global 53-bit radix sort (big: 240 -> 126 ms of sorting).  rocPRIM's segmented
     // sort serialises a giant segment on one workgroup (the 300 k run of one symbol in a parse cost
     // 68 ms), and for tiny groups its bookkeeping eats the gain, so the choice is per round.
-    seg_round = false;
-    pivot_round = pivot_ok && g.mode == MODE_DICT && out.finbit && kPivotCap >= 16 && ngrp && m / ngrp <= kPivotAvg;
+    seg_round = false; dbl_round = false;
+    pivot_round = pivot_ok && g.mode == MODE_DICT && out.finbit && kPivotCap >= 16 && ngrp && m / ngrp <= kPivotAvg &&
+                  (uint64_t)nb + kPivBits <= 64;
     if (pivot_round) {
       // large families (a collection of hundreds of copies): the members are already grouped, a
       // segmented sort of the 23-bit order key moves 16 B per suffix instead of 7 x 24 B
       bool seg = false;
       uint32_t ng = 0;
       static const uint32_t seg_min_avg = []() { const char *e = getenv("PFP_SEG_MINAVG"); return e ? (uint32_t)atoi(e) : 24u; }();
-      if (use_segsort && m >= (1u << 20) && m / ngrp >= seg_min_avg) {
-        if (!gs.p) { gs.alloc(c, N); k32.alloc(c, N); k32o.alloc(c, N); segb.alloc(c, N + 1); sege.alloc(c, N + 1); nseg_d.alloc(c, 2); }
-        hipLaunchKernelGGL(group_starts_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, act_grp.p, gs.p);
-        select_index_u32(c, gs.p, segb.p, nseg_d.p, m);
-        PFP_HIP(hipMemsetAsync(nseg_d.p + 1, 0, 4, c->stream));
-        ng = read_scalar(c, nseg_d.p);
-        hipLaunchKernelGGL(seg_end_kernel, dim3(cdiv(ng, TB)), dim3(TB), 0, c->stream, ng, (uint32_t)m, segb.p, sege.p,
-                           nseg_d.p + 1);
-        seg = read_scalar(c, nseg_d.p + 1) <= (1u << 15) && m / ng >= seg_min_avg;
+      if (use_segsort && m >= (1u << 20) && m < 0xFFFFFFFFull && m / ngrp >= seg_min_avg) {
+        uint32_t maxlen = 0;
+        seg_setup(m, ng, maxlen);
+        seg = maxlen <= (1u << 15) && m / ng >= seg_min_avg;
       }
       { KScope ks(c, "pfp::build_keys_pivot_kernel", m * (4 + 4 + 4 + 12 + 64));
-        hipLaunchKernelGGL(build_keys_pivot_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, out.bytes, m, h, piv_cap, act_i.p,
+        hipLaunchKernelGGL(build_keys_pivot_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, out.bytes, m, h, piv_cap, act_i.p,
                            act_grp.p, out.sa.p, out.finbit, key.p, seg ? k32.p : (uint32_t *)nullptr, val.p); }
-      if (seg) { segsort_pairs_u32_u32(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, kPivBits); seg_round = true; }
-      else sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, nb + kPivBits);
+      if (seg) { segsort_pairs_u32<I>(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, kPivBits); seg_round = true; }
+      else { sort_pairs_db(c, key, keyo, val, valo, m, 0, nb + kPivBits); std::swap(key, keyo); std::swap(val, valo); }
       out.rounds++;
-      (void)was_pivot;
       continue;                 // the sorted prefix common to all groups is still h: no doubling of h
     }
     if (range_mode) { out.complete = false; break; }     // doubling would read ranks of suffixes other ranks hold
     if (lazy_pending) {
       lazy_pending = false;
-      if ((uint64_t)m * kLazyRatio > N) {      // most lookups would need the search: scatter the settled ranks once
+      if (m * kLazyRatio > N) {      // most lookups would need the search: scatter the settled ranks once
         KScope ks(c, "pfp::write_back_kernel", N * (4 + 4 + 1 + 4));
-        hipLaunchKernelGGL(scatter_settled_kernel, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, out.sa.p, out.grp.p, keep0.p,
+        hipLaunchKernelGGL(scatter_settled_kernel<I>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, out.sa.p, out.grp.p, keep0.p,
                            out.finbit, out.rank.p);
         if (!out.paybits) out.skeys.release();      // with payload the merge still reads the records from skeys
         out.tab.release();
       }
     }
     repair_ranks(m, aslot.p);                 // a doubling round reads rank[] of arbitrary positions
-    const RankView L = rank_view(out);
-    if (use_segsort && m >= (1u << 20) && ngrp && m / ngrp >= 24) {
-      if (!gs.p) { gs.alloc(c, N); k32.alloc(c, N); k32o.alloc(c, N); segb.alloc(c, N + 1); sege.alloc(c, N + 1); nseg_d.alloc(c, 2); }
-      hipLaunchKernelGGL(group_starts_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, act_grp.p, gs.p);
-      select_index_u32(c, gs.p, segb.p, nseg_d.p, m);
-      PFP_HIP(hipMemsetAsync(nseg_d.p + 1, 0, 4, c->stream));
-      const uint32_t ng = read_scalar(c, nseg_d.p);
-      hipLaunchKernelGGL(seg_end_kernel, dim3(cdiv(ng, TB)), dim3(TB), 0, c->stream, ng, (uint32_t)m, segb.p, sege.p,
-                         nseg_d.p + 1);
-      const uint32_t maxlen = read_scalar(c, nseg_d.p + 1);
-      if (maxlen <= (1u << 15) && m / ng >= 24) {
-        { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
-          hipLaunchKernelGGL(build_keys32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, L,
-                             k32.p, val.p); }
-        segsort_pairs_u32_u32(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, bits_for(N));
-        seg_round = true;
+    const RankViewT<I> L = rank_view(out);
+    dbl_round = true;
+    if constexpr (!kWide) {
+      if (use_segsort && m >= (1u << 20) && ngrp && m / ngrp >= 24) {
+        uint32_t ng = 0, maxlen = 0;
+        seg_setup(m, ng, maxlen);
+        if (maxlen <= (1u << 15) && m / ng >= 24) {
+          { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
+            hipLaunchKernelGGL(build_keys32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
+          segsort_pairs_u32<I>(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, bits_for(N));
+          seg_round = true;
+        }
       }
     }
     if (!seg_round) {
-      { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 4 + 12));
-      hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p,
-                         L, nb, key.p, val.p); }
-      sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, 0, keybits);
+      if constexpr (kWide) {
+        if (!dkey.p || dkey.n < m) { dkey.alloc(c, m); dkeyo.alloc(c, m); }
+        { KScope ks(c, "pfp::build_keys_kernel", m * (8 + 8 + 8 + 24));
+          hipLaunchKernelGGL(build_keys_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p, L, nb, dkey.p, val.p); }
+        sort_pairs_db(c, dkey, dkeyo, val, valo, m, 0, keybits);
+        std::swap(dkey, dkeyo); std::swap(val, valo);
+      } else {
+        { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 4 + 12));
+          hipLaunchKernelGGL(build_keys_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p, L, nb, key.p, val.p); }
+        sort_pairs_db(c, key, keyo, val, valo, m, 0, keybits);
+        std::swap(key, keyo); std::swap(val, valo);
+      }
     }
     h *= 2;
     out.rounds++;
@@ -865,16 +942,20 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<uint32_t> 
   if (c->debug && out.complete) repair_ranks(0, nullptr);
 }
 
-__global__ void gather_ranks_kernel(RankView L, uint64_t count, const uint64_t *__restrict__ pos, uint32_t *__restrict__ out) {
+template <class I>
+__global__ void gather_ranks_kernel(RankViewT<I> L, uint64_t count, const uint64_t *__restrict__ pos, I *__restrict__ out) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool settled;
   if (a < count) out[a] = rank_at(L, pos[a], settled);
 }
-void gather_ranks(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint64_t count, uint32_t *d_out) {
+template <class I>
+void gather_ranks(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, uint64_t count, I *d_out) {
   if (!count) return;
-  hipLaunchKernelGGL(gather_ranks_kernel, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, rank_view(so), count, d_pos, d_out);
+  hipLaunchKernelGGL(gather_ranks_kernel<I>, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, rank_view(so), count, d_pos, d_out);
   PFP_HIP(hipGetLastError());
 }
+template void gather_ranks<uint32_t>(pfp_ctx *, const SuffixOrderT<uint32_t> &, const uint64_t *, uint64_t, uint32_t *);
+template void gather_ranks<uint64_t>(pfp_ctx *, const SuffixOrderT<uint64_t> &, const uint64_t *, uint64_t, uint64_t *);
 
 static KeyCode dict_key_code(pfp_ctx *c, const uint8_t *bytes, uint64_t N) {
   DBuf<uint32_t> hist(c, 256);
@@ -887,18 +968,20 @@ static KeyCode dict_key_code(pfp_ctx *c, const uint8_t *bytes, uint64_t N) {
   return make_key_code(hh.data());
 }
 
-void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, SuffixOrder &out,
+template <class I>
+void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *slen, SuffixOrderT<I> &out,
                         const SlotPayloadSrc *pay) {
-  PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
-  SufGeom g{MODE_DICT, N, endpos};
+  PFP_REQUIRE(N >= 1 && (sizeof(I) == 8 ? N < (1ull << 40) : N < 0xFFFFFFF0ull), PFP_ELIMIT,
+              sizeof(I) == 8 ? "dictionary of 2^40 bytes or more" : "dictionary too large for 32-bit suffix indices");
+  SufGeom g{MODE_DICT, N, slen};
   const KeyCode kc = dict_key_code(c, bytes, N);
   DBuf<uint64_t> key(c, N);
-  DBuf<uint32_t> val(c, N);
+  DBuf<I> val(c, N);
   static const bool no_payload = getenv("PFP_NO_PAYLOAD") != nullptr;
   out.paybits = (pay && !no_payload && kc.kbits + 1 <= 48) ? 16 : 0;
   out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
-  { KScope ks(c, "pfp::init_keys_packed_kernel", N * (13 + (out.paybits ? 9 : 0)));
-    hipLaunchKernelGGL(init_keys_packed_kernel, dim3((unsigned)cdiv64(N, kKeyPos)), dim3(256), 0, c->stream, bytes, N, kc, endpos,
+  { KScope ks(c, "pfp::init_keys_packed_kernel", N * (9 + sizeof(I) + (out.paybits ? 9 : 0)));
+    hipLaunchKernelGGL(init_keys_packed_kernel<I>, dim3((unsigned)cdiv64(N, kKeyPos)), dim3(256), 0, c->stream, bytes, N, kc, slen,
                        pay ? *pay : SlotPayloadSrc{}, out.paybits, key.p, val.p); }
   if (c->debug) {
     DBuf<unsigned long long> bad(c, 1);
@@ -912,8 +995,10 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   PFP_HIP(hipMemcpyAsync(out.lut.p, kc.lut, 1024, hipMemcpyHostToDevice, c->stream));
   sync(c);      // kc is a stack object
   out.bytes = bytes; out.kbits = kc.kbits;
-  doubling(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true);
+  doubling<I>(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true);
 }
+template void sort_dict_suffixes<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, SuffixOrderT<uint32_t> &, const SlotPayloadSrc *);
+template void sort_dict_suffixes<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, SuffixOrderT<uint64_t> &, const SlotPayloadSrc *);
 
 // ---- key-range sharded variant (multi-GPU)
 __global__ void sample_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t stride, uint32_t ns, KeyCode kp,
@@ -931,14 +1016,14 @@ __global__ void sample_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, ui
 // Also sums, over the suffixes of the range, the occurrences of their words (count.pos_word != null): the
 // number of BWT positions this range will emit, known before anything is sorted.
 __global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
-                                                          const uint32_t *__restrict__ endpos, uint64_t klo, uint64_t khi,
+                                                          const uint32_t *__restrict__ slen, uint64_t klo, uint64_t khi,
                                                           int khi_open, SlotPayloadSrc count, uint8_t *__restrict__ flag,
                                                           unsigned long long *__restrict__ tile_below,
                                                           unsigned long long *__restrict__ tile_emits) {
   __shared__ KeyStreamLds L;
   __shared__ unsigned long long wsum[2][4];
   const uint64_t B0 = (uint64_t)blockIdx.x * kKeyPos;
-  const uint64_t k = block_stream_key(L, s, N, kp, endpos, B0);
+  const uint64_t k = block_stream_key(L, s, N, kp, slen, B0);
   const uint64_t i = B0 + threadIdx.x;
   unsigned long long cnt = 0, emits = 0;
   if (threadIdx.x < kKeyPos && i < N) {
@@ -947,7 +1032,7 @@ __global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restr
     flag[i] = mine ? 1 : 0;
     if (mine && count.pos_word) {
       const uint32_t wd = count.pos_word[i];
-      if (wd < count.d && (count.endpos[i] - (uint32_t)i) > (uint32_t)count.w) emits = count.wocc[wd];
+      if (wd < count.d && count.slen[i] > (uint32_t)count.w) emits = count.wocc[wd];
     }
   }
   for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o, 64); emits += __shfl_down(emits, o, 64); }
@@ -971,25 +1056,28 @@ __global__ __launch_bounds__(256) void sum2_u64_kernel(const unsigned long long 
     atomicAdd(out + 1, ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3]);
   }
 }
+template <class I>
 __global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__restrict__ s, uint64_t n, KeyCode kp,
-                                                             SlotPayloadSrc P, int paybits, const uint32_t *__restrict__ idx,
-                                                             uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+                                                             SlotPayloadSrc P, int paybits, const I *__restrict__ idx,
+                                                             uint64_t *__restrict__ key, I *__restrict__ val) {
   __shared__ uint32_t lut[256];
   lut[threadIdx.x] = kp.lut[threadIdx.x];
   __syncthreads();
   uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (a >= n) return;
-  const uint32_t i = idx[a];
+  const I i = idx[a];
   uint64_t k = packed_key_at(s, i, kp.kbits, lut);
   if (paybits) k |= (uint64_t)slot_record(s, i, P) << 48;
   key[a] = k; val[a] = i;
 }
 
-void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *endpos, uint32_t part,
-                              uint32_t parts, SuffixOrder &out, const SlotPayloadSrc *pay, const SlotPayloadSrc *count) {
-  PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "dictionary too large for 32-bit suffix indices");
+template <class I>
+void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *slen, uint32_t part,
+                              uint32_t parts, SuffixOrderT<I> &out, const SlotPayloadSrc *pay, const SlotPayloadSrc *count) {
+  PFP_REQUIRE(N >= 1 && (sizeof(I) == 8 ? N < (1ull << 40) : N < 0xFFFFFFF0ull), PFP_ELIMIT,
+              sizeof(I) == 8 ? "dictionary of 2^40 bytes or more" : "dictionary too large for 32-bit suffix indices");
   PFP_REQUIRE(parts >= 1 && part < parts, PFP_EINVAL, "bad key-range share");
-  SufGeom g{MODE_DICT, N, endpos};
+  SufGeom g{MODE_DICT, N, slen};
   const KeyCode kc = dict_key_code(c, bytes, N);
   // splitters: every stride-th suffix's key, sorted; the same on every rank
   uint64_t klo = 0, khi = ~0ull;
@@ -1013,29 +1101,29 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   {
     const uint64_t nblk = cdiv64(N, kKeyPos);
     DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
-    hipLaunchKernelGGL(range_flags_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, bytes, N, kc, endpos, klo, khi, khi_open,
+    hipLaunchKernelGGL(range_flags_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, bytes, N, kc, slen, klo, khi, khi_open,
                        count ? *count : SlotPayloadSrc{}, flag.p, tb.p, te.p);
     hipLaunchKernelGGL(sum2_u64_kernel, dim3((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), dim3(256), 0, c->stream, tb.p, te.p, nblk,
                        below.p);
   }
-  DBuf<uint32_t> idx(c, N), cnt_d(c, 1);
-  select_index_u32(c, flag.p, idx.p, cnt_d.p, N);
-  PFP_HIP(hipMemcpyAsync(c->h_scalars, cnt_d.p, 4, hipMemcpyDeviceToHost, c->stream));
+  const uint64_t n_mine = count_flags(c, flag.p, N);      // the share's size first: its index list is then exactly that long
+  PFP_REQUIRE(sizeof(I) == 8 || n_mine < 0xFFFFFFF0ull, PFP_ELIMIT, "a share of the suffix array too large for 32-bit slots");
+  DBuf<I> idx(c, std::max<uint64_t>(n_mine, 1));
+  DBuf<uint64_t> cnt_d(c, 1);
+  select_index<I>(c, flag.p, idx.p, cnt_d.p, N);
   PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, below.p, 16, hipMemcpyDeviceToHost, c->stream));
   sync(c);
-  uint32_t n_mine;
-  memcpy(&n_mine, c->h_scalars, 4);
   const uint64_t slot_base = c->h_scalars[1];
   const uint64_t range_emits = c->h_scalars[2];
   flag.release();
   DBuf<uint64_t> key(c, std::max<uint64_t>(n_mine, 1));
-  DBuf<uint32_t> val(c, std::max<uint64_t>(n_mine, 1));
+  DBuf<I> val(c, std::max<uint64_t>(n_mine, 1));
   static const bool no_payload = getenv("PFP_NO_PAYLOAD") != nullptr;
   out.paybits = (pay && !no_payload && kc.kbits + 1 <= 48) ? 16 : 0;
   out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
   if (n_mine) {
     KScope ks(c, "pfp::init_keys_packed_kernel", (uint64_t)n_mine * 17);
-    hipLaunchKernelGGL(init_keys_list_kernel, dim3(cdiv(n_mine, 256)), dim3(256), 0, c->stream, bytes, (uint64_t)n_mine, kc,
+    hipLaunchKernelGGL(init_keys_list_kernel<I>, dim3(cdiv(n_mine, 256)), dim3(256), 0, c->stream, bytes, (uint64_t)n_mine, kc,
                        pay ? *pay : SlotPayloadSrc{}, out.paybits, idx.p, key.p, val.p);
   }
   idx.release();
@@ -1043,35 +1131,46 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   PFP_HIP(hipMemcpyAsync(out.lut.p, kc.lut, 1024, hipMemcpyHostToDevice, c->stream));
   sync(c);      // kc is a stack object
   out.bytes = bytes; out.kbits = kc.kbits;
-  doubling(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true, (uint64_t)n_mine);
+  doubling<I>(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true, (uint64_t)n_mine);
   out.slot_base = slot_base; out.klo = klo; out.khi = khi_open ? ~0ull : khi; out.range_emits = range_emits;
 }
+template void sort_dict_suffixes_range<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, uint32_t, uint32_t,
+                                                 SuffixOrderT<uint32_t> &, const SlotPayloadSrc *, const SlotPayloadSrc *);
+template void sort_dict_suffixes_range<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, uint32_t, uint32_t,
+                                                 SuffixOrderT<uint64_t> &, const SlotPayloadSrc *, const SlotPayloadSrc *);
 
-__global__ void gather_slots_range_kernel(RankView L, uint64_t klo, uint64_t khi, uint64_t slot_base, uint64_t count,
-                                          const uint64_t *__restrict__ pos, uint32_t *__restrict__ out) {
+template <class I>
+__global__ void gather_slots_range_kernel(RankViewT<I> L, uint64_t klo, uint64_t khi, uint64_t slot_base, uint64_t count,
+                                          const uint64_t *__restrict__ pos, uint64_t *__restrict__ out) {
   uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= count) return;
   const uint64_t j = pos[a];
   const uint64_t k = packed_key_at(L.bytes, j, L.kbits, L.lut);
-  uint32_t r = 0;
-  if (k >= klo && (khi == ~0ull || k < khi)) { bool settled; r = (uint32_t)(slot_base + rank_at(L, j, settled) + 1); }
+  uint64_t r = 0;
+  if (k >= klo && (khi == ~0ull || k < khi)) { bool settled; r = slot_base + (uint64_t)rank_at(L, j, settled) + 1; }
   out[a] = r;
 }
-void gather_slots_range(pfp_ctx *c, const SuffixOrder &so, const uint64_t *d_pos, uint64_t count, uint32_t *d_out) {
+template <class I>
+void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, uint64_t count, uint64_t *d_out) {
   if (!count) return;
-  hipLaunchKernelGGL(gather_slots_range_kernel, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, rank_view(so), so.klo, so.khi,
+  hipLaunchKernelGGL(gather_slots_range_kernel<I>, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, rank_view(so), so.klo, so.khi,
                      so.slot_base, count, d_pos, d_out);
   PFP_HIP(hipGetLastError());
 }
+template void gather_slots_range<uint32_t>(pfp_ctx *, const SuffixOrderT<uint32_t> &, const uint64_t *, uint64_t, uint64_t *);
+template void gather_slots_range<uint64_t>(pfp_ctx *, const SuffixOrderT<uint64_t> &, const uint64_t *, uint64_t, uint64_t *);
 
-void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrder &out) {
-  PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "text too large for 32-bit suffix indices");
+template <class I>
+void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrderT<I> &out) {
+  PFP_REQUIRE(N >= 1 && (sizeof(I) == 8 ? N < (1ull << 40) : N < 0xFFFFFFF0ull), PFP_ELIMIT, "text too large for the suffix index width");
   SufGeom g{MODE_PLAIN, N, nullptr};
   DBuf<uint64_t> key(c, N);
-  DBuf<uint32_t> val(c, N);
-  hipLaunchKernelGGL(init_keys_bytes_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, key.p, val.p);
-  doubling(c, g, key, val, 8, out);
+  DBuf<I> val(c, N);
+  hipLaunchKernelGGL(init_keys_bytes_kernel<I>, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, key.p, val.p);
+  doubling<I>(c, g, key, val, 8, out);
 }
+template void sort_byte_suffixes<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, SuffixOrderT<uint32_t> &);
+template void sort_byte_suffixes<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t, SuffixOrderT<uint64_t> &);
 
 void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym) {
   PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "parse too large for 32-bit suffix indices");
@@ -1095,7 +1194,7 @@ void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder 
   } else {
     hipLaunchKernelGGL(init_keys_int_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, sym, N, key.p, val.p);
   }
-  doubling(c, g, key, val, 2, out);
+  doubling<uint32_t>(c, g, key, val, 2, out);
 }
 
 }  // namespace pfp

@@ -49,8 +49,8 @@ void validate_index(pfp_ctx *c, const Dictionary &D, const DictIndex &ix) {
   auto b = fetch(c, D.bytes.p, D.dsize);
   auto pw = fetch(c, ix.pos_word.p, D.dsize);
   auto we = fetch(c, ix.wend.p, D.d + 1);
-  auto ep = fetch(c, ix.endpos.p, D.dsize);
-  for (uint64_t i = 0; i < D.dsize; i++) if (pw[i] > D.d || ep[i] != we[pw[i]]) VFAIL("index: endpos wrong at " + std::to_string(i));
+  auto sl = fetch(c, ix.slen.p, D.dsize);
+  for (uint64_t i = 0; i < D.dsize; i++) if (pw[i] > D.d || i + sl[i] != we[pw[i]]) VFAIL("index: slen wrong at " + std::to_string(i));
   uint32_t wd = 0;
   for (uint64_t i = 0; i < D.dsize; i++) {
     if (pw[i] != wd) VFAIL("index: pos_word wrong at " + std::to_string(i));
@@ -60,7 +60,7 @@ void validate_index(pfp_ctx *c, const Dictionary &D, const DictIndex &ix) {
 }
 
 // compare two dictionary suffixes as 0x01-terminated strings
-static int cmp_suffix(const std::vector<uint8_t> &b, uint32_t x, uint32_t y) {
+static int cmp_suffix(const std::vector<uint8_t> &b, uint64_t x, uint64_t y) {
   for (;;) {
     uint8_t cx = b[x], cy = b[y];
     if (cx != cy) return cx < cy ? -1 : 1;
@@ -69,18 +69,19 @@ static int cmp_suffix(const std::vector<uint8_t> &b, uint32_t x, uint32_t y) {
   }
 }
 
-void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, SuffixOrder &so, bool dict_mode, const char *what) {
+template <class I>
+void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, SuffixOrderT<I> &so, bool dict_mode, const char *what) {
   const uint64_t N = so.N;
   auto sa = fetch(c, so.sa.p, N);
   // ranks through the sorter's own lookup (rank[] is sparse in dictionary mode), checked against grp[]
-  std::vector<uint32_t> rk(N);
+  std::vector<I> rk(N);
   {
     std::vector<uint64_t> pos(N);
     for (uint64_t i = 0; i < N; i++) pos[i] = i;
     DBuf<uint64_t> dpos(c, N);
-    DBuf<uint32_t> dr(c, N);
+    DBuf<I> dr(c, N);
     h2d(c, dpos.p, pos.data(), N);
-    gather_ranks(c, so, dpos.p, N, dr.p);
+    gather_ranks<I>(c, so, dpos.p, N, dr.p);
     rk = fetch(c, dr.p, N);
   }
   auto gr = fetch(c, so.grp.p, N);
@@ -102,6 +103,9 @@ void validate_suffix_order(pfp_ctx *c, const uint8_t *bytes, SuffixOrder &so, bo
     }
   }
 }
+
+template void validate_suffix_order<uint32_t>(pfp_ctx *, const uint8_t *, SuffixOrderT<uint32_t> &, bool, const char *);
+template void validate_suffix_order<uint64_t>(pfp_ctx *, const uint8_t *, SuffixOrderT<uint64_t> &, bool, const char *);
 
 void validate_int_sa(pfp_ctx *c, const uint32_t *sym, const SuffixOrder &so) {
   const uint64_t N = so.N;

@@ -28,9 +28,9 @@ ERRORS = {0: "PFP_OK", -1: "PFP_EINVAL", -2: "PFP_ENODEV", -3: "PFP_EHIP", -4: "
 
 # every symbol include/pfpgpu.h declares
 SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror", "pfp_version", "pfp_ctx_stream",
-           "pfp_free", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak",
-           "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_dev", "pfp_get_stats",
-           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
+           "pfp_free", "pfp_debug_check", "pfp_get_mem_stats", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak", "pfp_sacak_int64", "pfp_sacak64", "pfp_gsacak64",
+           "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_dev", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
+           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
            "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_merge", "pfp_dist_release"]
 
 
@@ -64,7 +64,7 @@ class Stats(C.Structure):
                 ("hard_groups", C.c_uint64), ("hard_chars", C.c_uint64),
                 ("hard_big_groups", C.c_uint64), ("hard_max_chars", C.c_uint64), ("hard_max_members", C.c_uint64),
                 ("hash_reseeds", C.c_uint64),
-                ("extra_triggers", C.c_uint64),
+                ("extra_triggers", C.c_uint64), ("index_bits", C.c_uint64),
                 ("ms_scan", C.c_double), ("ms_phrases", C.c_double), ("ms_sa_dict", C.c_double),
                 ("ms_sa_parse", C.c_double), ("ms_merge", C.c_double), ("ms_total", C.c_double)]
 
@@ -176,6 +176,15 @@ class Context:
     def stream(self):
         return self.lib.pfp_ctx_stream(self._h)
 
+    def debug_check(self):
+        """PFP_POOL_DEBUG=1: raise if a canary band of any released device block was damaged"""
+        self._check(self.lib.pfp_debug_check(self._h))
+
+    def mem_stats(self):
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.pfp_get_mem_stats(self._h, out))
+        return dict(held=int(out[0]), peak=int(out[1]), live=int(out[2]), debug_blocks=int(out[3]))
+
     def set_profiling(self, on=True):
         self.lib.pfp_set_profiling(self._h, C.c_int(1 if on else 0))
 
@@ -196,6 +205,10 @@ class Context:
     def set_max_phrase(self, max_phrase):
         """fused chain: split phrases longer than this with extra trigger windows (0 = reference parse)"""
         self.lib.pfp_set_max_phrase(self._h, C.c_uint64(max_phrase))
+
+    def set_index_bits(self, bits):
+        """0: index width by size (32 bits below 4 GiB), 64: always the wide build (bigbwt:109-151)"""
+        self._check(self.lib.pfp_set_index_bits(self._h, C.c_int(bits)))
 
     def stats(self):
         st = Stats()
@@ -242,6 +255,25 @@ class Context:
         s = _arr(s, np.uint8)
         sa = np.zeros(len(s), dtype=np.uint32)
         self._check(self.lib.pfp_gsacak(self._h, _ptr(s, C.c_uint8), _ptr(sa, C.c_uint32), C.c_uint64(len(s))))
+        return sa
+
+    # -- the -DM64 build of gsa/gsacak.h: 64-bit SA entries
+    def sacak_int64(self, s, k=0):
+        s = _arr(s, np.uint32)
+        sa = np.zeros(len(s), dtype=np.uint64)
+        self._check(self.lib.pfp_sacak_int64(self._h, _ptr(s, C.c_uint32), _ptr(sa, C.c_uint64), C.c_uint64(len(s)), C.c_uint64(k)))
+        return sa
+
+    def sacak64(self, s):
+        s = _arr(s, np.uint8)
+        sa = np.zeros(len(s), dtype=np.uint64)
+        self._check(self.lib.pfp_sacak64(self._h, _ptr(s, C.c_uint8), _ptr(sa, C.c_uint64), C.c_uint64(len(s))))
+        return sa
+
+    def gsacak64(self, s):
+        s = _arr(s, np.uint8)
+        sa = np.zeros(len(s), dtype=np.uint64)
+        self._check(self.lib.pfp_gsacak64(self._h, _ptr(s, C.c_uint8), _ptr(sa, C.c_uint64), C.c_uint64(len(s))))
         return sa
 
     # -- stage 2: bwtparse.c main
@@ -292,6 +324,24 @@ class Context:
                                             C.c_void_p(d_sa_ptr) if d_sa_ptr else None, C.byref(used)))
         return used.value
 
+    def pack5_dev(self, d_vals_ptr, count, d_out5_ptr):
+        """count u64 device values -> 5-byte LE ints in device memory (utils.c:112-129)"""
+        self._check(self.lib.pfp_pack5_dev(self._h, C.c_void_p(d_vals_ptr), C.c_uint64(count), C.c_void_p(d_out5_ptr)))
+
+    def sample_runs_dev(self, d_bwt_ptr, d_sa_ptr, count, pos_base=0, left=-1, right=-1, run_end=False, d_out10_ptr=None, cap_pairs=0):
+        """.ssa / .esa pairs of a BWT slice in device memory (pfbwt.cpp:605-676); returns the number of pairs"""
+        k = C.c_uint64()
+        rc = self.lib.pfp_sample_runs_dev(self._h, C.c_void_p(d_bwt_ptr), C.c_void_p(d_sa_ptr) if d_sa_ptr else None, C.c_uint64(count),
+                                          C.c_uint64(pos_base), C.c_int(left), C.c_int(right), C.c_int(1 if run_end else 0),
+                                          C.c_void_p(d_out10_ptr) if d_out10_ptr else None, C.c_uint64(cap_pairs), C.byref(k))
+        self._check(rc)
+        return k.value
+
+    def pwrite_dev(self, path, file_offset, d_src_ptr, nbytes):
+        """device bytes -> file at an offset (pfthreads.hpp:369-376 pattern), through pinned staging buffers"""
+        self._check(self.lib.pfp_pwrite_dev(self._h, C.c_char_p(os.fsencode(path)), C.c_uint64(file_offset), C.c_void_p(d_src_ptr),
+                                            C.c_uint64(nbytes)))
+
     # -- multi-GPU chain, one rank's share (device pointers; collectives are the caller's: dist.py)
     def dist_propose_triggers(self, d_text_ptr, n, w, p):
         hashes = (C.c_uint32 * 8)()
@@ -325,7 +375,7 @@ class Context:
                                                   C.c_uint64(n_union), C.c_uint32(part), C.c_uint32(parts), C.c_void_p(d_wslot_out),
                                                   info))
         return dict(words=int(info[0]), dict_bytes=int(info[1]), rounds=int(info[2]), complete=bool(info[3]), slots=int(info[4]),
-                    slot_base=int(info[5]), emits=int(info[6]))
+                    slot_base=int(info[5]), emits=int(info[6]), index_bits=int(info[7]))
 
     def dist_global_finish(self, d_wslot_all, parts, my_word_base, d_sym_out):
         self._check(self.lib.pfp_dist_global_finish(self._h, C.c_void_p(d_wslot_all), C.c_uint32(parts), C.c_uint64(my_word_base),

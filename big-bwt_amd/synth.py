@@ -1,0 +1,157 @@
+"""Synthetic repetitive FASTA for benchmarks and full-size parity tests (host-side utility).
+
+One definition, two evaluators that give the SAME bytes: numpy (CPU, used where the reference is run
+to make golden digests) and torch (any device, used by bench.py to build the text directly in HBM).
+The text family is SURVEY.md section 4's GEN - a base genome over ACGT, C copies with point mutations
+at rate r, `>copy<c>` headers, 60-column lines - but every random draw is a pure function of
+(seed, copy, position) through the splitmix64 finaliser, so it can be evaluated in parallel and on
+any device (GEN's scalar xorshift stream cannot).
+
+    base[i]        = "ACGT"[mix(seed*K0 + i) & 3]                  overwritten by 'N' inside nblocks
+    copy c, pos i  : h = mix((seed*K1 + c + 1 + variant*4096)*K2 + i)
+                     mutated iff (h >> 11) < r * 2^53 and base[i] != 'N';  then "ACGT"[(h >> 3) & 3]
+"""
+import numpy as np
+
+K0, K1, K2 = 0x9E3779B97F4A7C15, 0xD1B54A32D192ED03, 0x8CB92BA72F3D8DD7
+_M64 = (1 << 64) - 1
+KR_PRIME = 1999999973            # newscan.cpp:172
+
+
+def _s64(x):                     # python int -> two's complement int64 value
+    x &= _M64
+    return x - (1 << 64) if x >> 63 else x
+
+
+def mix64_np(x):
+    """splitmix64 finaliser on a uint64 array"""
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def mix64_torch(x):
+    """the same on an int64 tensor (wrapping multiplies, logical shifts spelled out)"""
+    def lsr(v, k):
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    z = x + _s64(0x9E3779B97F4A7C15)
+    z = (z ^ lsr(z, 30)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * _s64(0x94D049BB133111EB)
+    return z ^ lsr(z, 31)
+
+
+def header(c):
+    return b">copy%d\n" % c
+
+
+def collection_np(G, C, r, seed, nblocks=(), variant=0, first_copy=0, header_base=None):
+    """numpy evaluator -> uint8 array"""
+    assert G % 60 == 0
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    idx = np.arange(G, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        base = lut[(mix64_np(np.uint64((seed * K0) & _M64) + idx) & np.uint64(3)).astype(np.int64)]
+    for st, ln in nblocks:
+        base[st:st + ln] = ord("N")
+    thr = np.uint64(int(r * (1 << 53)))
+    nl = np.full((G // 60, 1), ord("\n"), dtype=np.uint8)
+    parts = []
+    for c in range(first_copy, first_copy + C):
+        seq = base
+        if r > 0:
+            with np.errstate(over="ignore"):
+                k = np.uint64((((seed * K1 + c + 1 + variant * 4096) & _M64) * K2) & _M64)
+                h = mix64_np(k + idx)
+            mut = ((h >> np.uint64(11)) < thr) & (base != ord("N"))
+            seq = np.where(mut, lut[((h >> np.uint64(3)) & np.uint64(3)).astype(np.int64)], base)
+        parts.append(np.frombuffer(header(c + (variant * C if header_base is None else header_base)), dtype=np.uint8))
+        parts.append(np.concatenate([seq.reshape(-1, 60), nl], axis=1).reshape(-1))
+    return np.concatenate(parts)
+
+
+def collection_torch(dev, G, C, r, seed, nblocks=(), variant=0, first_copy=0, header_base=None):
+    """torch evaluator (any device) -> uint8 tensor with the same bytes as collection_np"""
+    import torch
+    assert G % 60 == 0
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    idx = torch.arange(G, dtype=torch.int64, device=dev)
+    base = lut[mix64_torch(idx + _s64(seed * K0)) & 3]
+    for st, ln in nblocks:
+        base[st:st + ln] = ord("N")
+    thr = int(r * (1 << 53))
+    nl = torch.full((G // 60, 1), ord("\n"), dtype=torch.uint8, device=dev)
+    parts = []
+    for c in range(first_copy, first_copy + C):
+        seq = base
+        if r > 0:
+            k = _s64((((seed * K1 + c + 1 + variant * 4096) & _M64) * K2) & _M64)
+            h = mix64_torch(idx + k)
+            mut = (((h >> 11) & ((1 << 53) - 1)) < thr) & (base != ord("N"))
+            seq = torch.where(mut, lut[(h >> 3) & 3], base)
+            del h, mut
+        parts.append(torch.tensor(list(header(c + (variant * C if header_base is None else header_base))), dtype=torch.uint8, device=dev))
+        parts.append(torch.cat([seq.view(-1, 60), nl], dim=1).reshape(-1))
+    out = torch.cat(parts).contiguous()
+    return out
+
+
+def kr_window_hash(win):
+    """hash of one window as KR_window leaves it after w characters (newscan.cpp:168-202)"""
+    h = 0
+    for b in bytes(win):
+        h = (h * 256 + b) % KR_PRIME
+    return h
+
+
+def first_window_triggers(first_bytes, w, p):
+    """the reference writes 0x02 where the EOS belongs when the first window triggers"""
+    return kr_window_hash(bytes(first_bytes[:w])) % p == 0
+
+
+# BASELINE.json configs as synthetic workloads, shared by bench.py and the parity tests
+WORKLOADS = {
+    "c2": dict(G=249_000_000, C=1, r=0.0, nblocks=[(120_000_000, 18_000_000), (30_000_000, 10_000), (200_000_000, 10_000)],
+               w=10, p=100, flags=0, seed=2,
+               desc="BASELINE configs[1]: 1x human-chr1-shaped FASTA (~253 MB), -w 10 -p 100, BWT only"),
+    "c3": dict(G=12_100_020, C=64, r=1e-3, nblocks=[], w=10, p=100, flags=6, seed=3,
+               desc="BASELINE configs[2]: 64x mutated yeast-shaped FASTA (~0.79 GB), -w 10 -p 100, BWT + -s -e sampled SA"),
+    "big": dict(G=12_100_020, C=512, r=1e-3, nblocks=[], w=10, p=100, flags=0, seed=3,
+                desc="512x mutated yeast-shaped FASTA (~6.3 GB > 2^32 bytes), -w 10 -p 100, BWT only (robustness / scaling probe)"),
+    "huge": dict(G=12_100_020, C=1024, r=1e-3, nblocks=[], w=10, p=100, flags=0, seed=3,
+                 desc="1024x mutated yeast-shaped FASTA (~12.6 GB; the north star's >= 10 GB repetitive input on one GPU), BWT only"),
+    "huge_s": dict(G=12_100_020, C=1024, r=1e-3, nblocks=[], w=10, p=100, flags=2, seed=3,
+                   desc="1024x mutated yeast-shaped FASTA (~12.6 GB; the north star's >= 10 GB repetitive input on one GPU), BWT + -s sampled SA"),
+    "wide": dict(G=12_100_020, C=300, r=1e-2, nblocks=[], w=10, p=100, flags=0, seed=3,
+                 desc="300x yeast-shaped FASTA at 1 % SNPs (~3.7 GB): dictionary > 4 GiB, exercises the 64-bit index build"),
+    "c4s": dict(G=12_100_020, C=16, r=1e-3, nblocks=[], w=10, p=100, flags=1, seed=3,
+                desc="BASELINE configs[3] parameters (-w 10 -p 100 -S, full SA) on a 16-copy, 0.2 GB stand-in (parity probe, not a reportable number)"),
+    "c5s": dict(G=12_100_020, C=16, r=1e-3, nblocks=[], w=12, p=200, flags=2, seed=3,
+                desc="BASELINE configs[4] parameters (-w 12 -p 200 -s) on a 16-copy, 0.2 GB stand-in (parity probe, not a reportable number)"),
+    "small": dict(G=6_000_000, C=4, r=1e-3, nblocks=[(1_000_000, 300_000)], w=10, p=100, flags=0, seed=3,
+                  desc="reduced smoke workload (not a reportable number)"),
+}
+
+
+def workload_seed(name, evaluator=collection_np, **kw):
+    """first seed >= the workload's nominal one whose text does not start with a trigger window (Q1)"""
+    wl = WORKLOADS[name]
+    seed = wl["seed"]
+    while True:
+        # the first w bytes are ">copy0\\n" + the first bases: enough to evaluate 60 bases of copy 0
+        v = kw.get("variant", 0)
+        head = collection_np(60, 1, wl["r"], seed, [], v, header_base=v * wl["C"])[: wl["w"]]
+        if not first_window_triggers(head, wl["w"], wl["p"]):
+            return seed
+        seed += 1
+
+
+def workload_text_np(name, variant=0):
+    wl = WORKLOADS[name]
+    return collection_np(wl["G"], wl["C"], wl["r"], workload_seed(name, variant=variant), wl["nblocks"], variant)
+
+
+def workload_text_torch(dev, name, variant=0):
+    wl = WORKLOADS[name]
+    return collection_torch(dev, wl["G"], wl["C"], wl["r"], workload_seed(name, variant=variant), wl["nblocks"], variant)

@@ -51,6 +51,12 @@ const char *pfp_version(void);
 /* HIP stream the ctx launches on (hipStream_t), for callers that time with events */
 void *pfp_ctx_stream(pfp_ctx *ctx);
 void pfp_free(void *host_ptr);     /* frees host buffers returned by this library */
+/* PFP_POOL_DEBUG=1 in the environment of pfp_ctx_create: every device block of the context gets an exact-size
+ * allocation of its own with canary bands on both sides and a poison-filled body; bands are verified when a
+ * block is released.  pfp_debug_check returns PFP_EHIP (message in pfp_last_error) once a band was damaged. */
+int pfp_debug_check(pfp_ctx *ctx);
+/* out = {bytes held from the driver, peak bytes in use, bytes in use now, blocks handed out in debug mode} */
+int pfp_get_mem_stats(const pfp_ctx *ctx, uint64_t out[4]);
 
 /* ------------------------------------------------------------------------------------
  * Stage 1a: rolling Karp-Rabin window scan + phrase-boundary compaction.
@@ -92,6 +98,13 @@ void pfp_parse_result_free(pfp_parse_result *r);
 int pfp_sacak_int(pfp_ctx *ctx, const uint32_t *s, uint32_t *SA, uint64_t n, uint64_t k);
 int pfp_sacak(pfp_ctx *ctx, const uint8_t *s, uint32_t *SA, uint64_t n);
 int pfp_gsacak(pfp_ctx *ctx, const uint8_t *s, uint32_t *SA, uint64_t n);
+/* The same for the reference's -DM64 build (gsa/gsacak.h:42-60: uint_t = uint64_t, int_text stays 32 bits), which
+ * bigbwt selects for parses / dictionaries / texts beyond the 32-bit limits (bigbwt:109-151, 177-194): 64-bit SA
+ * entries, n up to 2^40.  Inside the library the index width follows the input size in every entry point
+ * (32-bit positions below 4 GiB, 64-bit above; PFP_FORCE_IDX64=1 in the environment forces the wide build). */
+int pfp_sacak_int64(pfp_ctx *ctx, const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k);
+int pfp_sacak64(pfp_ctx *ctx, const uint8_t *s, uint64_t *SA, uint64_t n);
+int pfp_gsacak64(pfp_ctx *ctx, const uint8_t *s, uint64_t *SA, uint64_t n);
 
 /* ------------------------------------------------------------------------------------
  * Stage 2: bwtparse main (bwtparse.c:212-322): SA of the parse, BWT(P), inverted lists and
@@ -129,10 +142,30 @@ int pfp_bigbwt(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p,
 /* Device-resident variant: d_text is a device pointer to n bytes; d_bwt must hold n+1 bytes.
  * Optional device outputs (may be NULL unless the flag is set):
  *   d_sa   u64[n+1]  SA value per BWT position (d_sa[0] = n), flags & (SA|SSA|ESA)
- * Run-sampled / packed outputs are derived from d_bwt/d_sa by pfp_pack_* below.
+ * Run-sampled / packed outputs are derived from d_bwt/d_sa by pfp_pack5_dev / pfp_sample_runs_dev below.
  * *n_used returns the parsed length; bwt length is *n_used + 1. */
 int pfp_bigbwt_dev(pfp_ctx *ctx, const void *d_text, uint64_t n, int w, uint64_t p, int flags,
                    void *d_bwt, void *d_sa, uint64_t *n_used);
+
+/* Reference file formats from device-resident results (device pointers in and out):
+ *   pfp_pack5_dev       : count u64 values -> 5-byte little-endian ints (utils.c:112-129; `.sa`, pfbwt.cpp:159-160:
+ *                         pass d_sa + 1 and count = n, SA[0] = n is not written)
+ *   pfp_sample_runs_dev : the `.ssa` (run_end = 0: positions j with BWT[j] != BWT[j-1], incl. j = 0; pfbwt.cpp:169-174,
+ *                         184-189, 605-676) or `.esa` (run_end = 1: BWT[j] != BWT[j+1], incl. j = n; pfbwt.cpp:175-179,
+ *                         225-229) pairs <j, SA[j]>, 5 + 5 bytes each, of the BWT slice [pos_base, pos_base + count):
+ *                         d_bwt / d_sa point at the slice's first element; left_byte / right_byte = the BWT byte just
+ *                         before / after the slice (a rank's halo from its neighbours), -1 at the ends of
+ *                         the whole BWT.  *n_pairs = boundaries in the slice; d_out10 == NULL only counts; more pairs
+ *                         than cap_pairs -> PFP_ELIMIT (with *n_pairs set).  Concatenating the slices' outputs in
+ *                         order gives the reference's file. */
+int pfp_pack5_dev(pfp_ctx *ctx, const void *d_vals_u64, uint64_t count, void *d_out5);
+/* writes nbytes of device memory into `path` at file_offset (file created if missing, never truncated), streamed
+ * through pinned staging buffers: how a rank of the multi-GPU chain stores its slice of .bwt/.sa/.ssa/.esa -
+ * the reference's threads pwrite() their ranges the same way (pfthreads.hpp:369-376) */
+int pfp_pwrite_dev(pfp_ctx *ctx, const char *path, uint64_t file_offset, const void *d_src, uint64_t nbytes);
+int pfp_sample_runs_dev(pfp_ctx *ctx, const void *d_bwt, const void *d_sa, uint64_t count, uint64_t pos_base,
+                        int left_byte, int right_byte, int run_end, void *d_out10, uint64_t cap_pairs,
+                        uint64_t *n_pairs);
 
 /* per-call statistics of the most recent pfp_bigbwt / pfp_bigbwt_dev / pfp_parse on this ctx */
 typedef struct {
@@ -142,6 +175,7 @@ typedef struct {
   uint64_t hard_big_groups, hard_max_chars, hard_max_members;
   uint64_t hash_reseeds;
   uint64_t extra_triggers;   /* window hashes added by the fused chain to split giant phrases */
+  uint64_t index_bits;       /* 32 or 64: width of dictionary positions / suffix-array slots used (bigbwt:130-151) */
   double ms_scan, ms_phrases, ms_sa_dict, ms_sa_parse, ms_merge, ms_total; /* host wall, synced */
 } pfp_stats;
 int pfp_get_stats(const pfp_ctx *ctx, pfp_stats *st);
@@ -160,6 +194,10 @@ int pfp_get_kernel_trace(pfp_ctx *ctx, pfp_kernel_stat *out, int cap);
  * as the reference does).  The .bwt/.sa/.ssa/.esa outputs do not depend on the parse
  * (SURVEY.md 2.2-Q11); pfp_scan / pfp_parse always use the reference's trigger set. */
 void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
+/* Index width of dictionary positions and suffix-array slots: 0 = by size (32 bits below 4 GiB of dictionary /
+ * text, 64 above: the reference's choice between its 32-bit and -DM64 executables, bigbwt:109-151), 64 = always
+ * the wide build (what PFP_FORCE_IDX64=1 in the environment sets at pfp_ctx_create).  Outputs are identical. */
+int pfp_set_index_bits(pfp_ctx *ctx, int bits);
 
 /* ------------------------------------------------------------------------------------
  * Multi-GPU chain, one rank's share (the reference's analogue is the byte-range
@@ -184,10 +222,10 @@ void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
  *       range across threads, pfthreads.hpp:171-176): share `part` of `parts` sorts the suffixes
  *       whose first-round key falls in its part of the key space (splitters from a deterministic
  *       sample, identical on all ranks, no exchange) and holds one contiguous range of SA(D).
- *       d_wslot_out (u32[n_union], the first out_info[0] used): 1 + SA(D) slot of every global
+ *       d_wslot_out (u64[n_union], the first out_info[0] used): 1 + SA(D) slot of every global
  *       word's first suffix if this share holds it, else 0.  out_info = {global words, global
  *       dict bytes, sorting rounds, complete (0/1), slots held, first slot, BWT positions the held
- *       slots emit, 0}.  complete == 0: some group could not be settled without other shares'
+ *       slots emit, index width used (32 / 64)}.  complete == 0: some group could not be settled without other shares'
  *       ranks - every rank must then redo the step with parts = 1 (the replicated sort).
  *       The caller allgathers d_wslot_out (and complete / emit counts) and passes all `parts`
  *       arrays, out_info[0] entries each, back to back to pfp_dist_global_finish, which ranks the

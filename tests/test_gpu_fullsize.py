@@ -1,0 +1,100 @@
+"""Full-size parity (-m gpu): the HIP path on the benchmark workloads themselves, against digests the
+real reference produced for the same texts in the build container (tests/golden/golden_full.json, made
+by tests/golden/make_golden_full.py), and SURVEY.md section 4's GEN(12e6,16,1e-3,42) digests."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def sha_dev(t):
+    h = hashlib.sha256()
+    for s in range(0, t.numel(), 1 << 28):
+        h.update(t[s:s + (1 << 28)].cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def run_dev(pkg, ctx, text, w, p, flags):
+    """device-resident chain + reference file formats, all through the C ABI"""
+    import torch
+    n = text.numel()
+    bwt = torch.empty(n + 17, dtype=torch.uint8, device=text.device)
+    sa = torch.empty(n + 1, dtype=torch.int64, device=text.device) if flags else None
+    used = ctx.bigbwt_dev(text.data_ptr(), n, bwt.data_ptr(), sa.data_ptr() if flags else None, w, p, flags)
+    assert used == n
+    out = {"bwt": sha_dev(bwt[: n + 1])}
+    if flags & pkg.FLAG_SA:
+        packed = torch.empty(5 * n + 16, dtype=torch.uint8, device=text.device)
+        ctx.pack5_dev(sa.data_ptr() + 8, n, packed.data_ptr())
+        out["sa"] = sha_dev(packed[: 5 * n])
+    for key, flag, run_end in (("ssa", pkg.FLAG_SSA, False), ("esa", pkg.FLAG_ESA, True)):
+        if flags & flag:
+            k = ctx.sample_runs_dev(bwt.data_ptr(), sa.data_ptr(), n + 1, 0, -1, -1, run_end)
+            pairs = torch.empty(10 * k + 16, dtype=torch.uint8, device=text.device)
+            assert ctx.sample_runs_dev(bwt.data_ptr(), sa.data_ptr(), n + 1, 0, -1, -1, run_end, pairs.data_ptr(), k) == k
+            out[key] = sha_dev(pairs[: 10 * k])
+    return out
+
+
+def check(got, g):
+    for key in ("bwt", "sa", "ssa", "esa"):
+        if key + "_sha256" in g:
+            assert got[key] == g[key + "_sha256"], key
+
+
+def test_survey_gen16_digests(O, pkg, ctx, golden_full):
+    """GEN(12e6,16,1e-3,42), 195 MB: .bwt b53bfd57..., .ssa b16eb8c4..., .esa dc6dc812..."""
+    import torch
+    g = golden_full["gen16"]
+    assert g["bwt_sha256"].startswith("b53bfd57") and g["ssa_sha256"].startswith("b16eb8c4") and g["esa_sha256"].startswith("dc6dc812")
+    text = O.gen_fasta(12_000_000, 16, 1e-3, 42)
+    assert hashlib.sha256(text.tobytes()).hexdigest() == g["text_sha256"]
+    check(run_dev(pkg, ctx, torch.from_numpy(text).cuda(), g["w"], g["p"], g["flags"]), g)
+
+
+@pytest.mark.parametrize("name", ["small", "c2", "c3", "c4s", "c5s"])
+def test_benchmark_workloads_match_reference_digests(pkg, ctx, synth, golden_full, name):
+    """BASELINE configs[1] (c2), configs[2] (c3, -s -e) at full size; configs[3]/[4] flag sets (-S; -w 12 -p 200 -s)
+    on 16-copy stand-ins"""
+    import torch
+    if name not in golden_full:
+        pytest.skip("no reference digest committed for this workload")
+    g = golden_full[name]
+    text = synth.workload_text_torch(torch.device("cuda", 0), name)
+    assert text.numel() == g["n"] and sha_dev(text) == g["text_sha256"]          # torch evaluator == numpy evaluator
+    check(run_dev(pkg, ctx, text, g["w"], g["p"], g["flags"]), g)
+
+
+def test_pack_and_sample_exports_on_slices(O, pkg, ctx):
+    """pfp_pack5_dev / pfp_sample_runs_dev: slices with one halo byte on each side concatenate to the whole file"""
+    import torch
+    text = O.gen_fasta(40000, 3, 0.002, 11)
+    want = O.bigbwt(text, 10, 100, 6)
+    n = len(text)
+    dev = torch.device("cuda", 0)
+    bwt = torch.from_numpy(want["bwt"]).to(dev)
+    full = O.bigbwt(text, 10, 100, 1)["sa"]
+    sa = torch.from_numpy(np.concatenate([[n], full]).astype(np.int64)).to(dev)
+    packed = torch.empty(5 * n, dtype=torch.uint8, device=dev)
+    ctx.pack5_dev(sa.data_ptr() + 8, n, packed.data_ptr())
+    assert np.array_equal(packed.cpu().numpy(), O.pack5(full))
+    for odd in (1, 3, 7):          # short, unaligned packs
+        ctx.pack5_dev(sa.data_ptr() + 8 * odd, odd, packed.data_ptr())
+        assert np.array_equal(packed[: 5 * odd].cpu().numpy(), O.pack5(sa[odd: 2 * odd].cpu().numpy().astype(np.uint64)))
+    for run_end, key in ((False, "ssa"), (True, "esa")):
+        cuts = [0, 1, 17, 4096, 4097, n // 3, n // 3 + 1, n - 5, n, n + 1]
+        parts = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            left = -1 if lo == 0 else int(want["bwt"][lo - 1])
+            right = -1 if hi == n + 1 else int(want["bwt"][hi])
+            k = ctx.sample_runs_dev(bwt.data_ptr() + lo, sa.data_ptr() + 8 * lo, hi - lo, lo, left, right, run_end)
+            buf = torch.empty(10 * k + 16, dtype=torch.uint8, device=dev)
+            assert ctx.sample_runs_dev(bwt.data_ptr() + lo, sa.data_ptr() + 8 * lo, hi - lo, lo, left, right, run_end, buf.data_ptr(), k) == k
+            parts.append(buf[: 10 * k].cpu().numpy())
+        got = pkg.unpack5(np.concatenate(parts)).reshape(-1, 2)
+        assert np.array_equal(got, want[key]), key
+    with pytest.raises(pkg.PfpError):
+        buf = torch.empty(64, dtype=torch.uint8, device=dev)
+        ctx.sample_runs_dev(bwt.data_ptr(), sa.data_ptr(), n + 1, 0, -1, -1, False, buf.data_ptr(), 1)

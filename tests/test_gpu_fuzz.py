@@ -73,7 +73,9 @@ def test_extra_trigger_never_fires_on_the_first_window(pkg, O, ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [11, 12, 13])
-def test_structured_random_inputs_match_oracle(pkg, O, ctx, seed):
+def test_structured_random_inputs_match_oracle(pkg, O, wctx, seed):
+    ctx = wctx
+    bits = 64 if "idx64" in os.environ.get("PYTEST_CURRENT_TEST", "") else 0
     d = importlib.import_module("bigbwt_amd.dist")
     rng = np.random.default_rng(seed)
     done = dist_done = 0
@@ -98,6 +100,7 @@ def test_structured_random_inputs_match_oracle(pkg, O, ctx, seed):
                 try:
                     for c in ctxs:
                         c.set_max_phrase(2000)
+                        c.set_index_bits(bits)
                     shards = [torch.from_numpy(t[cuts[r]:cuts[r + 1]].copy()).cuda() for r in range(R)]
                     try:
                         res = d.simulate(ctxs, shards, w, p, flags, halo=1 << 16)

@@ -19,15 +19,17 @@ def sha(a):
 
 
 @pytest.mark.parametrize("idx", range(15))
-def test_bigbwt_matches_reference_golden(golden, O, pkg, ctx, idx):
+def test_bigbwt_matches_reference_golden(golden, O, pkg, wctx, idx):
     """pfp_bigbwt == bigbwt -w W -p M [-S | -s -e] (bit-exact .bwt/.sa/.ssa/.esa)."""
     if idx >= len(golden):
         pytest.skip("no such case")
     c = golden[idx]
     text = make_text(c["spec"], O)
+    ctx = wctx
     for flags in (0, 1, 6):
         r = c["runs"][str(flags)]
         got = ctx.bigbwt(text, c["w"], c["p"], flags)
+        assert ctx.stats()["index_bits"] == (64 if "idx64" in os.environ.get("PYTEST_CURRENT_TEST", "") else 32)
         assert len(got["bwt"]) == r["bwt_len"]
         assert sha(got["bwt"]) == r["bwt_sha256"], (c["name"], flags, "bwt")
         if flags & 1:
@@ -39,13 +41,14 @@ def test_bigbwt_matches_reference_golden(golden, O, pkg, ctx, idx):
 
 
 @pytest.mark.parametrize("idx", range(15))
-def test_stage_files_match_reference_golden(golden, O, pkg, ctx, idx):
+def test_stage_files_match_reference_golden(golden, O, pkg, wctx, idx):
     """pfp_parse / pfp_bwtparse / pfp_merge reproduce every temp file of the reference."""
     if idx >= len(golden):
         pytest.skip("no such case")
     c = golden[idx]
     text = make_text(c["spec"], O)
     r = c["runs"]["6"]
+    ctx = wctx
     ps = ctx.parse(text, c["w"], c["p"], want_sai=True)
     for k in ("dict", "occ", "parse", "last", "sai"):
         assert sha(ps[k]) == r[k + "_sha256"], (c["name"], k)
@@ -107,7 +110,8 @@ def test_scan_random_bytes_all_windows(O, ctx):
         assert np.array_equal(ends, O.scan(text, w, 10)), w
 
 
-def test_suffix_sorters_match_oracle(O, ctx):
+def test_suffix_sorters_match_oracle(O, wctx):
+    ctx = wctx
     rng = np.random.default_rng(7)
     s = np.concatenate([rng.integers(1, 50, size=30000), [0]]).astype(np.uint32)
     assert np.array_equal(ctx.sacak_int(s), O.sacak_int(s))
@@ -120,6 +124,10 @@ def test_suffix_sorters_match_oracle(O, ctx):
     assert np.array_equal(ctx.gsacak(d), sa)
     ex = np.frombuffer(b"banana\x01anaba\x01anan\x01\x00", dtype=np.uint8)   # gsa/README.md:76-104
     assert np.array_equal(ctx.gsacak(ex), O.gsacak(ex, want_lcp=False)[0])
+    # the -DM64 entry points (gsa/gsacak.h:42-60): the same arrays in 64-bit entries
+    assert np.array_equal(ctx.gsacak64(d), sa.astype(np.uint64))
+    assert np.array_equal(ctx.sacak64(t), O.sacak(t).astype(np.uint64))
+    assert np.array_equal(ctx.sacak_int64(s), O.sacak_int(s).astype(np.uint64))
 
 
 def test_error_behaviour(pkg, ctx, O):
@@ -147,19 +155,21 @@ def test_special_byte_truncates_like_reference(O, ctx):
     assert np.array_equal(got["bwt"], want["bwt"]) and len(got["bwt"]) == 12346
 
 
-def test_many_snp_variants_do_not_collide(O, pkg, ctx):
+def test_many_snp_variants_do_not_collide(O, pkg, wctx):
     """48 copies at 1 % SNP rate: thousands of phrase variants that differ in two bytes.  A weak
     phrase hash (high chunk byte reaching only the top byte of the term) produced verified
     collisions on exactly this shape; the dedup must stay exact and need no reseed."""
     text = O.gen_fasta(100000, 48, 0.01, 77)
+    ctx = wctx
     got = ctx.bigbwt(text, 10, 100, pkg.FLAG_SA)
     assert ctx.stats()["hash_reseeds"] == 0
     want = O.bigbwt(text, 10, 100, O.FLAG_SA)
     assert np.array_equal(got["bwt"], want["bwt"]) and np.array_equal(pkg.unpack5(got["sa"]), want["sa"])
 
 
-def test_mid_size_against_oracle(O, pkg, ctx):
+def test_mid_size_against_oracle(O, pkg, wctx):
     """~24 MB, 8 near-identical copies: every output against the oracle."""
+    ctx = wctx
     text = O.gen_fasta(3000000, 8, 0.001, 31)
     got = ctx.bigbwt(text, 10, 100, pkg.FLAG_SSA | pkg.FLAG_ESA)
     want = O.bigbwt(text, 10, 100, O.FLAG_SSA | O.FLAG_ESA)
