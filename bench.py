@@ -291,7 +291,8 @@ def main():
         cpu = None
         parity_sample = None
         if O is not None:
-            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            # N = this process's share of the host: a one-GPU box gives 16 cores per GPU (the affinity mask shows all 256 of the node)
+            threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
             sample_bytes = n if args.cpu_sample_mb <= 0 else int(min(n, args.cpu_sample_mb * 1e6))
             host = text[:sample_bytes].cpu().numpy()
             cpu, ref = cpu_baseline(host, w, p, flags, O, threads)
@@ -319,7 +320,7 @@ def main():
             "phases_ms": dict({k: round(st[k], 3) for k in ("ms_scan", "ms_phrases", "ms_sa_dict", "ms_sa_parse", "ms_merge", "ms_total")},
                               formats=round(t_formats, 3), profiled_step=round(prof_ms, 3)),
             "sa_rounds": {"dict": st["sa_rounds_dict"], "parse": st["sa_rounds_parse"]},
-            "merge_stats": {k: st[k] for k in ("hard_groups", "hard_chars", "hard_big_groups", "hard_max_chars", "hard_max_members", "extra_triggers")},
+            "merge_stats": {k: st[k] for k in ("hard_groups", "hard_chars", "hard_big_groups", "hard_max_chars", "hard_max_members", "hard_minor_groups", "hard_minor_chars", "extra_triggers", "index_bits")},
             "runs": R,
             "device_memory": {"peak_bytes_in_use": mem["peak"], "held_from_driver": mem["held"]},
             "verified": {"outputs_match_reference_digests_whole_text": digests,

@@ -171,6 +171,7 @@ struct BwtOutputs {
   uint8_t *d_bwt = nullptr;    // [n+1] device, caller-provided
   uint64_t *d_sa = nullptr;    // [n+1] device, caller-provided when flags != 0
   uint64_t hard_groups = 0, hard_chars = 0, hard_big_groups = 0, hard_max_chars = 0, hard_max_members = 0;
+  uint64_t hard_minor_groups = 0, hard_minor_chars = 0;   // groups handled by majority fill; occurrences ranked for them
 };
 // emits BWT positions [out_lo,out_hi) into out.d_bwt[0..) / out.d_sa[0..) (default: everything)
 template <class I>

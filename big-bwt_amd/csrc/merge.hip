@@ -336,12 +336,26 @@ __global__ void group_flags_kernel(uint64_t N, const I *__restrict__ grp, const 
   if (any_multi_is_hard || pc[t] != pc[g]) hard[g] = 1;
 }
 
-enum : uint8_t { CLS_NONE = 0, CLS_FILL = 1, CLS_FULL = 2, CLS_HARD = 3 };
+// CLS_MULTI (sparse SA mode only): member of a group of several words that all have the same preceding char -
+// its chars are a fill, its SA values (needed at the two ends of the group's range only) come from group_edges_kernel
+enum : uint8_t { CLS_NONE = 0, CLS_FILL = 1, CLS_FULL = 2, CLS_HARD = 3, CLS_MULTI = 4 };
+// SA values asked for: none (BWT only), every position (-S), or only where the sampled SA files can look:
+// at run boundaries of the BWT (-s / -e)
+enum : int { SA_NONE = 0, SA_DENSE = 1, SA_SPARSE = 2 };
 
+template <class I>
+__global__ void gather_idx_kernel(uint64_t n, const I *__restrict__ idx, const I *__restrict__ src, I *__restrict__ dst) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
 __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank, const uint32_t *__restrict__ istart_lex,
-                               uint32_t *__restrict__ wistart) {
+                               const uint32_t *__restrict__ wocc, const uint32_t *__restrict__ ilist,
+                               uint32_t *__restrict__ wistart, uint32_t *__restrict__ wfirst, uint32_t *__restrict__ wlast) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < d) wistart[j] = istart_lex[lexrank[j]] + 1;   // +1: ilist[0] is the EOS symbol (pfbwt.cpp:389)
+  if (j >= d) return;
+  const uint32_t st = istart_lex[lexrank[j]] + 1;   // +1: ilist[0] is the EOS symbol (pfbwt.cpp:389)
+  wistart[j] = st;
+  if (wfirst) { wfirst[j] = ilist[st]; wlast[j] = ilist[st + wocc[j] - 1]; }      // smallest / largest BWT(P) position of the word
 }
 
 template <class I>
@@ -350,8 +364,8 @@ struct MergeArgsT {
   uint64_t pos_base, n_out_global;   // global BWT position of local position 0; global n+1 (== n_out unless the slots are one rank's range)
   uint64_t out_lo, out_hi;   // this call emits BWT positions [out_lo,out_hi) only (multi-GPU slices); bwt/out_sa are indexed by global position
   const I *sa, *grp;
-  const uint32_t *slen, *ist, *pos_word, *wistart;
-  const uint8_t *pc, *hard;
+  const uint32_t *slen, *ist, *pos_word, *wistart, *wfirst, *wlast;
+  const uint8_t *pc, *hard, *gmaj;     // gmaj[g]: majority char of hard group g when the minority path places the rest (else 0)
   const uint64_t *tbase; const uint32_t *loc;    // output offset of slot t = tbase[t >> 11] + loc[t] (slot_off)
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
   uint8_t *bwt; uint64_t *out_sa;
@@ -382,6 +396,9 @@ __device__ __forceinline__ uint32_t slot_ist(const MergeArgsT<I> &a, uint64_t t)
 //                     by BWT(P) position - own index + lower_bound in every other member's
 //                     inverted list - and written to that slot of the group's range: the
 //                     data-parallel form of the reference's heap merge (pfbwt.cpp:537-556).
+constexpr int kHardLds = 1024;   // occurrences of one batch ranked in LDS
+constexpr int kHardMem = 256;    // members of one batch
+constexpr int kHardSortMin = 512;   // a group with more occurrences than this (and <= kHardLds) is sorted, not ranked all-pairs
 constexpr int kSlots = 2048;
 constexpr uint64_t kExpandQuota = 1u << 16;   // output bytes one workgroup expands before the rest is shared
 
@@ -394,17 +411,29 @@ template <class I>
 __device__ __forceinline__ void expand_stage(const MergeArgsT<I> &a, ExpandLds &L, uint64_t t0, int ns, uint64_t base) {
   for (int s = threadIdx.x; s <= ns; s += 256) L.loff[s] = slot_off(a, t0 + s) - base;
   for (int s = threadIdx.x; s < ns; s += 256) {
-    uint8_t ch = a.pc[t0 + s];
+    const uint64_t t = t0 + s;
+    uint8_t ch = a.pc[t];
+    uint8_t cls = ch == 0 ? CLS_NONE : (ch == kEndOfWord ? CLS_FULL : CLS_FILL);
+    if (cls == CLS_FILL) {
+      const I g = a.grp[t];
+      if (a.hard[g]) {
+        cls = CLS_HARD;
+        ch = a.gmaj ? a.gmaj[g] : 0;      // the group's majority char (minority path) or 0 (every position written later)
+      } else if (a.want_sa == SA_SPARSE && (g != (I)t || (t + 1 < a.N && a.grp[t + 1] == (I)t))) cls = CLS_MULTI;
+    }
     L.lpc[s] = ch;
-    L.lcls[s] = ch == 0 ? CLS_NONE : (ch == kEndOfWord ? CLS_FULL : (a.hard[a.grp[t0 + s]] ? CLS_HARD : CLS_FILL));
+    L.lcls[s] = cls;
   }
   __syncthreads();
 }
 
 // 16 output bytes starting at block-relative offset x0 (< Ltot)
+// cmp (sparse SA mode): the same 16 chars for neighbour comparisons, 0x01 where the char is not known here
+// (hard group, past the end) - 0x01 is no BWT char, so such a neighbour always counts as "different"
 template <class I>
 __device__ __forceinline__ void expand_16(const MergeArgsT<I> &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
-                                          uint64_t x0, uint64_t Ltot) {
+                                          uint64_t x0, uint64_t Ltot, uint4 *cmp = nullptr) {
+  if (cmp) *cmp = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
   if (base + x0 + 16 <= a.out_lo || base + x0 >= a.out_hi) return;     // outside this rank's slice
   int lo = 0, hi = ns;                    // loff[lo] <= x0 < loff[hi]
   while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (L.loff[mid] <= x0) lo = mid; else hi = mid; }
@@ -412,6 +441,7 @@ __device__ __forceinline__ void expand_16(const MergeArgsT<I> &a, const ExpandLd
   uint64_t nxt = L.loff[s + 1];
   const int nb = (Ltot - x0) >= 16 ? 16 : (int)(Ltot - x0);
   uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  uint32_t hm = 0;       // positions whose char is decided elsewhere (hard groups)
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     if (k < nb) {
@@ -419,17 +449,25 @@ __device__ __forceinline__ void expand_16(const MergeArgsT<I> &a, const ExpandLd
       while (x >= nxt) { s++; nxt = L.loff[s + 1]; }
       const uint8_t cl = L.lcls[s];
       uint32_t ch = 0;
-      const bool in_slice = base + x >= a.out_lo && base + x < a.out_hi;
-      (void)in_slice;
-      if (cl == CLS_FILL) {
+      if (cl == CLS_FILL || cl == CLS_MULTI) {
         ch = fix_char(L.lpc[s]);
       } else if (cl == CLS_FULL) {
         const uint64_t pos = a.ilist[slot_ist(a, t0 + s) + (uint32_t)(x - L.loff[s])];
         ch = a.bwlast[pos];
-      }   // CLS_HARD: left 0 here, written by the hard-group kernels that run after this one
+      } else {      // CLS_HARD: the group's majority char (its other occurrences are placed by hard_minor_kernel), or 0 and
+        ch = L.lpc[s];      // every position of the group is written by the hard-group kernels that run after this one
+        hm |= 1u << k;
+      }
       const uint32_t sh = (uint32_t)ch << (8 * (k & 3));
       if (k < 4) r0 |= sh; else if (k < 8) r1 |= sh; else if (k < 12) r2 |= sh; else r3 |= sh;
-    }
+    } else hm |= 1u << k;
+  }
+  if (cmp) {
+    uint32_t c4[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      if ((hm >> k) & 1u) c4[k >> 2] = (c4[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (0x01u << (8 * (k & 3)));
+    *cmp = make_uint4(c4[0], c4[1], c4[2], c4[3]);
   }
   uint8_t *dst = a.bwt + base + x0;
   if (nb == 16 && base + x0 >= a.out_lo && base + x0 + 16 <= a.out_hi) st16u(dst, make_uint4(r0, r1, r2, r3));
@@ -458,10 +496,30 @@ __device__ __forceinline__ void expand_sa_1(const MergeArgsT<I> &a, const Expand
                                                                       : a.bwsai[pos] - (uint64_t)a.slen[i];
 }
 
+// Sparse SA mode: which of the 16 positions starting at x0 can be a run boundary of the BWT, judged from their
+// own chars (cmp form) and the two neighbours' (0x01 = unknown, counts as different); SA values are written for
+// those only.  Fill / full-word entries here; groups of several words by group_edges_kernel / the hard-group kernels.
 template <class I>
+__device__ __forceinline__ void expand_sa_sparse16(const MergeArgsT<I> &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
+                                                   uint64_t x0, uint64_t Ltot, uint4 cmp, uint32_t left, uint32_t right) {
+  const uint32_t c4[4] = {cmp.x, cmp.y, cmp.z, cmp.w};
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    if (x0 + k >= Ltot) break;
+    const uint32_t c = (c4[k >> 2] >> (8 * (k & 3))) & 0xffu;
+    if (c == 0x01u) continue;
+    const uint32_t l = k ? (c4[(k - 1) >> 2] >> (8 * ((k - 1) & 3))) & 0xffu : left;
+    const uint32_t r = k < 15 ? (c4[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xffu : right;
+    const uint64_t gx = base + x0 + k;
+    if (c != l || c != r || gx == a.out_lo || gx + 1 == a.out_hi) expand_sa_1(a, L, t0, ns, base, x0 + k);
+  }
+}
+
+template <class I, int SPARSE>
 __global__ __launch_bounds__(256) void expand_kernel(MergeArgsT<I> a, uint32_t *__restrict__ heavy, uint32_t *__restrict__ nheavy,
                                                      uint32_t heavy_cap) {
   __shared__ ExpandLds L;
+  __shared__ uint32_t lch[SPARSE ? 256 * 4 : 1];      // compare-form chars of the 4 KiB the workgroup has just produced
   const uint64_t t0 = (uint64_t)blockIdx.x * kSlots;
   const int ns = (a.N - t0) >= (uint64_t)kSlots ? kSlots : (int)(a.N - t0);
   const uint64_t base = slot_off(a, t0);
@@ -472,9 +530,25 @@ __global__ __launch_bounds__(256) void expand_kernel(MergeArgsT<I> a, uint32_t *
   // occurrences) finishes only its first quota here; expand_heavy_kernel shares the rest
   const uint64_t mine = Ltot <= kExpandQuota ? Ltot : kExpandQuota;
   if (Ltot > kExpandQuota && threadIdx.x == 0) { uint32_t i = atomicAdd(nheavy, 1u); if (i < heavy_cap) heavy[i] = blockIdx.x; }
-  for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < mine; x0 += 256 * 16) expand_16(a, L, t0, ns, base, x0, Ltot);
-  if (a.want_sa)
-    for (uint64_t x = threadIdx.x; x < mine; x += 256) expand_sa_1(a, L, t0, ns, base, x);
+  if (SPARSE) {
+    for (uint64_t c0 = 0; c0 < mine; c0 += 256 * 16) {      // every thread runs every iteration: barriers inside
+      const uint64_t x0 = c0 + (uint64_t)threadIdx.x * 16;
+      uint4 cmp = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+      if (x0 < mine) expand_16(a, L, t0, ns, base, x0, mine, &cmp);      // chars past `mine` belong to expand_heavy_kernel: unknown here
+      __syncthreads();
+      *reinterpret_cast<uint4 *>(&lch[threadIdx.x * 4]) = cmp;
+      __syncthreads();
+      if (x0 < mine) {
+        const uint32_t left = threadIdx.x ? lch[threadIdx.x * 4 - 1] >> 24 : 0x01u;
+        const uint32_t right = threadIdx.x < 255 ? lch[threadIdx.x * 4 + 4] & 0xffu : 0x01u;
+        expand_sa_sparse16(a, L, t0, ns, base, x0, mine, cmp, left, right);
+      }
+    }
+  } else {
+    for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < mine; x0 += 256 * 16) expand_16(a, L, t0, ns, base, x0, Ltot);
+    if (a.want_sa)
+      for (uint64_t x = threadIdx.x; x < mine; x += 256) expand_sa_1(a, L, t0, ns, base, x);
+  }
 }
 
 template <class I>
@@ -487,11 +561,171 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgsT<I> a, cons
     __syncthreads();
     expand_stage(a, L, t0, ns, base);
     const uint64_t Ltot = L.loff[ns];
-    for (uint64_t x0 = kExpandQuota + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; x0 < Ltot; x0 += (uint64_t)gridDim.x * 256 * 16)
-      expand_16(a, L, t0, ns, base, x0, Ltot);
-    if (a.want_sa)
+    for (uint64_t x0 = kExpandQuota + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; x0 < Ltot; x0 += (uint64_t)gridDim.x * 256 * 16) {
+      uint4 cmp;
+      expand_16(a, L, t0, ns, base, x0, Ltot, a.want_sa == SA_SPARSE ? &cmp : (uint4 *)nullptr);
+      // sparse SA: the neighbours outside these 16 positions are not looked at - both ends count as boundaries
+      if (a.want_sa == SA_SPARSE) expand_sa_sparse16(a, L, t0, ns, base, x0, Ltot, cmp, 0x01u, 0x01u);
+    }
+    if (a.want_sa == SA_DENSE)
       for (uint64_t x = kExpandQuota + (uint64_t)blockIdx.x * 256 + threadIdx.x; x < Ltot; x += (uint64_t)gridDim.x * 256)
         expand_sa_1(a, L, t0, ns, base, x);
+  }
+}
+
+// Sparse SA mode: a group of several words whose chars all agree fills its range with one char, so only its first
+// and its last position can be run boundaries.  The first position belongs to the smallest BWT(P) position over
+// the members' inverted lists, the last one to the largest (wfirst / wlast per word): O(members) per group
+// instead of merging the lists.  Hard groups get the same two values here (their interior comes from the
+// hard-group kernels).  Thread = slot; group heads do the work.
+template <class I>
+__global__ __launch_bounds__(256) void group_edges_kernel(MergeArgsT<I> a) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t + 1 >= a.N) return;
+  const uint8_t ch = a.pc[t];
+  if (ch == 0 || ch == kEndOfWord) return;
+  if (a.grp[t] != (I)t || a.grp[t + 1] != (I)t) return;      // not the head of a group of several words
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  uint64_t m = t;
+  for (; m < a.N && a.grp[m] == (I)t; m++) {
+    const uint32_t wd = a.pos_word[a.sa[m]];
+    const uint32_t f = a.wfirst[wd], l = a.wlast[wd];
+    mn = f < mn ? f : mn; mx = l > mx ? l : mx;
+  }
+  const uint64_t lo = slot_off(a, t), hi = slot_off(a, m);      // the group's output range [lo, hi)
+  const uint64_t sl = a.slen[a.sa[t]];
+  if (lo >= a.out_lo && lo < a.out_hi) a.out_sa[lo] = a.bwsai[mn] - sl;
+  if (hi - 1 >= a.out_lo && hi - 1 < a.out_hi) a.out_sa[hi - 1] = a.bwsai[mx] - sl;
+}
+
+// Hard groups, BWT-only and sparse-SA modes: majority fill + minority placement.  The members of a group of equal
+// suffixes whose preceding chars disagree are, in a collection of similar sequences, one or a few words with most of
+// the occurrences and one char (the base phrase and the variants that differ elsewhere) plus a handful of
+// occurrences with another char (the variants that differ right here).  The occurrences of the majority char need no
+// ranks: whatever their order, they write the same byte.  So the group's range is filled with the majority char (by
+// expand_kernel, through gmaj[]) and only the minority occurrences are ranked - own index + lower_bound in every other
+// member's inverted list, straight from global memory - and written over the fill.  In sparse SA mode a minority
+// occurrence also gives the SA values of its two neighbours in the merged order (predecessor / successor of its
+// BWT(P) position over all lists): those and the group's two ends are the only places a run can start or end.
+// Groups where no char dominates and that fit the LDS kernels keep the old path (fallback list).
+struct HardGroupInfo { uint64_t g; uint64_t E; uint32_t k; uint32_t minor; };
+template <class I>
+__global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, const I *__restrict__ heads, uint64_t nH,
+                                                            uint8_t *__restrict__ gmaj, HardGroupInfo *__restrict__ info,
+                                                            uint32_t *__restrict__ minor_cnt, uint8_t *__restrict__ fallback,
+                                                            unsigned long long *__restrict__ chars_total) {
+  const uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long mychars = 0;
+  if (h < nH) {
+  const uint64_t g = heads[h];
+  // members are the slots g .. g+k-1 (grp == g): gallop, then bisect
+  uint64_t lo = 1, hi = 2;                   // offset lo is inside (a hard group has two members), hi will be outside
+  while (g + hi < a.N && a.grp[g + hi] == (I)g) { lo = hi; hi *= 2; }
+  if (g + hi > a.N) hi = a.N - g;            // slot N counts as outside
+  while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (a.grp[g + mid] == (I)g) lo = mid; else hi = mid; }
+  const uint64_t k = hi;                     // first offset outside = number of members
+  const uint64_t base = slot_off(a, g);
+  const uint64_t E = slot_off(a, g + k) - base;
+  // occurrences per distinct char (up to 4 kept; more distinct chars: fallback)
+  uint32_t c0 = 0x100, c1 = 0x100, c2 = 0x100, c3 = 0x100;
+  uint64_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+  bool many = false;
+  uint64_t prev = base;
+  for (uint64_t m = 0; m < k; m++) {
+    const uint64_t nxt = slot_off(a, g + m + 1);
+    const uint64_t occ = nxt - prev;
+    prev = nxt;
+    const uint32_t c = fix_char(a.pc[g + m]);
+    if (c == c0 || c0 == 0x100) { c0 = c; n0 += occ; }
+    else if (c == c1 || c1 == 0x100) { c1 = c; n1 += occ; }
+    else if (c == c2 || c2 == 0x100) { c2 = c; n2 += occ; }
+    else if (c == c3 || c3 == 0x100) { c3 = c; n3 += occ; }
+    else many = true;
+  }
+  uint32_t mc = c0; uint64_t mnn = n0;
+  if (n1 > mnn) { mc = c1; mnn = n1; }
+  if (n2 > mnn) { mc = c2; mnn = n2; }
+  if (n3 > mnn) { mc = c3; mnn = n3; }
+  const uint64_t minor = E - mnn;
+  // fallback: no dominating char and small enough for the LDS kernels; or too many distinct chars / a minority
+  // count that does not fit the 32-bit list
+  const bool fb = many || minor >= 0x7FFFFFFFull || (E <= (uint64_t)kHardLds && minor * 4 > E) || a.dbg_mode != 0;
+  const bool in_slice = !(base + E <= a.out_lo || base >= a.out_hi);
+  fallback[h] = (fb && in_slice) ? 1 : 0;
+  gmaj[g] = fb ? 0 : (uint8_t)mc;
+  minor_cnt[h] = (fb || !in_slice) ? 0u : (uint32_t)minor;
+  info[h] = HardGroupInfo{g, E, (uint32_t)k, (uint32_t)(fb ? 0 : minor)};
+  if (!fb && in_slice) mychars = E;
+  }
+  for (int o = 32; o > 0; o >>= 1) mychars += __shfl_down(mychars, o, 64);      // "Hard bwt chars" (pfbwt.cpp:231-233) of these groups
+  if ((threadIdx.x & 63) == 0 && mychars) atomicAdd(chars_total, mychars);
+}
+
+// one thread per minority occurrence (flattened over the groups by the prefix sums of minor_cnt)
+template <class I>
+__global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const HardGroupInfo *__restrict__ info, uint64_t nH,
+                                                         const uint64_t *__restrict__ minor_off, uint64_t total,
+                                                         const uint8_t *__restrict__ gmaj) {
+  for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (uint64_t)gridDim.x * 256) {
+    uint64_t lo = 0, hi = nH;               // minor_off[lo] <= q < minor_off[hi]
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (minor_off[mid] <= q) lo = mid; else hi = mid; }
+    const HardGroupInfo gi = info[lo];
+    const uint64_t g = gi.g;
+    const uint32_t k = gi.k;
+    const uint32_t maj = gmaj[g];
+    uint64_t ord = q - minor_off[lo];       // ordinal among the group's minority occurrences, in member order
+    // own member and index
+    uint32_t me = 0, j = 0;
+    uint64_t prev = slot_off(a, g);
+    const uint64_t base = prev;
+    for (uint32_t m = 0; m < k; m++) {
+      const uint64_t nxt = slot_off(a, g + m + 1);
+      const uint64_t occ = nxt - prev;
+      prev = nxt;
+      if ((uint32_t)fix_char(a.pc[g + m]) == maj) continue;
+      if (ord < occ) { me = m; j = (uint32_t)ord; break; }
+      ord -= occ;
+    }
+    const uint32_t my_ist = slot_ist(a, g + me);
+    const uint32_t pos = a.ilist[my_ist + j];
+    // rank among all occurrences of the group; predecessor and successor position over all lists
+    uint64_t r = j;
+    uint32_t pred = 0, succ = 0xFFFFFFFFu;
+    bool has_pred = false, has_succ = false;
+    prev = base;
+    for (uint32_t m = 0; m < k; m++) {
+      const uint64_t nxt = slot_off(a, g + m + 1);
+      const uint32_t occ = (uint32_t)(nxt - prev);
+      prev = nxt;
+      const uint32_t *lst = a.ilist + (m == me ? my_ist : slot_ist(a, g + m));
+      uint32_t lb;
+      if (m == me) lb = j;
+      else {
+        uint32_t l2 = 0, h2 = occ;          // # entries < pos
+        while (l2 < h2) { const uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
+        lb = l2;
+        r += lb;
+      }
+      if (a.want_sa) {
+        if (lb > 0) { const uint32_t v = lst[lb - 1]; if (!has_pred || v > pred) { pred = v; has_pred = true; } }
+        const uint32_t nx = m == me ? lb + 1 : lb;
+        if (nx < occ) { const uint32_t v = lst[nx]; if (!has_succ || v < succ) { succ = v; has_succ = true; } }
+      }
+    }
+    const uint64_t o = base + r;
+    if (o >= a.out_lo && o < a.out_hi) {
+      a.bwt[o] = fix_char(a.pc[g + me]);
+      if (a.want_sa) {
+        const uint64_t sl = a.slen[a.sa[g]];
+        a.out_sa[o] = a.bwsai[pos] - sl;
+        if (has_pred && o - 1 >= a.out_lo) a.out_sa[o - 1] = a.bwsai[pred] - sl;
+        if (has_succ && o + 1 < a.out_hi) a.out_sa[o + 1] = a.bwsai[succ] - sl;
+      }
+    } else if (a.want_sa) {      // the occurrence lies just outside this rank's slice: its neighbours may be inside
+      const uint64_t sl = a.slen[a.sa[g]];
+      if (has_pred && o >= 1 && o - 1 >= a.out_lo && o - 1 < a.out_hi) a.out_sa[o - 1] = a.bwsai[pred] - sl;
+      if (has_succ && o + 1 >= a.out_lo && o + 1 < a.out_hi) a.out_sa[o + 1] = a.bwsai[succ] - sl;
+    }
   }
 }
 
@@ -508,9 +742,6 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgsT<I> a, cons
 // group's LDS segment, or, when the group is a few long sorted lists, own index + lower_bound in
 // each other member's segment.  Groups that do not fit the LDS tables are queued for
 // hard_big_kernel.  (One group at a time per wave took 7.7 us per group, 22 ms at 8.8 M groups.)
-constexpr int kHardLds = 1024;   // occurrences of one batch ranked in LDS
-constexpr int kHardMem = 256;    // members of one batch
-constexpr int kHardSortMin = 512;   // a group with more occurrences than this (and <= kHardLds) is sorted, not ranked all-pairs
 struct BigGroup { uint64_t g; uint64_t E; uint32_t k; uint32_t pad; };
 struct HardLds {
   uint32_t lpos[kHardLds];
@@ -773,14 +1004,22 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   // istart in lexicographic order (pfbwt.cpp:388-396), looked up per word
   DBuf<uint32_t> istart_lex(c, d), wistart(c, d);
   exclusive_sum_u32(c, occ_lex, istart_lex.p, d);
-  hipLaunchKernelGGL(wistart_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, wistart.p);
+  // SA values: none, all (-S), or only where the sampled files can look (-s / -e): run boundaries of the BWT
+  const int sa_mode = !flags ? SA_NONE : ((flags & PFP_FLAG_SA) ? SA_DENSE : SA_SPARSE);
+  static const bool dense_always = getenv("PFP_DENSE_SA") != nullptr;      // tests: -s / -e through the dense path
+  const int samode = (sa_mode == SA_SPARSE && dense_always) ? SA_DENSE : sa_mode;
+  const bool dense = samode == SA_DENSE;
+  DBuf<uint32_t> wfirst, wlast;
+  if (samode == SA_SPARSE) { wfirst.alloc(c, d); wlast.alloc(c, d); }
+  hipLaunchKernelGGL(wistart_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, D.wocc.p, pb.ilist.p,
+                     wistart.p, wfirst.p, wlast.p);
   DBuf<uint16_t> pp16;
   DBuf<uint64_t> pp64;
   DBuf<uint32_t> cnt(c, N + 8), ist;
   // records already sit at their slots - unless most slots were re-ordered after the first round (a
   // dictionary of near-identical variants), where fetching each such record costs more than the gather
-  const bool from_keys = !flags && so.paybits == 16 && so.skeys.p && so.n_refined * 5 < N;
-  if (flags) { ist.alloc(c, N + 8); pp64.alloc(c, NP); } else if (!from_keys) pp16.alloc(c, NP);
+  const bool from_keys = !dense && so.paybits == 16 && so.skeys.p && so.n_refined * 5 < N;
+  if (dense) { ist.alloc(c, N + 8); pp64.alloc(c, NP); } else if (!from_keys) pp16.alloc(c, NP);
   DBuf<uint8_t> pc(c, N + 8), hard(c, N);
   const uint64_t ntile = (N >> kOffTileLog) + 1;        // covers slot index N (one past the last)
   DBuf<uint32_t> loc(c, ntile << kOffTileLog), ovf(c, 1);
@@ -792,14 +1031,14 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     hipLaunchKernelGGL(slot_payload_kernel<I>, dim3(cdiv(cdiv64(N, 8), 256)), dim3(256), 0, c->stream, N, so.sa.p, so.skeys.p,
                        so.refined.p, D.bytes.p, ix.pos_word.p, ix.slen.p, D.wocc.p, d, w, cnt.p, pc.p);
   } else {
-  { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + (flags ? 8 : 2)));
-    if (flags) hipLaunchKernelGGL(pprec_kernel<uint64_t>, dim3(cdiv(NP, TB)), dim3(TB), 0, c->stream, D.bytes.p, NP, d, w,
+  { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + (dense ? 8 : 2)));
+    if (dense) hipLaunchKernelGGL(pprec_kernel<uint64_t>, dim3(cdiv(NP, TB)), dim3(TB), 0, c->stream, D.bytes.p, NP, d, w,
                                   ix.pos_word.p, ix.slen.p, D.wocc.p, pp64.p);
     else hipLaunchKernelGGL(pprec_kernel<uint16_t>, dim3(cdiv(NP, TB)), dim3(TB), 0, c->stream, D.bytes.p, NP, d, w,
                             ix.pos_word.p, ix.slen.p, D.wocc.p, pp16.p); }
-  { KScope ks(c, "pfp::slot_gather_kernel", N * (sizeof(I) + 5 + (flags ? 12 : 2)));
+  { KScope ks(c, "pfp::slot_gather_kernel", N * (sizeof(I) + 5 + (dense ? 12 : 2)));
     const dim3 grid(cdiv(cdiv64(N, 8), 256));
-    if (flags) hipLaunchKernelGGL((slot_gather_kernel<uint64_t, I>), grid, dim3(256), 0, c->stream, N, so.sa.p, pp64.p,
+    if (dense) hipLaunchKernelGGL((slot_gather_kernel<uint64_t, I>), grid, dim3(256), 0, c->stream, N, so.sa.p, pp64.p,
                                   ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, ist.p);
     else hipLaunchKernelGGL((slot_gather_kernel<uint16_t, I>), grid, dim3(256), 0, c->stream, N, so.sa.p, pp16.p,
                             ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, (uint32_t *)nullptr); }
@@ -811,7 +1050,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     hipLaunchKernelGGL(slot_loc_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, cnt.p, N, loc.p, tsum.p, ovf.p); }
   exclusive_sum_u64(c, tsum.p, tbase.p, ntile + 1);
   { KScope ks(c, "pfp::group_flags_kernel", N * 5);
-  hipLaunchKernelGGL(group_flags_kernel<I>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.grp.p, pc.p, flags ? 1 : 0, hard.p); }
+  hipLaunchKernelGGL(group_flags_kernel<I>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.grp.p, pc.p, dense ? 1 : 0, hard.p); }
   PFP_REQUIRE(read_scalar(c, ovf.p) == 0, PFP_ELIMIT, "2048 consecutive suffix-array slots emit 2^32 or more BWT positions");
   const uint64_t n_out = read_scalar(c, tbase.p + ntile);
   PFP_REQUIRE(expect_n_out == 0 || n_out == expect_n_out, PFP_EFORMAT,
@@ -820,11 +1059,11 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   out.n_out = n_out;
   cnt.release();
   MergeArgsT<I> a{};
-  a.N = N; a.n_out = n_out; a.d = d; a.w = w; a.want_sa = flags ? 1 : 0;
+  a.N = N; a.n_out = n_out; a.d = d; a.w = w; a.want_sa = samode;
   a.pos_base = pos_base; a.n_out_global = n_out_global ? n_out_global : n_out;
   { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
-  a.sa = so.sa.p; a.slen = ix.slen.p; a.grp = so.grp.p; a.ist = flags ? ist.p : nullptr;
-  a.pos_word = ix.pos_word.p; a.wistart = wistart.p;
+  a.sa = so.sa.p; a.slen = ix.slen.p; a.grp = so.grp.p; a.ist = dense ? ist.p : nullptr;
+  a.pos_word = ix.pos_word.p; a.wistart = wistart.p; a.wfirst = wfirst.p; a.wlast = wlast.p;
   a.pc = pc.p; a.hard = hard.p; a.tbase = tbase.p; a.loc = loc.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p;
   // the caller's buffers hold positions [out_lo, out_hi): rebase so that kernels index by global position
@@ -837,24 +1076,68 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   // such a group emits > kHardSortMin positions (PFP_HARD_MODE=3, tests: every group takes this path)
   const uint32_t mid_cap = (uint32_t)std::min<uint64_t>(a.dbg_mode == 3 ? N / 2 + 2 : n_out / (kHardSortMin + 1) + 64, 0x7FFFFFFFull);
   DBuf<BigGroup> mid(c, mid_cap);
+  // hard[] marks exactly the heads of the hard groups (group_flags_kernel): count, then compact them once
+  const uint64_t n_heads = count_flags(c, hard.p, N);
+  DBuf<I> heads(c, n_heads + 1);
+  DBuf<uint64_t> nheads(c, 2);
+  select_index<I>(c, hard.p, heads.p, nheads.p, N);
+  // BWT only / sparse SA: majority fill + minority placement; groups it leaves (no dominating char) go to the LDS kernels
+  DBuf<uint8_t> gmaj, fallback;
+  DBuf<unsigned long long> mstat(c, 1);
+  mstat.zero();
+  DBuf<HardGroupInfo> ginfo;
+  DBuf<uint32_t> minor_cnt;
+  DBuf<uint64_t> minor_off;
+  DBuf<I> fb_heads;
+  const I *hard_list = heads.p;             // what hard_groups_kernel works through
+  const uint64_t *hard_list_n = nheads.p;
+  uint64_t n_minor = 0, n_fallback = n_heads;
+  if (!dense && n_heads) {
+    gmaj.alloc(c, N); fallback.alloc(c, n_heads); ginfo.alloc(c, n_heads); minor_cnt.alloc(c, n_heads + 1); minor_off.alloc(c, n_heads + 1);
+    PFP_HIP(hipMemsetAsync(minor_cnt.p + n_heads, 0, 4, c->stream));
+    a.gmaj = gmaj.p;
+    { KScope ks(c, "pfp::hard_classify_kernel", n_heads * 40);
+      hipLaunchKernelGGL(hard_classify_kernel<I>, dim3(cdiv(n_heads, 256)), dim3(256), 0, c->stream, a, heads.p, n_heads, gmaj.p,
+                         ginfo.p, minor_cnt.p, fallback.p, mstat.p); }
+    exclusive_sum_u32_u64(c, minor_cnt.p, minor_off.p, n_heads + 1);
+    n_fallback = count_flags(c, fallback.p, n_heads);
+    n_minor = read_scalar(c, minor_off.p + n_heads);
+    fb_heads.alloc(c, n_fallback + 1);
+    {  // heads of the fallback groups = heads[] where fallback[] is set
+      DBuf<I> fidx(c, n_fallback + 1);
+      select_index<I>(c, fallback.p, fidx.p, nheads.p + 1, n_heads);
+      if (n_fallback) hipLaunchKernelGGL(gather_idx_kernel<I>, dim3(cdiv(n_fallback, 256)), dim3(256), 0, c->stream, n_fallback, fidx.p,
+                                         heads.p, fb_heads.p);
+      PFP_HIP(hipGetLastError());
+      sync(c);
+    }
+    hard_list = fb_heads.p; hard_list_n = nheads.p + 1;
+  }
   {
     const uint32_t nblk = (uint32_t)cdiv64(N, kSlots);
     DBuf<uint32_t> heavy(c, nblk), nheavy(c, 1);
     nheavy.zero();
-    { KScope ks(c, "pfp::expand_kernel", N * 14 + n_out * (flags ? 17 : 1));
-    hipLaunchKernelGGL(expand_kernel<I>, dim3(nblk), dim3(256), 0, c->stream, a, heavy.p, nheavy.p, nblk); }
+    { KScope ks(c, "pfp::expand_kernel", N * 14 + n_out * (dense ? 17 : 1));
+    if (samode == SA_SPARSE) hipLaunchKernelGGL((expand_kernel<I, 1>), dim3(nblk), dim3(256), 0, c->stream, a, heavy.p, nheavy.p, nblk);
+    else hipLaunchKernelGGL((expand_kernel<I, 0>), dim3(nblk), dim3(256), 0, c->stream, a, heavy.p, nheavy.p, nblk); }
     const uint32_t nh = read_scalar(c, nheavy.p);
     KScope ks2(c, "pfp::expand_heavy_kernel", 0);   // bytes are accounted in expand_kernel's n_out term
     if (nh) hipLaunchKernelGGL(expand_heavy_kernel<I>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, heavy.p, nh);
   }
-  // hard[] marks exactly the heads of the hard groups (group_flags_kernel): count, then compact them once
-  const uint64_t n_heads = count_flags(c, hard.p, N);
-  DBuf<I> heads(c, n_heads + 1);
-  DBuf<uint64_t> nheads(c, 1);
-  select_index<I>(c, hard.p, heads.p, nheads.p, N);
+  if (samode == SA_SPARSE) {
+    KScope ks(c, "pfp::group_edges_kernel", N * 5);
+    hipLaunchKernelGGL(group_edges_kernel<I>, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, a);
+  }
+  if (n_minor) {
+    KScope ks(c, "pfp::hard_minor_kernel", n_minor * 64);
+    hipLaunchKernelGGL(hard_minor_kernel<I>, dim3((unsigned)std::min<uint64_t>(cdiv64(n_minor, 256), (uint64_t)c->n_cu * 64)), dim3(256), 0,
+                       c->stream, a, ginfo.p, n_heads, minor_off.p, n_minor, gmaj.p);
+  }
+  PFP_HIP(hipGetLastError());
   for (;;) {
-    { KScope ks(c, "pfp::hard_groups_kernel", N * 5);
-      hipLaunchKernelGGL(hard_groups_kernel<I>, dim3(c->n_cu * 8), dim3(256), 0, c->stream, a, heads.p, nheads.p, hstats.p, big.p,
+    if (!n_fallback) { PFP_HIP(hipMemsetAsync(hstats.p, 0, 40, c->stream)); }
+    else { KScope ks(c, "pfp::hard_groups_kernel", N * 5);
+      hipLaunchKernelGGL(hard_groups_kernel<I>, dim3(c->n_cu * 8), dim3(256), 0, c->stream, a, hard_list, hard_list_n, hstats.p, big.p,
                          big_cap, mid.p, mid_cap); }
     PFP_HIP(hipGetLastError());
     PFP_HIP(hipMemcpyAsync(c->h_scalars, hstats.p, 40, hipMemcpyDeviceToHost, c->stream));
@@ -866,12 +1149,15 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   }
   out.hard_chars = c->h_scalars[0];
   out.hard_groups = c->h_scalars[1];
+  out.hard_minor_groups = n_heads - n_fallback; out.hard_minor_chars = n_minor;
+  out.hard_chars += read_scalar(c, (const uint64_t *)mstat.p);      // all chars of hard groups, whichever path wrote them
+  out.hard_groups += n_heads - n_fallback;
   out.hard_big_groups = c->h_scalars[2]; out.hard_max_chars = 0; out.hard_max_members = c->h_scalars[4];
   const uint32_t nmid = (uint32_t)std::min<uint64_t>(c->h_scalars[3], mid_cap);
   PFP_REQUIRE(c->h_scalars[3] <= mid_cap, PFP_EHIP, "more sorted-path hard groups than the output can hold");
   const uint32_t nbig = (uint32_t)c->h_scalars[2];
   if (nmid) {
-    KScope ks(c, "pfp::hard_sort_kernel", (uint64_t)nmid * (kHardSortMin + 1) * (flags ? 21 : 5));      // lower bound: ilist entry + char (+ SA) per occurrence
+    KScope ks(c, "pfp::hard_sort_kernel", (uint64_t)nmid * (kHardSortMin + 1) * (samode ? 21 : 5));      // lower bound: ilist entry + char (+ SA) per occurrence
     hipLaunchKernelGGL(hard_sort_kernel<I>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, mid.p, nmid);
     PFP_HIP(hipGetLastError());
   }

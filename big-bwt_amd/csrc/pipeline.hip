@@ -128,7 +128,8 @@ static void check_args(int w, uint64_t p, int flags) {
 }
 
 // stage 1 on a staged text: scan, dictionary, dictionary suffix order, lexicographic ranks
-static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool want_sai, bool exact_reference_parse) {
+static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool want_sai, bool exact_reference_parse,
+                      bool dense_sa = false) {
   pfp_stats &st = c->stats;
   {
     PhaseTimer t(c, &st.ms_scan);
@@ -153,7 +154,7 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
     with_width(ch.ord.wide, [&](auto tag) {
       using I = decltype(tag);
       auto &so = ch.ord.get<I>();
-      sort_dict_suffixes<I>(c, ch.D.bytes.p, ch.D.dsize, ch.ix.slen.p, so, want_sai ? nullptr : &pay);
+      sort_dict_suffixes<I>(c, ch.D.bytes.p, ch.D.dsize, ch.ix.slen.p, so, dense_sa ? nullptr : &pay);
       if (c->debug) validate_suffix_order<I>(c, ch.D.bytes.p, so, true, "dict SA");
       compute_lexrank<I>(c, ch.D, so, ch.ix);
     });
@@ -176,7 +177,7 @@ static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, 
   pfp_stats &st = c->stats;
   st = pfp_stats{};
   auto t0 = std::chrono::steady_clock::now();
-  run_parse(c, ch, n, w, p, flags != 0, false);
+  run_parse(c, ch, n, w, p, flags != 0, false, (flags & PFP_FLAG_SA) != 0);
   {
     PhaseTimer t(c, &st.ms_sa_parse);
     parse_bwt(c, ch.sym.p, ch.D.P, ch.D.last.p, flags ? ch.D.sai.p : nullptr, ch.occ_lex.p, ch.D.d, ch.pb);
@@ -193,6 +194,7 @@ static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, 
     });
     st.hard_groups = bo.hard_groups; st.hard_chars = bo.hard_chars;
     st.hard_big_groups = bo.hard_big_groups; st.hard_max_chars = bo.hard_max_chars; st.hard_max_members = bo.hard_max_members;
+    st.hard_minor_groups = bo.hard_minor_groups; st.hard_minor_chars = bo.hard_minor_chars;
   }
   sync(c);
   st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -462,7 +464,7 @@ int pfp_parse(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, in
   c->stats = pfp_stats{};
   Chain ch;
   ch.tx.stage(c, text, false, n, w);
-  run_parse(c, ch, n, w, p, want_sai != 0, true);
+  run_parse(c, ch, n, w, p, want_sai != 0, true, true);      // the staged parser's outputs do not depend on the key payload
   const uint32_t d = (uint32_t)ch.D.d;
   const uint64_t P = ch.D.P;
   // .dict in lexicographic order
@@ -680,7 +682,7 @@ int pfp_merge(pfp_ctx *c, const uint8_t *dict, uint64_t dict_size, const uint32_
   with_width(ord.wide, [&](auto tag) {
     using I = decltype(tag);
     auto &so = ord.get<I>();
-    sort_dict_suffixes<I>(c, D.bytes.p, D.dsize, ix.slen.p, so, flags ? nullptr : &pay);
+    sort_dict_suffixes<I>(c, D.bytes.p, D.dsize, ix.slen.p, so, (flags & PFP_FLAG_SA) ? nullptr : &pay);
     if (c->debug) validate_suffix_order<I>(c, D.bytes.p, so, true, "dict SA");
     compute_lexrank<I>(c, D, so, ix);
   });
@@ -830,6 +832,7 @@ struct DistState {
   DBuf<uint32_t> occ_lex;
   uint64_t local_total = 0;     // BWT positions the held slots emit
   bool want_sai = false;
+  int flags = 0;                // output flags announced at pfp_dist_local_parse (0: BWT only)
 };
 static DistState *dist_of(pfp_ctx *c) {
   if (!c->dist) c->dist = new DistState();
@@ -912,6 +915,7 @@ int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t ha
   // T' index x of the local text is global text position global_offset - halo_len + x - 1; sai = end position + 1
   const uint64_t sai_base = global_offset - halo_len;
   ds->want_sai = want_sai != 0;
+  ds->flags = want_sai & 7;     // callers pass the output flags here (any non-zero value asks for sa info)
   build_dictionary_shard(c, ds->tx, n, w, ds->ends, ds->n_ends, ds->k0, ds->P_local, want_sai != 0, sai_base, ds->L);
   out_sizes[0] = ds->L.dsize - 1;      // local dictionary bytes without the final 0x00
   out_sizes[1] = ds->L.d;
@@ -960,7 +964,7 @@ int pfp_dist_global_sort(pfp_ctx *c, const void *d_union, uint64_t union_bytes, 
   build_dict_index(c, ds->G, ds->ix);
   const uint32_t d = (uint32_t)ds->G.d;
   const SlotPayloadSrc pay{ds->ix.pos_word.p, ds->ix.slen.p, ds->G.wocc.p, d, ds->w};
-  const SlotPayloadSrc *payp = ds->want_sai ? nullptr : &pay;      // no sa info was parsed: the merge will be BWT only
+  const SlotPayloadSrc *payp = (ds->flags & PFP_FLAG_SA) ? nullptr : &pay;      // full SA: the merge gathers wider records itself
   ds->ord.wide = use_wide_index(c, ds->G.dsize);
   uint64_t info_rounds = 0, info_complete = 1, info_N = 0, info_base = 0;
   with_width(ds->ord.wide, [&](auto tag) {

@@ -355,6 +355,53 @@ __global__ void build_keys32_kernel(SufGeom g, uint64_t m, uint64_t h, const uin
   key[a] = (g.mode == MODE_DICT || (uint64_t)i + h < g.N) ? rank_at(L, (uint64_t)i + h, settled) + 1u : 0u;
   val[a] = i | (settled ? L.finbit : 0u);
 }
+// Small segments.  The unresolved suffixes of a dictionary of variants come in families of a handful of members
+// (a phrase and the variants that agree with it over the first-round prefix): a device-wide radix sort of
+// (group, order key) moves every element 7 times to reorder it inside a group of six.  Here every element
+// finds its place directly: start of its group in the (grouped) active list from a max-scan of the group
+// starts, rank inside the group by comparing with the group's members (a few neighbouring, cached loads).
+// Stable: equal keys keep their list order.  Used while the longest group has at most kSmallSeg members.
+constexpr uint32_t kSmallSeg = 256;
+template <class I>
+__global__ void seg_marks_kernel(uint64_t m, const I *__restrict__ act_grp, uint8_t *__restrict__ gs, I *__restrict__ mark) {
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  const bool h = a == 0 || act_grp[a] != act_grp[a - 1];
+  gs[a] = h ? 1 : 0;
+  mark[a] = h ? (I)a : (I)0;
+}
+template <class I>
+__global__ __launch_bounds__(256) void seg_maxlen_kernel(uint64_t m, const uint8_t *__restrict__ gs, const I *__restrict__ start_of,
+                                                         unsigned long long *__restrict__ maxlen) {
+  __shared__ unsigned long long ws[4];
+  uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long len = 0;
+  if (a < m && (a + 1 == m || gs[a + 1])) len = a - (uint64_t)start_of[a] + 1;
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_down(len, o, 64); len = v > len ? v : len; }
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = len;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long v = ws[0];
+    for (int q = 1; q < 4; q++) v = ws[q] > v ? ws[q] : v;
+    if (v) atomicMax(maxlen, v);
+  }
+}
+template <class I>
+__global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const uint8_t *__restrict__ gs, const I *__restrict__ start_of,
+                                                             const uint32_t *__restrict__ key, const I *__restrict__ val,
+                                                             uint32_t *__restrict__ keyo, I *__restrict__ valo) {
+  uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (a >= m) return;
+  const uint64_t s0 = start_of[a];
+  const uint32_t ka = key[a];
+  uint64_t r = 0;
+  for (uint64_t j = s0; j < m && (j == s0 || !gs[j]); j++) {
+    const uint32_t kj = key[j];
+    r += (kj < ka || (kj == ka && j < a)) ? 1 : 0;
+  }
+  keyo[s0 + r] = ka;
+  valo[s0 + r] = val[a];
+}
 __global__ void seg_end_kernel(uint32_t ng, uint32_t m, const uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
                                uint32_t *__restrict__ maxlen) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -731,9 +778,28 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
                        out.finbit, out.rank.p);
     ranks_stale = false;
   };
+  DBuf<unsigned long long> maxlen_d;
+  auto seg_bufs = [&]() {
+    if (!gs.p) { gs.alloc(c, list_cap + 1); k32.alloc(c, list_cap); k32o.alloc(c, list_cap); nseg_d.alloc(c, 2); nsel_d.alloc(c, 1); maxlen_d.alloc(c, 1); }
+  };
+  // group starts of the active list, start index of every element's group (-> newhead, scratch at this point of
+  // a round) and the longest group
+  auto seg_starts = [&](uint64_t mm) -> uint64_t {
+    seg_bufs();
+    maxlen_d.zero();
+    KScope ks(c, "pfp::seg_small_sort_kernel", mm * (sizeof(I) * 3 + 2));
+    hipLaunchKernelGGL(seg_marks_kernel<I>, dim3(cdiv(mm, TB)), dim3(TB), 0, c->stream, mm, act_grp.p, gs.p, hv.p);
+    inclusive_max<I>(c, hv.p, newhead.p, mm);
+    hipLaunchKernelGGL(seg_maxlen_kernel<I>, dim3(cdiv(mm, TB)), dim3(TB), 0, c->stream, mm, gs.p, newhead.p, maxlen_d.p);
+    return read_scalar(c, (const uint64_t *)maxlen_d.p);
+  };
+  auto seg_small_sort = [&](uint64_t mm) {      // k32/val -> k32o/valo, every group sorted by its 32-bit key
+    KScope ks(c, "pfp::seg_small_sort_kernel", mm * (8 + 2 * sizeof(I) + sizeof(I) + 1));
+    hipLaunchKernelGGL(seg_small_sort_kernel<I>, dim3(cdiv(mm, TB)), dim3(TB), 0, c->stream, mm, gs.p, newhead.p, k32.p, val.p, k32o.p, valo.p);
+  };
   auto seg_setup = [&](uint64_t mm, uint32_t &ng, uint32_t &maxlen) {      // segments = groups of the (grouped) active list
-    if (!gs.p) { gs.alloc(c, list_cap); k32.alloc(c, list_cap); k32o.alloc(c, list_cap); segb.alloc(c, list_cap + 1); sege.alloc(c, list_cap + 1);
-                 nseg_d.alloc(c, 2); nsel_d.alloc(c, 1); }
+    seg_bufs();
+    if (!segb.p) { segb.alloc(c, list_cap + 1); sege.alloc(c, list_cap + 1); }
     hipLaunchKernelGGL(group_starts_kernel<I>, dim3(cdiv(mm, TB)), dim3(TB), 0, c->stream, mm, act_grp.p, gs.p);
     select_index<uint32_t>(c, gs.p, segb.p, nsel_d.p, mm);
     PFP_HIP(hipMemsetAsync(nseg_d.p + 1, 0, 4, c->stream));
@@ -879,18 +945,21 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     if (pivot_round) {
       // large families (a collection of hundreds of copies): the members are already grouped, a
       // segmented sort of the 23-bit order key moves 16 B per suffix instead of 7 x 24 B
-      bool seg = false;
+      bool seg = false, small = false;
       uint32_t ng = 0;
       static const uint32_t seg_min_avg = []() { const char *e = getenv("PFP_SEG_MINAVG"); return e ? (uint32_t)atoi(e) : 24u; }();
-      if (use_segsort && m >= (1u << 20) && m < 0xFFFFFFFFull && m / ngrp >= seg_min_avg) {
+      static const bool use_small = getenv("PFP_NO_SMALLSEG") == nullptr;
+      if (use_segsort && use_small) small = seg_starts(m) <= kSmallSeg;      // families of a handful of members: placed directly
+      if (!small && use_segsort && m >= (1u << 20) && m < 0xFFFFFFFFull && m / ngrp >= seg_min_avg) {
         uint32_t maxlen = 0;
         seg_setup(m, ng, maxlen);
         seg = maxlen <= (1u << 15) && m / ng >= seg_min_avg;
       }
       { KScope ks(c, "pfp::build_keys_pivot_kernel", m * (4 + 4 + 4 + 12 + 64));
         hipLaunchKernelGGL(build_keys_pivot_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, out.bytes, m, h, piv_cap, act_i.p,
-                           act_grp.p, out.sa.p, out.finbit, key.p, seg ? k32.p : (uint32_t *)nullptr, val.p); }
-      if (seg) { segsort_pairs_u32<I>(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, kPivBits); seg_round = true; }
+                           act_grp.p, out.sa.p, out.finbit, key.p, (seg || small) ? k32.p : (uint32_t *)nullptr, val.p); }
+      if (small) { seg_small_sort(m); seg_round = true; }
+      else if (seg) { segsort_pairs_u32<I>(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, kPivBits); seg_round = true; }
       else { sort_pairs_db(c, key, keyo, val, valo, m, 0, nb + kPivBits); std::swap(key, keyo); std::swap(val, valo); }
       out.rounds++;
       continue;                 // the sorted prefix common to all groups is still h: no doubling of h
@@ -910,7 +979,13 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     const RankViewT<I> L = rank_view(out);
     dbl_round = true;
     if constexpr (!kWide) {
-      if (use_segsort && m >= (1u << 20) && ngrp && m / ngrp >= 24) {
+      static const bool use_small = getenv("PFP_NO_SMALLSEG") == nullptr;
+      if (use_segsort && use_small && seg_starts(m) <= kSmallSeg) {
+        { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
+          hipLaunchKernelGGL(build_keys32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
+        seg_small_sort(m);
+        seg_round = true;
+      } else if (use_segsort && m >= (1u << 20) && ngrp && m / ngrp >= 24) {
         uint32_t ng = 0, maxlen = 0;
         seg_setup(m, ng, maxlen);
         if (maxlen <= (1u << 15) && m / ng >= 24) {

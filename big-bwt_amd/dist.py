@@ -145,7 +145,7 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
     extra.sort()
 
     def local_parse():
-        info = ctx.dist_local_parse(local.data_ptr(), local.numel(), left.numel(), w, p, rank == 0, rank == size - 1, goff, want_sai,
+        info = ctx.dist_local_parse(local.data_ptr(), local.numel(), left.numel(), w, p, rank == 0, rank == size - 1, goff, flags,
                                     extra)
         # the next rank re-derives my last phrase boundary from the last tail.numel() bytes of my shard
         if rank < size - 1 and info["last_trigger"] - (w - 1) < local.numel() - tail.numel():

@@ -65,6 +65,7 @@ class Stats(C.Structure):
                 ("hard_big_groups", C.c_uint64), ("hard_max_chars", C.c_uint64), ("hard_max_members", C.c_uint64),
                 ("hash_reseeds", C.c_uint64),
                 ("extra_triggers", C.c_uint64), ("index_bits", C.c_uint64),
+                ("hard_minor_groups", C.c_uint64), ("hard_minor_chars", C.c_uint64),
                 ("ms_scan", C.c_double), ("ms_phrases", C.c_double), ("ms_sa_dict", C.c_double),
                 ("ms_sa_parse", C.c_double), ("ms_merge", C.c_double), ("ms_total", C.c_double)]
 

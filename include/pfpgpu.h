@@ -141,7 +141,10 @@ int pfp_bigbwt(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p,
 
 /* Device-resident variant: d_text is a device pointer to n bytes; d_bwt must hold n+1 bytes.
  * Optional device outputs (may be NULL unless the flag is set):
- *   d_sa   u64[n+1]  SA value per BWT position (d_sa[0] = n), flags & (SA|SSA|ESA)
+ *   d_sa   u64[n+1]  SA value per BWT position (d_sa[0] = n), flags & (SA|SSA|ESA).  With PFP_FLAG_SA every entry is
+ *                    written.  With only PFP_FLAG_SSA / PFP_FLAG_ESA the entries at the run boundaries of the BWT -
+ *                    positions j with BWT[j] != BWT[j-1] or BWT[j] != BWT[j+1], j = 0 and j = n, i.e. every entry
+ *                    the .ssa/.esa files hold (pfbwt.cpp:605-676) - are written and the rest is left untouched.
  * Run-sampled / packed outputs are derived from d_bwt/d_sa by pfp_pack5_dev / pfp_sample_runs_dev below.
  * *n_used returns the parsed length; bwt length is *n_used + 1. */
 int pfp_bigbwt_dev(pfp_ctx *ctx, const void *d_text, uint64_t n, int w, uint64_t p, int flags,
@@ -176,6 +179,7 @@ typedef struct {
   uint64_t hash_reseeds;
   uint64_t extra_triggers;   /* window hashes added by the fused chain to split giant phrases */
   uint64_t index_bits;       /* 32 or 64: width of dictionary positions / suffix-array slots used (bigbwt:130-151) */
+  uint64_t hard_minor_groups, hard_minor_chars; /* hard groups done by majority fill; occurrences ranked for them */
   double ms_scan, ms_phrases, ms_sa_dict, ms_sa_parse, ms_merge, ms_total; /* host wall, synced */
 } pfp_stats;
 int pfp_get_stats(const pfp_ctx *ctx, pfp_stats *st);
@@ -209,7 +213,8 @@ int pfp_set_index_bits(pfp_ctx *ctx, int bits);
  *       extra_hashes so that all ranks parse with one trigger set (outputs do not depend on it)
  *   pfp_dist_local_parse : d_text = halo (the last halo_len bytes of the previous shard; 0 for the
  *       first rank) followed by this rank's shard, n bytes in all; global_offset = position of the
- *       shard's first byte in the whole text.  Owns the phrases that end inside the shard.
+ *       shard's first byte in the whole text.  Owns the phrases that end inside the shard.  want_sai = the output
+ *       flags of the run (PFP_FLAG_*; 0 = BWT only: no sa info is kept).
  *       out_sizes = {local dict bytes, local words, local phrases, local position of last trigger}
  *   pfp_dist_export_local: copies the local dictionary (words + 0x01), its occ (u32), last (u8)
  *       and sai (u64) into caller buffers (any may be NULL)

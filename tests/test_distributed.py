@@ -80,6 +80,67 @@ def test_allgather_plumbing_gloo_world2():
         assert res[1] == [sum(want_cat) + 0, sum(want_cat) + 1]
 
 
+def _pieces(res, key):
+    """concatenate the ranks' pieces of one output file after checking that their offsets tile it"""
+    off = 0
+    parts = []
+    for r in res:
+        assert r[key + "_off"] == off, (key, r[key + "_off"], off)
+        parts.append(r[key].cpu().numpy())
+        off += r[key].numel()
+    return np.concatenate(parts)
+
+
+def _check_files(pkg, res, want, flags, n):
+    assert res[0]["lo"] == 0 and res[-1]["hi"] == n + 1 and all(res[k]["hi"] == res[k + 1]["lo"] for k in range(len(res) - 1))
+    assert np.array_equal(torch.cat([r["bwt"] for r in res]).cpu().numpy(), want["bwt"])
+    if flags & pkg.FLAG_SA:
+        assert np.array_equal(pkg.unpack5(_pieces(res, "sa5")), want["sa"])
+    if flags & pkg.FLAG_SSA:
+        assert np.array_equal(pkg.unpack5(_pieces(res, "ssa")).reshape(-1, 2), want["ssa"])
+    if flags & pkg.FLAG_ESA:
+        assert np.array_equal(pkg.unpack5(_pieces(res, "esa")).reshape(-1, 2), want["esa"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [0, 64], ids=["idx32", "idx64"])
+@pytest.mark.parametrize("R", [2, 3, 8])
+@pytest.mark.parametrize("cfg", [(10, 100, 1), (10, 100, 6), (12, 200, 2), (12, 200, 4)],
+                         ids=["c4_w10_p100_S", "w10_p100_s_e", "c5_w12_p200_s", "w12_p200_e"])
+def test_baseline_flag_sets_across_ranks(O, pkg, R, cfg, width, tmp_path):
+    """BASELINE configs[3] (-w 10 -p 100 -S) and configs[4] (-w 12 -p 200 -s) flag sets, plus -s -e / -e, with 2, 3 and 8
+    virtual ranks: every rank's pieces of .bwt/.sa/.ssa/.esa - written with pfp_pwrite_dev at their offsets -
+    give the oracle's files; both index widths."""
+    import importlib
+    d = importlib.import_module("bigbwt_amd.dist")
+    w, p, flags = cfg
+    text = O.gen_fasta(60000, 8, 0.003, 59)
+    n = len(text)
+    want = O.bigbwt(text, w, p, flags)
+    cuts = [0] + [n * (r + 1) // R + (5 * r - 2) for r in range(R - 1)] + [n]
+    ctxs = [pkg.Context(0) for _ in range(R)]
+    try:
+        for c in ctxs:
+            c.set_index_bits(width)
+        shards = [torch.from_numpy(text[cuts[r]:cuts[r + 1]].copy()).cuda() for r in range(R)]
+        res = d.simulate(ctxs, shards, w, p, flags, halo=8192)
+        assert {r["stats"]["glob"]["index_bits"] for r in res} == {64 if width else 32}
+        _check_files(pkg, res, want, flags, n)
+        base = str(tmp_path / "t")
+        for r in range(R - 1, -1, -1):          # any order: every piece lands at its own offset
+            d.write_outputs(ctxs[r], base, res[r])
+        assert np.array_equal(np.fromfile(base + ".bwt", dtype=np.uint8), want["bwt"])
+        if flags & pkg.FLAG_SA:
+            assert np.array_equal(np.fromfile(base + ".sa", dtype=np.uint8), O.pack5(want["sa"]))
+        if flags & pkg.FLAG_SSA:
+            assert np.array_equal(np.fromfile(base + ".ssa", dtype=np.uint8), O.pack5(want["ssa"].reshape(-1)))
+        if flags & pkg.FLAG_ESA:
+            assert np.array_equal(np.fromfile(base + ".esa", dtype=np.uint8), O.pack5(want["esa"].reshape(-1)))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shard_sa", [True, False], ids=["sa_by_key_range", "sa_replicated"])
 @pytest.mark.parametrize("R", [2, 3, 5])
@@ -98,7 +159,7 @@ def test_distributed_chain_matches_oracle(O, pkg, R, shard_sa, nblock):
     cuts = [0] + [n * (r + 1) // R + (7 * r - 3) for r in range(R - 1)] + [n]     # uneven, unaligned shards
     ctxs = [pkg.Context(0) for _ in range(R)]
     try:
-        for flags in (0, pkg.FLAG_SA):
+        for flags in (0, pkg.FLAG_SA, pkg.FLAG_SSA | pkg.FLAG_ESA):
             shards = [torch.from_numpy(text[cuts[r]:cuts[r + 1]].copy()).to(dev) for r in range(R)]
             for c in ctxs:
                 c.set_max_phrase(2000)
@@ -114,7 +175,8 @@ def test_distributed_chain_matches_oracle(O, pkg, R, shard_sa, nblock):
             want = O.bigbwt(text, 10, 100, flags)
             assert res[0]["lo"] == 0 and res[-1]["hi"] == n + 1
             assert np.array_equal(bwt, want["bwt"]), (R, flags)
-            if flags:
+            _check_files(pkg, res, want, flags, n)
+            if flags & pkg.FLAG_SA:
                 sa = torch.cat([r["sa"] for r in res]).cpu().numpy().astype(np.uint64)
                 assert sa[0] == n and np.array_equal(sa[1:], want["sa"])
             assert sum(r["stats"]["local"]["phrases"] for r in res) == res[0]["stats"]["phrases_total"]
@@ -178,6 +240,26 @@ def test_distributed_halo_too_small_is_reported(O, pkg):
         shards = [torch.from_numpy(text[:50000].copy()).to(dev), torch.from_numpy(text[50000:].copy()).to(dev)]
         with pytest.raises(pkg.PfpError):
             d.simulate(ctxs, shards, 10, 100, 0, halo=12)      # 12 bytes cannot hold a phrase boundary
+        # an error on ONE rank (a byte <= 2 inside its shard) stops every rank at the same step: nobody is left
+        # waiting in the next collective
+        bad = text.copy()
+        bad[55000] = 1
+        shards = [torch.from_numpy(bad[:50000].copy()).to(dev), torch.from_numpy(bad[50000:].copy()).to(dev)]
+        gens = [d.phases(ctxs[r], shards[r], r, 2, 10, 100, 0, 4096) for r in range(2)]
+        replies, raised = [None, None], [None, None]
+        for _ in range(40):
+            reqs = []
+            for r in range(2):
+                if raised[r] is None:
+                    try:
+                        reqs.append(gens[r].send(replies[r])[1])
+                    except pkg.PfpError as ex:
+                        raised[r] = ex
+            if all(x is not None for x in raised):
+                break
+            assert len(reqs) == 2, "one rank stopped while the other went on to the next collective"
+            replies = [list(reqs), list(reqs)]
+        assert all(x is not None for x in raised) and "rank 1" in str(raised[0]) and raised[1].code == -6
     finally:
         for c in ctxs:
             c.close()
@@ -201,7 +283,13 @@ def _gpu_worker(rank, size, port, q):
     shard = torch.from_numpy(text[lo:hi].copy()).to(dev)
     ctx = pkg.Context(0)
     res = d.run(ctx, shard, 10, 100, pkg.FLAG_SA, halo=8192)
-    q.put((rank, res["lo"], res["hi"], res["bwt"].cpu().numpy(), res["sa"].cpu().numpy()))
+    # a halo too small on one rank only: both ranks must leave the chain at the same collective (no deadlock)
+    try:
+        d.run(ctx, shard, 10, 100, 0, halo=12 if rank == 0 else 8192)
+        failed = None
+    except pkg.PfpError as ex:
+        failed = str(ex)
+    q.put((rank, res["lo"], res["hi"], res["bwt"].cpu().numpy(), res["sa"].cpu().numpy(), failed))
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
@@ -229,3 +317,55 @@ def test_distributed_run_two_processes_one_gpu(O):
     assert out[0][1] == 0 and out[1][2] == len(text) + 1
     assert np.array_equal(bwt, want["bwt"])
     assert sa[0] == len(text) and np.array_equal(sa[1:], want["sa"])
+    assert all(o[5] is not None for o in out), "a rank-local failure must stop every rank"
+
+
+def _nccl_worker(rank, size, port, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=size)          # RCCL over xGMI
+    pkg = entry.load_package()
+    O = entry.load_oracle()
+    import importlib
+    d = importlib.import_module("bigbwt_amd.dist")
+    text = O.gen_fasta(120000, 4, 0.002, 47)
+    n = len(text)
+    lo, hi = n * rank // size, n * (rank + 1) // size
+    shard = torch.from_numpy(text[lo:hi].copy()).to(torch.device("cuda", rank))
+    ctx = pkg.Context(rank)
+    res = d.run(ctx, shard, 12, 200, pkg.FLAG_SSA, halo=8192)
+    q.put((rank, res["lo"], res["hi"], res["bwt"].cpu().numpy(), res["ssa"].cpu().numpy(), res["ssa_off"]))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_distributed_run_over_rccl():
+    """the N>1 path on the nccl (= RCCL) backend, one process per GPU; needs two GPUs, skips itself on a one-GPU box"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the driver's 8-GPU node runs it)")
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    O = entry.load_oracle()
+    pkg = entry.load_package()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=600) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    text = O.gen_fasta(120000, 4, 0.002, 47)
+    want = O.bigbwt(text, 12, 200, O.FLAG_SSA)
+    assert np.array_equal(np.concatenate([o[3] for o in out]), want["bwt"])
+    assert out[0][5] == 0 and out[1][5] == len(out[0][4])
+    assert np.array_equal(pkg.unpack5(np.concatenate([o[4] for o in out])).reshape(-1, 2), want["ssa"])
