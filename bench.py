@@ -288,6 +288,30 @@ def main():
                                  note="pfp_bigbwt: host text in, host .bwt/.ssa/.esa out (PCIe inclusive)")
             host_ok = bool(np.array_equal(hb["bwt"], bwt[: n + 1].cpu().numpy()))
             del hb, host_text
+        # the C `bigbwt` driver, file to files (process start, HIP initialisation, page-cache reads and writes included)
+        cli = None
+        if world == 1 and not args.no_host_boundary and n <= (2 << 30):
+            import subprocess
+            import tempfile
+            tmpd = tempfile.mkdtemp(prefix="pfpbench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            try:
+                fn = os.path.join(tmpd, "t.fa")
+                text.cpu().numpy().tofile(fn)
+                cmd = [os.path.join(ROOT, "big-bwt_amd", "bigbwt"), "-w", str(w), "-p", str(p)]
+                cmd += [f for f, bit in (("-S", 1), ("-s", 2), ("-e", 4)) if flags & bit] + [fn]
+                t1 = time.perf_counter()
+                pr = subprocess.run(cmd, capture_output=True, text=True)
+                cli_s = time.perf_counter() - t1
+                inner = [ln for ln in pr.stdout.splitlines() if ln.startswith("Total construction time")]
+                ok = pr.returncode == 0 and os.path.getsize(fn + ".bwt") == n + 1
+                if ok and digests is not None:
+                    ok = hashlib.sha256(open(fn + ".bwt", "rb").read()).hexdigest() == gold["bwt_sha256"]
+                cli = dict(MBps_process=round(n / cli_s / 1e6, 1), seconds_process=round(cli_s, 3),
+                           seconds_construction=float(inner[0].split(":")[1]) if inner else None, outputs_ok=bool(ok),
+                           note="bigbwt (C driver) on a file in /dev/shm: mmap -> chunked pinned H2D -> chain -> outputs streamed from HBM into the files")
+            finally:
+                import shutil
+                shutil.rmtree(tmpd, ignore_errors=True)
         cpu = None
         parity_sample = None
         if O is not None:
@@ -317,6 +341,7 @@ def main():
             "scan_pass_k1": scan_row,
             "cpu_baseline": cpu,
             "host_buffer_boundary": host_boundary,
+            "cli_file_to_file": cli,
             "phases_ms": dict({k: round(st[k], 3) for k in ("ms_scan", "ms_phrases", "ms_sa_dict", "ms_sa_parse", "ms_merge", "ms_total")},
                               formats=round(t_formats, 3), profiled_step=round(prof_ms, 3)),
             "sa_rounds": {"dict": st["sa_rounds_dict"], "parse": st["sa_rounds_parse"]},

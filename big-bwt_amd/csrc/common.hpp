@@ -36,7 +36,19 @@ struct Error : std::runtime_error {
     if (!(cond)) throw ::pfp::Error((code), (msg));        \
   } while (0)
 
-inline int cdiv(uint64_t a, uint64_t b) { return (int)((a + b - 1) / b); }
+inline uint64_t cdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+// Launch grid for nblocks workgroups.  HIP keeps the global work size of a dimension in 32 bits (blocks x threads
+// per block must stay below 2^32: a 1-D launch of 2^24 or more workgroups of 256 threads wraps around - met at
+// |D| > 2^32 with one thread per suffix), so beyond 2^22 workgroups the grid becomes 2-D and kernels number their
+// workgroup with BID; the last row may hold workgroups past nblocks: every kernel bounds-checks what it derives
+// from BID.
+inline dim3 gdim(uint64_t nblocks) {
+  const unsigned gx = 1u << 22;
+  if (nblocks <= gx) return dim3((unsigned)(nblocks ? nblocks : 1));
+  return dim3(gx, (unsigned)((nblocks + gx - 1) / gx));
+}
+#define BID ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x)
+#define GDIM ((uint64_t)gridDim.x * gridDim.y)
 inline uint64_t cdiv64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 inline int bits_for(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b)) b++; return b; }
 

@@ -60,8 +60,9 @@ void build_dictionary_shard(pfp_ctx *c, const StagedText &tx, uint64_t n, int w,
 // multi-GPU: dictionary of a union of word lists; D.pid[u] = id of union word u, occ = sum of weights
 void build_dictionary_words(pfp_ctx *c, const uint8_t *bytes, const uint64_t *wstart, const uint32_t *wlen, uint64_t U,
                             const uint32_t *weight, uint64_t total_bytes, Dictionary &D);
-// dictionary from a reference-format .dict/.occ pair already in device memory
-void dictionary_from_bytes(pfp_ctx *c, Dictionary &D);
+// identity hash of every word of a list (same function the dedup sorts by)
+void hash_word_list(pfp_ctx *c, const uint8_t *bytes, const uint64_t *wstart, const uint32_t *wlen, uint64_t U, uint64_t seed,
+                    uint64_t *d_hash);
 
 // ---------------------------------------------------------------- suffix sorting (sufsort.hip)
 // Index width.  Positions inside the dictionary and slots of its suffix array are `I` = uint32_t while the
@@ -72,7 +73,7 @@ template <class I> struct IdxTraits;
 template <> struct IdxTraits<uint32_t> { using DKey = uint64_t; static constexpr uint32_t kNone = 0xFFFFFFFFu; static constexpr uint32_t kTop = 0x80000000u; };
 template <> struct IdxTraits<uint64_t> { using DKey = unsigned __int128; static constexpr uint64_t kNone = ~0ull; static constexpr uint64_t kTop = 1ull << 63; };
 // true when a dictionary of dsize bytes needs (or PFP_FORCE_IDX64 asks for) the wide build
-inline bool use_wide_index(const pfp_ctx *c, uint64_t dsize) { return c->force_wide || dsize >= 0xFFFFFFF0ull; }
+inline bool use_wide_index(const pfp_ctx *c, uint64_t dsize) { return c->force_wide || dsize >= 0x7FFFFFF0ull; }
 
 template <class I>
 struct SuffixOrderT {

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void dict_index_fill_kernel(uint32_t d, const 
                                                               const uint32_t *__restrict__ wlen, uint64_t dsize,
                                                               uint32_t *__restrict__ pos_word, uint32_t *__restrict__ slen,
                                                               uint64_t *__restrict__ wend) {
-  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
   const uint64_t j = t >> 3;
   const uint32_t l8 = (uint32_t)(t & 7);
   if (j > d) return;
@@ -50,7 +50,7 @@ void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix) {
   ix.slen.alloc(c, N);
   ix.wend.alloc(c, D.d + 1);
   KScope ks(c, "pfp::dict_index_fill_kernel", N * 8);
-  hipLaunchKernelGGL(dict_index_fill_kernel, dim3(cdiv(((uint64_t)D.d + 1) * 8, TB)), dim3(TB), 0, c->stream, (uint32_t)D.d,
+  hipLaunchKernelGGL(dict_index_fill_kernel, gdim(cdiv(((uint64_t)D.d + 1) * 8, TB)), gdim(TB), 0, c->stream, (uint32_t)D.d,
                      D.woff.p, D.wlen.p, N, ix.pos_word.p, ix.slen.p, ix.wend.p);
   PFP_HIP(hipGetLastError());
 }
@@ -59,7 +59,7 @@ void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix) {
 // compaction of the 0x01 bytes, then starts and lengths
 __global__ void words_from_ends_kernel(uint32_t d, const uint64_t *__restrict__ ends, uint64_t dsize, uint64_t *__restrict__ woff,
                                        uint32_t *__restrict__ wlen) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = BID * blockDim.x + threadIdx.x;
   if (j == 0) woff[d] = dsize - 1;
   if (j >= d) return;
   const uint64_t s0 = j ? (uint64_t)ends[j - 1] + 1 : 0;
@@ -73,7 +73,7 @@ void word_table_from_bytes(pfp_ctx *c, Dictionary &D, uint64_t max_words) {
   PFP_REQUIRE(D.d <= max_words, PFP_EFORMAT, "more words in the dictionary bytes than announced");
   D.woff.alloc(c, D.d + 1); D.wlen.alloc(c, std::max<uint64_t>(D.d, 1));
   if (D.d)
-    hipLaunchKernelGGL(words_from_ends_kernel, dim3(cdiv(D.d, TB)), dim3(TB), 0, c->stream, (uint32_t)D.d, ends.p, D.dsize, D.woff.p,
+    hipLaunchKernelGGL(words_from_ends_kernel, gdim(cdiv(D.d, TB)), gdim(TB), 0, c->stream, (uint32_t)D.d, ends.p, D.dsize, D.woff.p,
                        D.wlen.p);
   PFP_HIP(hipGetLastError());
 }
@@ -82,18 +82,18 @@ void word_table_from_bytes(pfp_ctx *c, Dictionary &D, uint64_t max_words) {
 // prefix free), so rank[start of word] is its slot: sorting the d words by that slot gives the
 // order std::sort produces in the reference (newscan.cpp:622-636) without touching all N slots.
 __global__ void iota_u32_kernel(uint32_t d, uint32_t *__restrict__ val) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = BID * blockDim.x + threadIdx.x;
   if (j < d) val[j] = j;
 }
 __global__ void lexrank_from_order_kernel(uint32_t d, const uint32_t *__restrict__ word_sorted, uint32_t *__restrict__ lexrank) {
-  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t r = BID * blockDim.x + threadIdx.x;
   if (r < d) lexrank[word_sorted[r]] = r;
 }
 
 // multi-GPU: every share of the suffix array reported 1 + slot for the words it holds, 0 for the others
 __global__ void combine_word_slots_kernel(uint32_t d, uint32_t parts, const uint64_t *__restrict__ wslot_all,
                                           uint64_t *__restrict__ key, uint32_t *__restrict__ missing) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = BID * blockDim.x + threadIdx.x;
   if (j >= d) return;
   uint64_t v = 0;
   for (uint32_t r = 0; r < parts; r++) { const uint64_t x = wslot_all[(uint64_t)r * d + j]; v = x > v ? x : v; }
@@ -106,11 +106,11 @@ void compute_lexrank_from_slots(pfp_ctx *c, const Dictionary &D, const uint64_t 
   DBuf<uint64_t> key(c, d), keyo(c, d);
   DBuf<uint32_t> val(c, d), valo(c, d), missing(c, 1);
   missing.zero();
-  hipLaunchKernelGGL(combine_word_slots_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, parts, d_wslot_all, key.p, missing.p);
+  hipLaunchKernelGGL(combine_word_slots_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, parts, d_wslot_all, key.p, missing.p);
   PFP_REQUIRE(read_scalar(c, missing.p) == 0, PFP_EFORMAT, "a dictionary word was claimed by no share of the suffix array");
-  hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, val.p);
+  hipLaunchKernelGGL(iota_u32_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, val.p);
   sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
-  hipLaunchKernelGGL(lexrank_from_order_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
+  hipLaunchKernelGGL(lexrank_from_order_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
   PFP_HIP(hipGetLastError());
 }
 
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void slot_output_count_kernel(uint64_t n, cons
                                                                 unsigned long long *__restrict__ total) {
   __shared__ unsigned long long ws[4];
   unsigned long long cnt = 0;
-  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (uint64_t)gridDim.x * 256) {
+  for (uint64_t t = (uint64_t)BID * 256 + threadIdx.x; t < n; t += (uint64_t)GDIM * 256) {
     const I i = sa[t];
     const uint32_t wd = pos_word[i];
     if (wd < d && slen[i] > (uint32_t)w) cnt += wocc[wd];
@@ -138,7 +138,7 @@ uint64_t count_slot_outputs(pfp_ctx *c, const Dictionary &D, const DictIndex &ix
   DBuf<unsigned long long> total(c, 1);
   total.zero();
   if (so.N)
-    hipLaunchKernelGGL(slot_output_count_kernel<I>, dim3((int)std::min<uint64_t>(cdiv64(so.N, 256), (uint64_t)c->n_cu * 16)), dim3(256),
+    hipLaunchKernelGGL(slot_output_count_kernel<I>, gdim((int)std::min<uint64_t>(cdiv64(so.N, 256), (uint64_t)c->n_cu * 16)), gdim(256),
                        0, c->stream, so.N, so.sa.p, ix.pos_word.p, ix.slen.p, D.wocc.p, (uint32_t)D.d, w, total.p);
   PFP_HIP(hipGetLastError());
   PFP_HIP(hipMemcpyAsync(c->h_scalars, total.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -155,9 +155,9 @@ void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrderT<I> &so, DictI
   DBuf<I> key(c, d), keyo(c, d);
   DBuf<uint32_t> val(c, d), valo(c, d);
   gather_ranks<I>(c, so, D.woff.p, d, key.p);
-  hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, val.p);
+  hipLaunchKernelGGL(iota_u32_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, val.p);
   sort_pairs<I, uint32_t>(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
-  hipLaunchKernelGGL(lexrank_from_order_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
+  hipLaunchKernelGGL(lexrank_from_order_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
   PFP_HIP(hipGetLastError());
 }
 template void compute_lexrank<uint32_t>(pfp_ctx *, const Dictionary &, SuffixOrderT<uint32_t> &, DictIndex &);
@@ -171,7 +171,7 @@ __global__ void parse_gather_kernel(uint64_t P, const uint32_t *__restrict__ sa,
                                     const uint8_t *__restrict__ last, const uint64_t *__restrict__ sai,
                                     uint32_t *__restrict__ bwtp, uint8_t *__restrict__ bwlast,
                                     uint64_t *__restrict__ bwsai, uint32_t *__restrict__ jidx) {
-  uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t j = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (j > P) return;
   uint64_t s = sa[j];
   jidx[j] = (uint32_t)j;
@@ -200,7 +200,7 @@ void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t 
   out.bwlast.alloc(c, P + 1);
   if (sai) out.bwsai.alloc(c, P + 1);
   DBuf<uint32_t> bwtp(c, P + 1), bwtp_s(c, P + 1), jidx(c, P + 1);
-  hipLaunchKernelGGL(parse_gather_kernel, dim3(cdiv(P + 1, TB)), dim3(TB), 0, c->stream, P, so.sa.p, sym.p, last, sai,
+  hipLaunchKernelGGL(parse_gather_kernel, gdim(cdiv(P + 1, TB)), gdim(TB), 0, c->stream, P, so.sa.p, sym.p, last, sai,
                      bwtp.p, out.bwlast.p, sai ? out.bwsai.p : (uint64_t *)nullptr, jidx.p);
   // bwtparse.c:281-303: positions grouped by symbol, ascending inside a group == stable sort
   sort_pairs_u32_u32(c, bwtp.p, bwtp_s.p, jidx.p, out.ilist.p, P + 1, 0, bits_for(d));
@@ -222,7 +222,7 @@ template <class REC>
 __global__ void pprec_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t d, int w,
                              const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ slen,
                              const uint32_t *__restrict__ wocc, REC *__restrict__ pp) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i >= N) return;
   uint32_t wd = pos_word[i];
   bool valid = wd < d && slen[i] > (uint32_t)w;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const I *_
                                                           const uint32_t *__restrict__ wistart,
                                                           uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc,
                                                           uint32_t *__restrict__ ist) {
-  uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  uint64_t t0 = ((uint64_t)BID * 256 + threadIdx.x) * 8;
   if (t0 >= N) return;
   I idx[8];
   uint32_t c8[8], p8[8], w8[8];
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const I *
                                                            const uint32_t *__restrict__ slen,
                                                            const uint32_t *__restrict__ wocc, uint32_t d, int w,
                                                            uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc) {
-  uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  uint64_t t0 = ((uint64_t)BID * 256 + threadIdx.x) * 8;
   if (t0 >= N) return;
   uint32_t c8[8], p8[8];
   const int nk = (N - t0) >= 8 ? 8 : (int)(N - t0);
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const I *
 template <class I>
 __global__ void group_flags_kernel(uint64_t N, const I *__restrict__ grp, const uint8_t *__restrict__ pc,
                                    int any_multi_is_hard, uint8_t *__restrict__ hard) {
-  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (t >= N || pc[t] == 0) return;
   I g = grp[t];
   if (g == t) return;
@@ -345,13 +345,13 @@ enum : int { SA_NONE = 0, SA_DENSE = 1, SA_SPARSE = 2 };
 
 template <class I>
 __global__ void gather_idx_kernel(uint64_t n, const I *__restrict__ idx, const I *__restrict__ src, I *__restrict__ dst) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
 }
 __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank, const uint32_t *__restrict__ istart_lex,
                                const uint32_t *__restrict__ wocc, const uint32_t *__restrict__ ilist,
                                uint32_t *__restrict__ wistart, uint32_t *__restrict__ wfirst, uint32_t *__restrict__ wlast) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = BID * blockDim.x + threadIdx.x;
   if (j >= d) return;
   const uint32_t st = istart_lex[lexrank[j]] + 1;   // +1: ilist[0] is the EOS symbol (pfbwt.cpp:389)
   wistart[j] = st;
@@ -419,7 +419,7 @@ __device__ __forceinline__ void expand_stage(const MergeArgsT<I> &a, ExpandLds &
       if (a.hard[g]) {
         cls = CLS_HARD;
         ch = a.gmaj ? a.gmaj[g] : 0;      // the group's majority char (minority path) or 0 (every position written later)
-      } else if (a.want_sa == SA_SPARSE && (g != (I)t || (t + 1 < a.N && a.grp[t + 1] == (I)t))) cls = CLS_MULTI;
+      }
     }
     L.lpc[s] = ch;
     L.lcls[s] = cls;
@@ -428,12 +428,9 @@ __device__ __forceinline__ void expand_stage(const MergeArgsT<I> &a, ExpandLds &
 }
 
 // 16 output bytes starting at block-relative offset x0 (< Ltot)
-// cmp (sparse SA mode): the same 16 chars for neighbour comparisons, 0x01 where the char is not known here
-// (hard group, past the end) - 0x01 is no BWT char, so such a neighbour always counts as "different"
 template <class I>
 __device__ __forceinline__ void expand_16(const MergeArgsT<I> &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
-                                          uint64_t x0, uint64_t Ltot, uint4 *cmp = nullptr) {
-  if (cmp) *cmp = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+                                          uint64_t x0, uint64_t Ltot) {
   if (base + x0 + 16 <= a.out_lo || base + x0 >= a.out_hi) return;     // outside this rank's slice
   int lo = 0, hi = ns;                    // loff[lo] <= x0 < loff[hi]
   while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (L.loff[mid] <= x0) lo = mid; else hi = mid; }
@@ -441,7 +438,6 @@ __device__ __forceinline__ void expand_16(const MergeArgsT<I> &a, const ExpandLd
   uint64_t nxt = L.loff[s + 1];
   const int nb = (Ltot - x0) >= 16 ? 16 : (int)(Ltot - x0);
   uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-  uint32_t hm = 0;       // positions whose char is decided elsewhere (hard groups)
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     if (k < nb) {
@@ -456,18 +452,10 @@ __device__ __forceinline__ void expand_16(const MergeArgsT<I> &a, const ExpandLd
         ch = a.bwlast[pos];
       } else {      // CLS_HARD: the group's majority char (its other occurrences are placed by hard_minor_kernel), or 0 and
         ch = L.lpc[s];      // every position of the group is written by the hard-group kernels that run after this one
-        hm |= 1u << k;
       }
       const uint32_t sh = (uint32_t)ch << (8 * (k & 3));
       if (k < 4) r0 |= sh; else if (k < 8) r1 |= sh; else if (k < 12) r2 |= sh; else r3 |= sh;
-    } else hm |= 1u << k;
-  }
-  if (cmp) {
-    uint32_t c4[4] = {r0, r1, r2, r3};
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-      if ((hm >> k) & 1u) c4[k >> 2] = (c4[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (0x01u << (8 * (k & 3)));
-    *cmp = make_uint4(c4[0], c4[1], c4[2], c4[3]);
+    }
   }
   uint8_t *dst = a.bwt + base + x0;
   if (nb == 16 && base + x0 >= a.out_lo && base + x0 + 16 <= a.out_hi) st16u(dst, make_uint4(r0, r1, r2, r3));
@@ -489,65 +477,49 @@ __device__ __forceinline__ void expand_sa_1(const MergeArgsT<I> &a, const Expand
   int lo = 0, hi = ns;                    // loff[lo] <= x < loff[hi]
   while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (L.loff[mid] <= x) lo = mid; else hi = mid; }
   const uint8_t cl = L.lcls[lo];
-  if (cl != CLS_FILL && cl != CLS_FULL) return;
+  if (cl != CLS_FULL && (cl != CLS_FILL || a.want_sa == SA_SPARSE)) return;
   const I i = a.sa[t0 + lo];
   const uint64_t pos = a.ilist[slot_ist(a, t0 + lo) + (uint32_t)(x - L.loff[lo])];
   a.out_sa[base + x] = (cl == CLS_FULL && a.pos_base + base + x == 0) ? a.n_out_global - 1
                                                                       : a.bwsai[pos] - (uint64_t)a.slen[i];
 }
 
-// Sparse SA mode: which of the 16 positions starting at x0 can be a run boundary of the BWT, judged from their
-// own chars (cmp form) and the two neighbours' (0x01 = unknown, counts as different); SA values are written for
-// those only.  Fill / full-word entries here; groups of several words by group_edges_kernel / the hard-group kernels.
-template <class I>
-__device__ __forceinline__ void expand_sa_sparse16(const MergeArgsT<I> &a, const ExpandLds &L, uint64_t t0, int ns, uint64_t base,
-                                                   uint64_t x0, uint64_t Ltot, uint4 cmp, uint32_t left, uint32_t right) {
-  const uint32_t c4[4] = {cmp.x, cmp.y, cmp.z, cmp.w};
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    if (x0 + k >= Ltot) break;
-    const uint32_t c = (c4[k >> 2] >> (8 * (k & 3))) & 0xffu;
-    if (c == 0x01u) continue;
-    const uint32_t l = k ? (c4[(k - 1) >> 2] >> (8 * ((k - 1) & 3))) & 0xffu : left;
-    const uint32_t r = k < 15 ? (c4[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xffu : right;
-    const uint64_t gx = base + x0 + k;
-    if (c != l || c != r || gx == a.out_lo || gx + 1 == a.out_hi) expand_sa_1(a, L, t0, ns, base, x0 + k);
-  }
-}
-
+// Sparse SA mode (-s / -e without -S): SA values are only looked at where a run of the BWT starts or ends.
+//   * a whole word's occurrences carry unrelated chars (bwlast): all their SA values are written here, by the
+//     workgroup that expands them (P positions in all);
+//   * a slot, or a group of slots, whose chars all agree fills its range with one char: only the first and
+//     the last position of that range can be run boundaries - unit_edges_kernel;
+//   * hard groups: the two ends (unit_edges_kernel) and what the hard-group kernels find inside.
 template <class I, int SPARSE>
 __global__ __launch_bounds__(256) void expand_kernel(MergeArgsT<I> a, uint32_t *__restrict__ heavy, uint32_t *__restrict__ nheavy,
                                                      uint32_t heavy_cap) {
   __shared__ ExpandLds L;
-  __shared__ uint32_t lch[SPARSE ? 256 * 4 : 1];      // compare-form chars of the 4 KiB the workgroup has just produced
-  const uint64_t t0 = (uint64_t)blockIdx.x * kSlots;
+  __shared__ uint32_t nfull, fulls[SPARSE ? kSlots : 1];
+  const uint64_t t0 = (uint64_t)BID * kSlots;
+  if (t0 >= a.N) return;      // a workgroup of the padded last grid row
   const int ns = (a.N - t0) >= (uint64_t)kSlots ? kSlots : (int)(a.N - t0);
   const uint64_t base = slot_off(a, t0);
+  if (SPARSE && threadIdx.x == 0) nfull = 0;
   expand_stage(a, L, t0, ns, base);
   const uint64_t Ltot = L.loff[ns];
   if (base + Ltot <= a.out_lo || base >= a.out_hi) return;
   // a block whose slots emit more than the quota (a word with hundreds of thousands of
   // occurrences) finishes only its first quota here; expand_heavy_kernel shares the rest
   const uint64_t mine = Ltot <= kExpandQuota ? Ltot : kExpandQuota;
-  if (Ltot > kExpandQuota && threadIdx.x == 0) { uint32_t i = atomicAdd(nheavy, 1u); if (i < heavy_cap) heavy[i] = blockIdx.x; }
+  if (Ltot > kExpandQuota && threadIdx.x == 0) { uint32_t i = atomicAdd(nheavy, 1u); if (i < heavy_cap) heavy[i] = BID; }
+  for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < mine; x0 += 256 * 16) expand_16(a, L, t0, ns, base, x0, Ltot);
   if (SPARSE) {
-    for (uint64_t c0 = 0; c0 < mine; c0 += 256 * 16) {      // every thread runs every iteration: barriers inside
-      const uint64_t x0 = c0 + (uint64_t)threadIdx.x * 16;
-      uint4 cmp = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-      if (x0 < mine) expand_16(a, L, t0, ns, base, x0, mine, &cmp);      // chars past `mine` belong to expand_heavy_kernel: unknown here
-      __syncthreads();
-      *reinterpret_cast<uint4 *>(&lch[threadIdx.x * 4]) = cmp;
-      __syncthreads();
-      if (x0 < mine) {
-        const uint32_t left = threadIdx.x ? lch[threadIdx.x * 4 - 1] >> 24 : 0x01u;
-        const uint32_t right = threadIdx.x < 255 ? lch[threadIdx.x * 4 + 4] & 0xffu : 0x01u;
-        expand_sa_sparse16(a, L, t0, ns, base, x0, mine, cmp, left, right);
-      }
+    for (int s = threadIdx.x; s < ns; s += 256)
+      if (L.lcls[s] == CLS_FULL) fulls[atomicAdd(&nfull, 1u)] = (uint32_t)s;
+    __syncthreads();
+    const uint32_t nf = nfull;
+    for (uint32_t q = 0; q < nf; q++) {
+      const int sl = (int)fulls[q];
+      const uint64_t e = L.loff[sl + 1] < mine ? L.loff[sl + 1] : mine;
+      for (uint64_t x = L.loff[sl] + threadIdx.x; x < e; x += 256) expand_sa_1(a, L, t0, ns, base, x);
     }
-  } else {
-    for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < mine; x0 += 256 * 16) expand_16(a, L, t0, ns, base, x0, Ltot);
-    if (a.want_sa)
-      for (uint64_t x = threadIdx.x; x < mine; x += 256) expand_sa_1(a, L, t0, ns, base, x);
+  } else if (a.want_sa) {
+    for (uint64_t x = threadIdx.x; x < mine; x += 256) expand_sa_1(a, L, t0, ns, base, x);
   }
 }
 
@@ -561,41 +533,109 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgsT<I> a, cons
     __syncthreads();
     expand_stage(a, L, t0, ns, base);
     const uint64_t Ltot = L.loff[ns];
-    for (uint64_t x0 = kExpandQuota + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; x0 < Ltot; x0 += (uint64_t)gridDim.x * 256 * 16) {
-      uint4 cmp;
-      expand_16(a, L, t0, ns, base, x0, Ltot, a.want_sa == SA_SPARSE ? &cmp : (uint4 *)nullptr);
-      // sparse SA: the neighbours outside these 16 positions are not looked at - both ends count as boundaries
-      if (a.want_sa == SA_SPARSE) expand_sa_sparse16(a, L, t0, ns, base, x0, Ltot, cmp, 0x01u, 0x01u);
-    }
-    if (a.want_sa == SA_DENSE)
-      for (uint64_t x = kExpandQuota + (uint64_t)blockIdx.x * 256 + threadIdx.x; x < Ltot; x += (uint64_t)gridDim.x * 256)
+    for (uint64_t x0 = kExpandQuota + ((uint64_t)BID * 256 + threadIdx.x) * 16; x0 < Ltot; x0 += (uint64_t)GDIM * 256 * 16)
+      expand_16(a, L, t0, ns, base, x0, Ltot);
+    if (a.want_sa)      // sparse mode: expand_sa_1 writes for full-word slots only (other classes come from unit_edges_kernel)
+      for (uint64_t x = kExpandQuota + (uint64_t)BID * 256 + threadIdx.x; x < Ltot; x += (uint64_t)GDIM * 256)
         expand_sa_1(a, L, t0, ns, base, x);
   }
 }
 
-// Sparse SA mode: a group of several words whose chars all agree fills its range with one char, so only its first
-// and its last position can be run boundaries.  The first position belongs to the smallest BWT(P) position over
-// the members' inverted lists, the last one to the largest (wfirst / wlast per word): O(members) per group
-// instead of merging the lists.  Hard groups get the same two values here (their interior comes from the
-// hard-group kernels).  Thread = slot; group heads do the work.
+// Sparse SA mode.  A *unit* is a slot that emits, or a group of slots of equal suffixes (several words share the
+// suffix): its output range is one fill char c (unknown for hard groups), so a run of the BWT can start only at
+// the unit's first position - when the unit before ends in a different char - and end only at its last position.
+// The first position belongs to the smallest BWT(P) position over the members' inverted lists, the last one to the
+// largest (wfirst / wlast per word): O(members) per unit instead of merging the lists (pfbwt.cpp:605-676 walks a
+// heap through all of them).  One lane per slot: chars of the neighbouring units by ballot, "needed" flags spread
+// over a unit's lanes, segmented min / max by shuffles; a unit that crosses the wave is finished serially by
+// its first (last) lane.
 template <class I>
-__global__ __launch_bounds__(256) void group_edges_kernel(MergeArgsT<I> a) {
-  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t + 1 >= a.N) return;
-  const uint8_t ch = a.pc[t];
-  if (ch == 0 || ch == kEndOfWord) return;
-  if (a.grp[t] != (I)t || a.grp[t + 1] != (I)t) return;      // not the head of a group of several words
-  uint32_t mn = 0xFFFFFFFFu, mx = 0;
-  uint64_t m = t;
-  for (; m < a.N && a.grp[m] == (I)t; m++) {
-    const uint32_t wd = a.pos_word[a.sa[m]];
-    const uint32_t f = a.wfirst[wd], l = a.wlast[wd];
-    mn = f < mn ? f : mn; mx = l > mx ? l : mx;
+__device__ __forceinline__ uint32_t unit_char_of_slot(const MergeArgsT<I> &a, uint64_t t) {      // 0x100: unknown
+  const uint32_t c = a.pc[t];
+  if (c == 0) return 0x200u;                       // emits nothing
+  if (c == kEndOfWord) return 0x100u;
+  if (a.hard[a.grp[t]]) return 0x100u;
+  return fix_char((uint8_t)c);
+}
+template <class I>
+__global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
+  const uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const uint64_t wbase = t - lane;
+  const bool in = t < a.N;
+  const uint32_t ch = in ? a.pc[t] : 0u;
+  const bool emit = ch != 0, full = ch == kEndOfWord;
+  uint64_t g = t;
+  bool hd = false;
+  if (emit && !full) { g = a.grp[t]; hd = a.hard[g] != 0; }
+  const bool unit = emit && !full;                 // lanes that belong to a fill / hard unit
+  const uint32_t cu = (!emit) ? 0x200u : ((full || hd) ? 0x100u : (uint32_t)fix_char((uint8_t)ch));
+  const unsigned long long em = __ballot(emit);
+  // same unit as the next slot?
+  const uint64_t g_next = __shfl_down(g, 1, 64);
+  const bool emit_next = (em >> ((lane + 1) & 63)) & 1ull;
+  bool cont;                                       // the unit goes on in slot t + 1
+  if (lane < 63) cont = unit && emit_next && g_next == g;
+  else cont = unit && t + 1 < a.N && a.pc[t + 1] != 0 && a.pc[t + 1] != kEndOfWord && a.grp[t + 1] == (I)g;
+  const bool head = unit && g == t;
+  const bool last = unit && !cont;
+  // char of the emitting slot before / after (by lane; outside the wave: bounded walk)
+  const unsigned long long below = em & ((1ull << lane) - 1ull), above = lane < 63 ? em & ~((2ull << lane) - 1ull) : 0ull;
+  const int pl = below ? 63 - __clzll((long long)below) : lane, nl = above ? __ffsll((long long)above) - 1 : lane;
+  uint32_t prevc = __shfl(cu, pl, 64), nextc = __shfl(cu, nl, 64);
+  if (head && !below) {
+    prevc = 0x100u;
+    for (uint64_t tt = t, steps = 0; tt > 0 && steps < 64; steps++) { tt--; const uint32_t c = unit_char_of_slot(a, tt); if (c != 0x200u) { prevc = c; break; } }
   }
-  const uint64_t lo = slot_off(a, t), hi = slot_off(a, m);      // the group's output range [lo, hi)
-  const uint64_t sl = a.slen[a.sa[t]];
-  if (lo >= a.out_lo && lo < a.out_hi) a.out_sa[lo] = a.bwsai[mn] - sl;
-  if (hi - 1 >= a.out_lo && hi - 1 < a.out_hi) a.out_sa[hi - 1] = a.bwsai[mx] - sl;
+  if (last && !above) {
+    nextc = 0x100u;
+    for (uint64_t tt = t + 1, steps = 0; tt < a.N && steps < 64; tt++, steps++) { const uint32_t c = unit_char_of_slot(a, tt); if (c != 0x200u) { nextc = c; break; } }
+  }
+  const bool need_first = head && (hd || prevc != cu || prevc == 0x100u);
+  const bool need_last = last && (hd || nextc != cu || nextc == 0x100u);
+  // spread the two flags over the lanes of the unit that lie in this wave
+  const bool head_here = unit && g >= wbase;
+  const int hl = head_here ? (int)(g - wbase) : lane;
+  const unsigned long long lastmask = __ballot(last);
+  const unsigned long long lm = lastmask >> lane;
+  const int ll = lm ? lane + (__ffsll((long long)lm) - 1) : lane;
+  const bool nf = __shfl((int)need_first, hl, 64) != 0 && head_here;
+  const bool nlz = __shfl((int)need_last, ll, 64) != 0 && unit && lm != 0;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  I myi = 0;
+  if (unit && (nf || nlz)) {
+    myi = a.sa[t];
+    const uint32_t wd = a.pos_word[myi];
+    if (nf) mn = a.wfirst[wd];
+    if (nlz) mx = a.wlast[wd];
+  }
+  // segmented reductions: min towards the first lane of the unit, max towards its last lane
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t omn = __shfl_down(mn, o, 64);
+    const uint64_t og = __shfl_down(g, o, 64);
+    const int ou = __shfl_down((int)unit, o, 64);
+    if (lane + o < 64 && unit && ou && og == g) mn = omn < mn ? omn : mn;
+    const uint32_t umx = __shfl_up(mx, o, 64);
+    const uint64_t ug = __shfl_up(g, o, 64);
+    const int uu = __shfl_up((int)unit, o, 64);
+    if (lane >= o && unit && uu && ug == g) mx = umx > mx ? umx : mx;
+  }
+  // (shuffles above must be executed by every lane: the two serial extensions below are lane-local)
+  const uint64_t g63 = __shfl(g, 63, 64);
+  const bool cont63 = __shfl((int)cont, 63, 64) != 0;
+  if (need_first) {
+    if (cont63 && g63 == g)
+      for (uint64_t m = wbase + 64; m < a.N && a.grp[m] == (I)g; m++) { const uint32_t f = a.wfirst[a.pos_word[a.sa[m]]]; mn = f < mn ? f : mn; }
+    const uint64_t o = slot_off(a, t);
+    if (o >= a.out_lo && o < a.out_hi) a.out_sa[o] = a.bwsai[mn] - (uint64_t)a.slen[myi];
+  }
+  if (need_last) {
+    if (g < wbase)
+      for (uint64_t m = wbase; m-- > g;) { const uint32_t l = a.wlast[a.pos_word[a.sa[m]]]; mx = l > mx ? l : mx; }
+    const uint64_t o = slot_off(a, t + 1) - 1;
+    if (o >= a.out_lo && o < a.out_hi) a.out_sa[o] = a.bwsai[mx] - (uint64_t)a.slen[myi];
+  }
 }
 
 // Hard groups, BWT-only and sparse-SA modes: majority fill + minority placement.  The members of a group of equal
@@ -614,7 +654,7 @@ __global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, con
                                                             uint8_t *__restrict__ gmaj, HardGroupInfo *__restrict__ info,
                                                             uint32_t *__restrict__ minor_cnt, uint8_t *__restrict__ fallback,
                                                             unsigned long long *__restrict__ chars_total) {
-  const uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t h = (uint64_t)BID * 256 + threadIdx.x;
   unsigned long long mychars = 0;
   if (h < nH) {
   const uint64_t g = heads[h];
@@ -666,7 +706,7 @@ template <class I>
 __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const HardGroupInfo *__restrict__ info, uint64_t nH,
                                                          const uint64_t *__restrict__ minor_off, uint64_t total,
                                                          const uint8_t *__restrict__ gmaj) {
-  for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (uint64_t)gridDim.x * 256) {
+  for (uint64_t q = (uint64_t)BID * 256 + threadIdx.x; q < total; q += (uint64_t)GDIM * 256) {
     uint64_t lo = 0, hi = nH;               // minor_off[lo] <= q < minor_off[hi]
     while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (minor_off[mid] <= q) lo = mid; else hi = mid; }
     const HardGroupInfo gi = info[lo];
@@ -772,7 +812,7 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgsT<I> a, const
   const uint64_t nH = *nheads_p;
   const uint64_t nbatch = (nH + 63) / 64;
   unsigned long long my_chars = 0, my_groups = 0;
-  for (uint64_t b = blockIdx.x * 4 + wv; b < nbatch; b += gridDim.x * 4) {
+  for (uint64_t b = BID * 4 + wv; b < nbatch; b += GDIM * 4) {
     // ---- A: one group per lane
     const uint64_t hidx = b * 64 + lane;
     uint64_t g = 0, base = 0;
@@ -888,7 +928,7 @@ __global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgsT<I> a, const B
   __shared__ uint64_t skey[4][kHardLds];       // (position << 16 | occurrence index)
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint64_t *K = skey[wv];
-  for (uint32_t qi = blockIdx.x * 4 + wv; qi < nmid; qi += gridDim.x * 4) {
+  for (uint32_t qi = BID * 4 + wv; qi < nmid; qi += GDIM * 4) {
     const uint64_t g = mid[qi].g;
     const uint32_t E = (uint32_t)mid[qi].E, k = mid[qi].k;
     const uint64_t base = slot_off(a, g);
@@ -934,7 +974,7 @@ __global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgsT<I> a, const B
 template <class I>
 __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgsT<I> a, const BigGroup *__restrict__ big, uint32_t nbig,
                                                        const uint64_t *__restrict__ estart, uint64_t total) {
-  for (uint64_t ge = (uint64_t)blockIdx.x * 256 + threadIdx.x; ge < total; ge += (uint64_t)gridDim.x * 256) {
+  for (uint64_t ge = (uint64_t)BID * 256 + threadIdx.x; ge < total; ge += (uint64_t)GDIM * 256) {
     uint32_t lo = 0, hi = nbig;               // estart[lo] <= ge < estart[hi]
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (estart[mid] <= ge) lo = mid; else hi = mid; }
     const uint64_t g = big[lo].g, e = ge - estart[lo];
@@ -964,7 +1004,8 @@ __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgsT<I> a, const Bi
 __global__ __launch_bounds__(256) void slot_loc_kernel(const uint32_t *__restrict__ cnt, uint64_t N, uint32_t *__restrict__ loc,
                                                        uint64_t *__restrict__ tsum, uint32_t *__restrict__ overflow) {
   __shared__ uint64_t ws[4];
-  const uint64_t t0 = ((uint64_t)blockIdx.x << kOffTileLog) + (uint64_t)threadIdx.x * 8;
+  if (((uint64_t)BID << kOffTileLog) > N) return;      // tiles 0 .. N >> 11 exist (a workgroup of the padded last grid row)
+  const uint64_t t0 = ((uint64_t)BID << kOffTileLog) + (uint64_t)threadIdx.x * 8;
   uint32_t v[8];
   if (t0 + 8 <= N) {
     const uint4 x = *reinterpret_cast<const uint4 *>(cnt + t0), y = *reinterpret_cast<const uint4 *>(cnt + t0 + 4);
@@ -986,7 +1027,7 @@ __global__ __launch_bounds__(256) void slot_loc_kernel(const uint32_t *__restric
   *reinterpret_cast<uint4 *>(loc + t0) = make_uint4(o8[0], o8[1], o8[2], o8[3]);
   *reinterpret_cast<uint4 *>(loc + t0 + 4) = make_uint4(o8[4], o8[5], o8[6], o8[7]);
   if (threadIdx.x == 255) {
-    tsum[blockIdx.x] = run;
+    tsum[BID] = run;
     if (run >> 32) atomicOr(overflow, 1u);      // a tile's offsets would not fit 32 bits
   }
 }
@@ -1011,7 +1052,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   const bool dense = samode == SA_DENSE;
   DBuf<uint32_t> wfirst, wlast;
   if (samode == SA_SPARSE) { wfirst.alloc(c, d); wlast.alloc(c, d); }
-  hipLaunchKernelGGL(wistart_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, D.wocc.p, pb.ilist.p,
+  hipLaunchKernelGGL(wistart_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, D.wocc.p, pb.ilist.p,
                      wistart.p, wfirst.p, wlast.p);
   DBuf<uint16_t> pp16;
   DBuf<uint64_t> pp64;
@@ -1028,29 +1069,29 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   hard.zero();
   if (from_keys) {
     KScope ks(c, "pfp::slot_gather_kernel", N * (8 + 1 + 5));
-    hipLaunchKernelGGL(slot_payload_kernel<I>, dim3(cdiv(cdiv64(N, 8), 256)), dim3(256), 0, c->stream, N, so.sa.p, so.skeys.p,
+    hipLaunchKernelGGL(slot_payload_kernel<I>, gdim(cdiv(cdiv64(N, 8), 256)), gdim(256), 0, c->stream, N, so.sa.p, so.skeys.p,
                        so.refined.p, D.bytes.p, ix.pos_word.p, ix.slen.p, D.wocc.p, d, w, cnt.p, pc.p);
   } else {
   { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + (dense ? 8 : 2)));
-    if (dense) hipLaunchKernelGGL(pprec_kernel<uint64_t>, dim3(cdiv(NP, TB)), dim3(TB), 0, c->stream, D.bytes.p, NP, d, w,
+    if (dense) hipLaunchKernelGGL(pprec_kernel<uint64_t>, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, D.bytes.p, NP, d, w,
                                   ix.pos_word.p, ix.slen.p, D.wocc.p, pp64.p);
-    else hipLaunchKernelGGL(pprec_kernel<uint16_t>, dim3(cdiv(NP, TB)), dim3(TB), 0, c->stream, D.bytes.p, NP, d, w,
+    else hipLaunchKernelGGL(pprec_kernel<uint16_t>, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, D.bytes.p, NP, d, w,
                             ix.pos_word.p, ix.slen.p, D.wocc.p, pp16.p); }
   { KScope ks(c, "pfp::slot_gather_kernel", N * (sizeof(I) + 5 + (dense ? 12 : 2)));
-    const dim3 grid(cdiv(cdiv64(N, 8), 256));
-    if (dense) hipLaunchKernelGGL((slot_gather_kernel<uint64_t, I>), grid, dim3(256), 0, c->stream, N, so.sa.p, pp64.p,
+    const dim3 grid = gdim(cdiv(cdiv64(N, 8), 256));
+    if (dense) hipLaunchKernelGGL((slot_gather_kernel<uint64_t, I>), grid, gdim(256), 0, c->stream, N, so.sa.p, pp64.p,
                                   ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, ist.p);
-    else hipLaunchKernelGGL((slot_gather_kernel<uint16_t, I>), grid, dim3(256), 0, c->stream, N, so.sa.p, pp16.p,
+    else hipLaunchKernelGGL((slot_gather_kernel<uint16_t, I>), grid, gdim(256), 0, c->stream, N, so.sa.p, pp16.p,
                             ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, (uint32_t *)nullptr); }
   }
   pp16.release(); pp64.release();
   ovf.zero();
   PFP_HIP(hipMemsetAsync(tsum.p + ntile, 0, 8, c->stream));
   { KScope ks(c, "pfp::slot_loc_kernel", N * 8);
-    hipLaunchKernelGGL(slot_loc_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, cnt.p, N, loc.p, tsum.p, ovf.p); }
+    hipLaunchKernelGGL(slot_loc_kernel, gdim((unsigned)ntile), gdim(256), 0, c->stream, cnt.p, N, loc.p, tsum.p, ovf.p); }
   exclusive_sum_u64(c, tsum.p, tbase.p, ntile + 1);
   { KScope ks(c, "pfp::group_flags_kernel", N * 5);
-  hipLaunchKernelGGL(group_flags_kernel<I>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, so.grp.p, pc.p, dense ? 1 : 0, hard.p); }
+  hipLaunchKernelGGL(group_flags_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, so.grp.p, pc.p, dense ? 1 : 0, hard.p); }
   PFP_REQUIRE(read_scalar(c, ovf.p) == 0, PFP_ELIMIT, "2048 consecutive suffix-array slots emit 2^32 or more BWT positions");
   const uint64_t n_out = read_scalar(c, tbase.p + ntile);
   PFP_REQUIRE(expect_n_out == 0 || n_out == expect_n_out, PFP_EFORMAT,
@@ -1097,7 +1138,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     PFP_HIP(hipMemsetAsync(minor_cnt.p + n_heads, 0, 4, c->stream));
     a.gmaj = gmaj.p;
     { KScope ks(c, "pfp::hard_classify_kernel", n_heads * 40);
-      hipLaunchKernelGGL(hard_classify_kernel<I>, dim3(cdiv(n_heads, 256)), dim3(256), 0, c->stream, a, heads.p, n_heads, gmaj.p,
+      hipLaunchKernelGGL(hard_classify_kernel<I>, gdim(cdiv(n_heads, 256)), gdim(256), 0, c->stream, a, heads.p, n_heads, gmaj.p,
                          ginfo.p, minor_cnt.p, fallback.p, mstat.p); }
     exclusive_sum_u32_u64(c, minor_cnt.p, minor_off.p, n_heads + 1);
     n_fallback = count_flags(c, fallback.p, n_heads);
@@ -1106,7 +1147,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     {  // heads of the fallback groups = heads[] where fallback[] is set
       DBuf<I> fidx(c, n_fallback + 1);
       select_index<I>(c, fallback.p, fidx.p, nheads.p + 1, n_heads);
-      if (n_fallback) hipLaunchKernelGGL(gather_idx_kernel<I>, dim3(cdiv(n_fallback, 256)), dim3(256), 0, c->stream, n_fallback, fidx.p,
+      if (n_fallback) hipLaunchKernelGGL(gather_idx_kernel<I>, gdim(cdiv(n_fallback, 256)), gdim(256), 0, c->stream, n_fallback, fidx.p,
                                          heads.p, fb_heads.p);
       PFP_HIP(hipGetLastError());
       sync(c);
@@ -1118,26 +1159,26 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     DBuf<uint32_t> heavy(c, nblk), nheavy(c, 1);
     nheavy.zero();
     { KScope ks(c, "pfp::expand_kernel", N * 14 + n_out * (dense ? 17 : 1));
-    if (samode == SA_SPARSE) hipLaunchKernelGGL((expand_kernel<I, 1>), dim3(nblk), dim3(256), 0, c->stream, a, heavy.p, nheavy.p, nblk);
-    else hipLaunchKernelGGL((expand_kernel<I, 0>), dim3(nblk), dim3(256), 0, c->stream, a, heavy.p, nheavy.p, nblk); }
+    if (samode == SA_SPARSE) hipLaunchKernelGGL((expand_kernel<I, 1>), gdim(nblk), gdim(256), 0, c->stream, a, heavy.p, nheavy.p, nblk);
+    else hipLaunchKernelGGL((expand_kernel<I, 0>), gdim(nblk), gdim(256), 0, c->stream, a, heavy.p, nheavy.p, nblk); }
     const uint32_t nh = read_scalar(c, nheavy.p);
     KScope ks2(c, "pfp::expand_heavy_kernel", 0);   // bytes are accounted in expand_kernel's n_out term
-    if (nh) hipLaunchKernelGGL(expand_heavy_kernel<I>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, heavy.p, nh);
+    if (nh) hipLaunchKernelGGL(expand_heavy_kernel<I>, gdim(c->n_cu * 4), gdim(256), 0, c->stream, a, heavy.p, nh);
   }
   if (samode == SA_SPARSE) {
-    KScope ks(c, "pfp::group_edges_kernel", N * 5);
-    hipLaunchKernelGGL(group_edges_kernel<I>, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, a);
+    KScope ks(c, "pfp::unit_edges_kernel", N * (1 + sizeof(I) * 2 + 4));
+    hipLaunchKernelGGL(unit_edges_kernel<I>, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, a);
   }
   if (n_minor) {
     KScope ks(c, "pfp::hard_minor_kernel", n_minor * 64);
-    hipLaunchKernelGGL(hard_minor_kernel<I>, dim3((unsigned)std::min<uint64_t>(cdiv64(n_minor, 256), (uint64_t)c->n_cu * 64)), dim3(256), 0,
+    hipLaunchKernelGGL(hard_minor_kernel<I>, gdim((unsigned)std::min<uint64_t>(cdiv64(n_minor, 256), (uint64_t)c->n_cu * 64)), gdim(256), 0,
                        c->stream, a, ginfo.p, n_heads, minor_off.p, n_minor, gmaj.p);
   }
   PFP_HIP(hipGetLastError());
   for (;;) {
     if (!n_fallback) { PFP_HIP(hipMemsetAsync(hstats.p, 0, 40, c->stream)); }
     else { KScope ks(c, "pfp::hard_groups_kernel", N * 5);
-      hipLaunchKernelGGL(hard_groups_kernel<I>, dim3(c->n_cu * 8), dim3(256), 0, c->stream, a, hard_list, hard_list_n, hstats.p, big.p,
+      hipLaunchKernelGGL(hard_groups_kernel<I>, gdim(c->n_cu * 8), gdim(256), 0, c->stream, a, hard_list, hard_list_n, hstats.p, big.p,
                          big_cap, mid.p, mid_cap); }
     PFP_HIP(hipGetLastError());
     PFP_HIP(hipMemcpyAsync(c->h_scalars, hstats.p, 40, hipMemcpyDeviceToHost, c->stream));
@@ -1158,7 +1199,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   const uint32_t nbig = (uint32_t)c->h_scalars[2];
   if (nmid) {
     KScope ks(c, "pfp::hard_sort_kernel", (uint64_t)nmid * (kHardSortMin + 1) * (samode ? 21 : 5));      // lower bound: ilist entry + char (+ SA) per occurrence
-    hipLaunchKernelGGL(hard_sort_kernel<I>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, a, mid.p, nmid);
+    hipLaunchKernelGGL(hard_sort_kernel<I>, gdim(c->n_cu * 4), gdim(256), 0, c->stream, a, mid.p, nmid);
     PFP_HIP(hipGetLastError());
   }
   if (nbig) {
@@ -1172,7 +1213,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     PFP_HIP(hipMemcpyAsync(estart.p, es.data(), (nbig + 1) * 8, hipMemcpyHostToDevice, c->stream));
     const uint64_t total = es[nbig];
     const int nb = (int)std::min<uint64_t>(cdiv64(total, 256), (uint64_t)c->n_cu * 32);
-    hipLaunchKernelGGL(hard_big_kernel<I>, dim3(nb), dim3(256), 0, c->stream, a, big.p, nbig, estart.p, total);
+    hipLaunchKernelGGL(hard_big_kernel<I>, gdim(nb), gdim(256), 0, c->stream, a, big.p, nbig, estart.p, total);
     PFP_HIP(hipGetLastError());
     sync(c);
   }
@@ -1188,7 +1229,7 @@ template void merge_bwt<uint64_t>(pfp_ctx *, const Dictionary &, const DictIndex
 // (up to) four values its chunk overlaps - neighbouring lanes read overlapping, consecutive values - lays
 // their 5-byte fields end to end and cuts its 16 bytes out; every store is one aligned-size 16-byte store.
 __global__ __launch_bounds__(256) void pack5_kernel(const uint64_t *__restrict__ v, uint64_t cnt, uint8_t *__restrict__ out) {
-  const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t q = (uint64_t)BID * 256 + threadIdx.x;
   const uint64_t total = cnt * 5, b0 = q * 16;
   if (b0 >= total) return;
   const uint64_t v0 = b0 / 5;
@@ -1203,7 +1244,7 @@ __global__ __launch_bounds__(256) void pack5_kernel(const uint64_t *__restrict__
     for (uint64_t k = 0; b0 + k < total; k++) out[b0 + k] = (uint8_t)((k < 8 ? olo >> (8 * k) : ohi >> (8 * (k - 8))) & 0xff);
 }
 __global__ void unpack5_kernel(const uint8_t *__restrict__ in, uint64_t cnt, uint64_t *__restrict__ v) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i >= cnt) return;
   const uint8_t *p = in + 5 * i;
   uint64_t x = 0;
@@ -1214,12 +1255,12 @@ __global__ void unpack5_kernel(const uint8_t *__restrict__ in, uint64_t cnt, uin
 void pack5_dev(pfp_ctx *c, const uint64_t *vals, uint64_t cnt, uint8_t *out5) {
   if (!cnt) return;
   KScope ks(c, "pfp::pack5_kernel", cnt * 13);
-  hipLaunchKernelGGL(pack5_kernel, dim3((unsigned)cdiv64(cdiv64(cnt * 5, 16), TB)), dim3(TB), 0, c->stream, vals, cnt, out5);
+  hipLaunchKernelGGL(pack5_kernel, gdim((unsigned)cdiv64(cdiv64(cnt * 5, 16), TB)), gdim(TB), 0, c->stream, vals, cnt, out5);
   PFP_HIP(hipGetLastError());
 }
 void unpack5_dev(pfp_ctx *c, const uint8_t *in5, uint64_t cnt, uint64_t *vals) {
   if (!cnt) return;
-  hipLaunchKernelGGL(unpack5_kernel, dim3(cdiv(cnt, TB)), dim3(TB), 0, c->stream, in5, cnt, vals);
+  hipLaunchKernelGGL(unpack5_kernel, gdim(cdiv(cnt, TB)), gdim(TB), 0, c->stream, in5, cnt, vals);
   PFP_HIP(hipGetLastError());
 }
 
@@ -1254,21 +1295,23 @@ __device__ __forceinline__ void run_mask16(const uint8_t *__restrict__ bwt, uint
 __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restrict__ bwt, uint64_t cnt, int left, int right,
                                                         int run_end, uint32_t *__restrict__ tile_cnt) {
   __shared__ uint32_t ws[4];
-  const uint64_t base = (uint64_t)blockIdx.x * kRunTile + (uint64_t)threadIdx.x * 16;
+  if ((uint64_t)BID * kRunTile >= cnt) return;      // a workgroup of the padded last grid row
+  const uint64_t base = (uint64_t)BID * kRunTile + (uint64_t)threadIdx.x * 16;
   uint32_t m[4];
   run_mask16(bwt, base, cnt, left, right, run_end, m);
   uint32_t c = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
   __syncthreads();
-  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+  if (threadIdx.x == 0) tile_cnt[BID] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
 __global__ __launch_bounds__(256) void run_place_kernel(const uint8_t *__restrict__ bwt, const uint64_t *__restrict__ sa,
                                                         uint64_t cnt, uint64_t pos_base, int left, int right, int run_end,
                                                         const uint64_t *__restrict__ tile_off, uint8_t *__restrict__ out10) {
   __shared__ uint32_t ws[4];
-  const uint64_t base = (uint64_t)blockIdx.x * kRunTile + (uint64_t)threadIdx.x * 16;
+  if ((uint64_t)BID * kRunTile >= cnt) return;      // a workgroup of the padded last grid row
+  const uint64_t base = (uint64_t)BID * kRunTile + (uint64_t)threadIdx.x * 16;
   uint32_t m[4];
   run_mask16(bwt, base, cnt, left, right, run_end, m);
   const uint32_t c = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
@@ -1278,7 +1321,7 @@ __global__ __launch_bounds__(256) void run_place_kernel(const uint8_t *__restric
   if (lane == 63) ws[wv] = inc;
   __syncthreads();
   if (!c) return;
-  uint64_t o = tile_off[blockIdx.x] + inc - c;
+  uint64_t o = tile_off[BID] + inc - c;
   for (int q = 0; q < wv; q++) o += ws[q];
 #pragma unroll
   for (int k = 0; k < 16; k++)
@@ -1299,7 +1342,7 @@ RunSampler::RunSampler(pfp_ctx *c_, const uint8_t *bwt_, uint64_t cnt_, int left
   PFP_HIP(hipMemsetAsync(tile_cnt.p + ntile, 0, 4, c->stream));
   if (ntile) {
     KScope ks(c, "pfp::run_count_kernel", cnt);
-    hipLaunchKernelGGL(run_count_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, bwt, cnt, left, right, run_end ? 1 : 0,
+    hipLaunchKernelGGL(run_count_kernel, gdim((unsigned)ntile), gdim(256), 0, c->stream, bwt, cnt, left, right, run_end ? 1 : 0,
                        tile_cnt.p);
   }
   exclusive_sum_u32_u64(c, tile_cnt.p, tile_off.p, ntile + 1);
@@ -1309,7 +1352,7 @@ RunSampler::RunSampler(pfp_ctx *c_, const uint8_t *bwt_, uint64_t cnt_, int left
 void RunSampler::place(const uint64_t *sa, uint64_t pos_base, uint8_t *out10) {
   if (!ntile || !pairs) return;
   KScope ks(c, "pfp::run_place_kernel", cnt + pairs * 18);
-  hipLaunchKernelGGL(run_place_kernel, dim3((unsigned)ntile), dim3(256), 0, c->stream, bwt, sa, cnt, pos_base, left, right,
+  hipLaunchKernelGGL(run_place_kernel, gdim((unsigned)ntile), gdim(256), 0, c->stream, bwt, sa, cnt, pos_base, left, right,
                      run_end ? 1 : 0, tile_off.p, out10);
   PFP_HIP(hipGetLastError());
 }

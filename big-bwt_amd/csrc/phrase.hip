@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void phrase_hash_kernel(const uint8_t *__restr
                                                           uint64_t seed, uint64_t *__restrict__ hash,
                                                           uint32_t *__restrict__ long_list,
                                                           uint32_t *__restrict__ long_count) {
-  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
   uint64_t k = t >> 3;
   int l8 = (int)(t & 7);
   if (k >= P) return;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void phrase_hash_long_kernel(const uint8_t *__
     uint64_t s = ph_start(g, k), len = ph_end(g, k) - s + 1;
     uint64_t npieces = (len + 15) >> 4;
     uint64_t sum = 0;
-    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < npieces; c += (uint64_t)gridDim.x * 256)
+    for (uint64_t c = (uint64_t)BID * 256 + threadIdx.x; c < npieces; c += (uint64_t)GDIM * 256)
       sum += piece_terms(tp + s, c * 16, len, seed);
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void phrase_hash_long_kernel(const uint8_t *__
 __global__ void phrase_hash_long_finish_kernel(PhraseGeom g, const uint32_t *__restrict__ long_list, uint32_t nlong,
                                                const unsigned long long *__restrict__ hsum,
                                                uint64_t *__restrict__ hash) {
-  uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t li = BID * blockDim.x + threadIdx.x;
   if (li >= nlong) return;
   uint64_t k = long_list[li];
   uint64_t len = ph_end(g, k) - ph_start(g, k) + 1;
@@ -113,7 +113,7 @@ __global__ void phrase_hash_long_finish_kernel(PhraseGeom g, const uint32_t *__r
 }
 
 __global__ void iota_u32_kernel(uint32_t *p, uint64_t n) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i < n) p[i] = (uint32_t)i;
 }
 
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void dedup_verify_kernel(const uint8_t *__rest
                                                            const uint64_t *__restrict__ ks,
                                                            const uint32_t *__restrict__ vs,
                                                            uint32_t *__restrict__ head, uint32_t *__restrict__ collision) {
-  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
   uint64_t i = t >> 3;
   int l8 = (int)(t & 7);
   if (i >= P) return;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void dedup_verify_kernel(const uint8_t *__rest
 __global__ void collect_words_kernel(uint64_t P, const uint32_t *__restrict__ head, const uint32_t *__restrict__ hscan,
                                      const uint32_t *__restrict__ vs, uint32_t *__restrict__ hrep,
                                      uint32_t *__restrict__ hpos, uint32_t d) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i == 0) hpos[d] = (uint32_t)P;
   if (i >= P || !head[i]) return;
   uint32_t hw = hscan[i] - 1;
@@ -158,7 +158,7 @@ __global__ void collect_words_kernel(uint64_t P, const uint32_t *__restrict__ he
 // weighted occurrence counts (explicit mode): occ of a distinct word = sum of the weights of its copies
 __global__ void weighted_occ_kernel(uint64_t P, const uint32_t *__restrict__ hscan, const uint32_t *__restrict__ vs,
                                     const uint32_t *__restrict__ weight, uint32_t *__restrict__ hocc) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i < P) atomicAdd(&hocc[hscan[i] - 1], weight[vs[i]]);
 }
 
@@ -168,7 +168,7 @@ __global__ void finish_words_kernel(PhraseGeom g, uint32_t d, const uint32_t *__
                                     uint32_t *__restrict__ fo_of_hw, uint32_t *__restrict__ wlen,
                                     uint32_t *__restrict__ wlen1, uint64_t *__restrict__ wsrc,
                                     uint32_t *__restrict__ wocc, uint32_t *__restrict__ toolong) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = BID * blockDim.x + threadIdx.x;
   if (j == 0) wlen1[d] = 0;
   if (j >= d) return;
   uint32_t hw = hw_sorted[j];
@@ -184,7 +184,7 @@ __global__ void finish_words_kernel(PhraseGeom g, uint32_t d, const uint32_t *__
 
 __global__ void assign_pid_kernel(uint64_t P, const uint32_t *__restrict__ hscan, const uint32_t *__restrict__ vs,
                                   const uint32_t *__restrict__ fo_of_hw, uint32_t *__restrict__ pid) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i < P) pid[vs[i]] = fo_of_hw[hscan[i] - 1];
 }
 
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void dict_copy_kernel(const uint8_t *__restric
                                                         const uint64_t *__restrict__ woff, uint8_t *__restrict__ D,
                                                         uint32_t *__restrict__ long_list,
                                                         uint32_t *__restrict__ long_count) {
-  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
   uint64_t j = t >> 3;
   int l8 = (int)(t & 7);
   if (j >= d) return;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void dict_copy_long_kernel(const uint8_t *__re
     const uint8_t *src = tp + wsrc[j];
     uint8_t *dst = D + woff[j];
     uint64_t npieces = (len + 15) >> 4;
-    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < npieces; c += (uint64_t)gridDim.x * 256)
+    for (uint64_t c = (uint64_t)BID * 256 + threadIdx.x; c < npieces; c += (uint64_t)GDIM * 256)
       copy_piece(src, dst, c * 16, len);
   }
 }
@@ -237,11 +237,32 @@ __global__ __launch_bounds__(256) void dict_copy_long_kernel(const uint8_t *__re
 // .last (newscan.cpp:296) and .sai (newscan.cpp:298-301)
 __global__ void last_sai_kernel(const uint8_t *__restrict__ tp, PhraseGeom g, uint64_t P, uint64_t sai_base,
                                 uint8_t *__restrict__ last, uint64_t *__restrict__ sai) {
-  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (k >= P) return;
   uint64_t e = ph_end(g, k);
   last[k] = tp[e - (uint64_t)g.w];
   if (sai) sai[k] = e + sai_base;
+}
+
+// identity hashes of a word list over a byte buffer (the multi-GPU chain routes every word to the rank that owns
+// its hash class)
+void hash_word_list(pfp_ctx *c, const uint8_t *bytes, const uint64_t *wstart, const uint32_t *wlen, uint64_t U, uint64_t seed,
+                    uint64_t *d_hash) {
+  if (!U) return;
+  const int TB = 256;
+  PhraseGeom g{nullptr, 0, 0, 0, 0, wstart, wlen};
+  DBuf<uint32_t> long_list(c, U), counters(c, 1);
+  counters.zero();
+  hipLaunchKernelGGL(phrase_hash_kernel, gdim(cdiv(U * 8, TB)), gdim(TB), 0, c->stream, bytes, g, U, seed, d_hash, long_list.p, counters.p);
+  const uint32_t nlong = read_scalar(c, counters.p);
+  if (nlong) {
+    DBuf<unsigned long long> hsum(c, nlong);
+    hsum.zero();
+    hipLaunchKernelGGL(phrase_hash_long_kernel, gdim(c->n_cu * 4), gdim(TB), 0, c->stream, bytes, g, seed, long_list.p, nlong, hsum.p);
+    hipLaunchKernelGGL(phrase_hash_long_finish_kernel, gdim(cdiv(nlong, 64)), gdim(64), 0, c->stream, g, long_list.p, nlong, hsum.p, d_hash);
+  }
+  PFP_HIP(hipGetLastError());
+  sync(c);
 }
 
 // Core of the dictionary build over any phrase geometry.  weight == nullptr: every phrase counts
@@ -257,26 +278,26 @@ static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, u
   DBuf<uint64_t> hash(c, P), ks(c, P);
   DBuf<uint32_t> iota(c, P), vs(c, P), head(c, P), hscan(c, P);
   DBuf<uint32_t> long_list(c, P), counters(c, 4);  // [0] long count, [1] collision, [2] too long, [3] long count (copy)
-  hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, iota.p, P);
+  hipLaunchKernelGGL(iota_u32_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, iota.p, P);
   uint64_t seed = 0x243F6A8885A308D3ULL;
   uint32_t d = 0;
   for (int attempt = 0;; attempt++) {
     counters.zero();
     { KScope kscope(c, "pfp::phrase_hash_kernel", n + 16 * P);
-    hipLaunchKernelGGL(phrase_hash_kernel, dim3(cdiv(P * 8, TB)), dim3(TB), 0, c->stream, tp, g, P, seed, hash.p,
+    hipLaunchKernelGGL(phrase_hash_kernel, gdim(cdiv(P * 8, TB)), gdim(TB), 0, c->stream, tp, g, P, seed, hash.p,
                        long_list.p, counters.p); }
     uint32_t nlong = read_scalar(c, counters.p);
     if (nlong) {
       DBuf<unsigned long long> hsum(c, nlong);
       hsum.zero();
-      hipLaunchKernelGGL(phrase_hash_long_kernel, dim3(c->n_cu * 4), dim3(TB), 0, c->stream, tp, g, seed, long_list.p,
+      hipLaunchKernelGGL(phrase_hash_long_kernel, gdim(c->n_cu * 4), gdim(TB), 0, c->stream, tp, g, seed, long_list.p,
                          nlong, hsum.p);
-      hipLaunchKernelGGL(phrase_hash_long_finish_kernel, dim3(cdiv(nlong, 64)), dim3(64), 0, c->stream, g, long_list.p,
+      hipLaunchKernelGGL(phrase_hash_long_finish_kernel, gdim(cdiv(nlong, 64)), gdim(64), 0, c->stream, g, long_list.p,
                          nlong, hsum.p, hash.p);
     }
     sort_pairs_u64_u32(c, hash.p, ks.p, iota.p, vs.p, P, 0, 64);
     { KScope kscope(c, "pfp::dedup_verify_kernel", 2 * n + 16 * P);
-    hipLaunchKernelGGL(dedup_verify_kernel, dim3(cdiv(P * 8, TB)), dim3(TB), 0, c->stream, tp, g, P, ks.p, vs.p, head.p,
+    hipLaunchKernelGGL(dedup_verify_kernel, gdim(cdiv(P * 8, TB)), gdim(TB), 0, c->stream, tp, g, P, ks.p, vs.p, head.p,
                        counters.p + 1); }
     inclusive_sum_u32(c, head.p, hscan.p, P);
     PFP_HIP(hipGetLastError());
@@ -297,19 +318,19 @@ static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, u
   if (weight) {
     hocc.alloc(c, d);
     hocc.zero();
-    hipLaunchKernelGGL(weighted_occ_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, P, hscan.p, vs.p, weight, hocc.p);
+    hipLaunchKernelGGL(weighted_occ_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, P, hscan.p, vs.p, weight, hocc.p);
   }
-  hipLaunchKernelGGL(collect_words_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, P, head.p, hscan.p, vs.p, hrep.p,
+  hipLaunchKernelGGL(collect_words_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, P, head.p, hscan.p, vs.p, hrep.p,
                      hpos.p, d);
-  hipLaunchKernelGGL(iota_u32_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, hwi.p, (uint64_t)d);
+  hipLaunchKernelGGL(iota_u32_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, hwi.p, (uint64_t)d);
   sort_pairs_u32_u32(c, hrep.p, rep_sorted.p, hwi.p, hw_sorted.p, d, 0, bits_for(P));
   D.wlen.alloc(c, d); D.wocc.alloc(c, d); D.woff.alloc(c, (size_t)d + 1); D.pid.alloc(c, P);
   DBuf<uint32_t> wlen1(c, (size_t)d + 1);
   DBuf<uint64_t> wsrc(c, d);
-  hipLaunchKernelGGL(finish_words_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, g, d, rep_sorted.p, hw_sorted.p,
+  hipLaunchKernelGGL(finish_words_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, g, d, rep_sorted.p, hw_sorted.p,
                      hpos.p, weight ? hocc.p : (const uint32_t *)nullptr, fo_of_hw.p, D.wlen.p, wlen1.p, wsrc.p, D.wocc.p,
                      counters.p + 2);
-  hipLaunchKernelGGL(assign_pid_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, P, hscan.p, vs.p, fo_of_hw.p, D.pid.p);
+  hipLaunchKernelGGL(assign_pid_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, P, hscan.p, vs.p, fo_of_hw.p, D.pid.p);
   exclusive_sum_u32_u64(c, wlen1.p, D.woff.p, (size_t)d + 1);
   PFP_HIP(hipMemcpyAsync(c->h_scalars, D.woff.p + d, 8, hipMemcpyDeviceToHost, c->stream));
   PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, counters.p + 2, 4, hipMemcpyDeviceToHost, c->stream));
@@ -321,16 +342,16 @@ static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, u
   D.bytes.alloc(c, D.dsize + 64);
   PFP_HIP(hipMemsetAsync(D.bytes.p + (D.dsize - 1), 0, 65, c->stream));
   PFP_HIP(hipMemsetAsync(counters.p + 3, 0, 4, c->stream));
-  hipLaunchKernelGGL(dict_copy_kernel, dim3(cdiv((uint64_t)d * 8, TB)), dim3(TB), 0, c->stream, tp, d, wsrc.p, D.wlen.p,
+  hipLaunchKernelGGL(dict_copy_kernel, gdim(cdiv((uint64_t)d * 8, TB)), gdim(TB), 0, c->stream, tp, d, wsrc.p, D.wlen.p,
                      D.woff.p, D.bytes.p, long_list.p, counters.p + 3);
   uint32_t nlongw = read_scalar(c, counters.p + 3);
   if (nlongw)
-    hipLaunchKernelGGL(dict_copy_long_kernel, dim3(c->n_cu * 4), dim3(TB), 0, c->stream, tp, wsrc.p, D.wlen.p, D.woff.p,
+    hipLaunchKernelGGL(dict_copy_long_kernel, gdim(c->n_cu * 4), gdim(TB), 0, c->stream, tp, wsrc.p, D.wlen.p, D.woff.p,
                        D.bytes.p, long_list.p, nlongw);
   if (want_last) {
     D.last.alloc(c, P);
     if (want_sai) D.sai.alloc(c, P);
-    hipLaunchKernelGGL(last_sai_kernel, dim3(cdiv(P, TB)), dim3(TB), 0, c->stream, tp, g, P, sai_base, D.last.p,
+    hipLaunchKernelGGL(last_sai_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, tp, g, P, sai_base, D.last.p,
                        want_sai ? D.sai.p : (uint64_t *)nullptr);
   }
   PFP_HIP(hipGetLastError());

@@ -8,7 +8,10 @@
 #include <new>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sys/mman.h>
 #include <cerrno>
+#include <thread>
+#include <algorithm>
 
 using namespace pfp;
 
@@ -16,189 +19,20 @@ namespace pfp {
 
 static constexpr int TB = 256;
 
-void StagedText::stage(pfp_ctx *c, const void *src, bool src_on_device, uint64_t n_, int w_) {
-  n = n_; w = w_;
-  size_t total = kFront + n + (size_t)w + kBack;
-  buf.alloc(c, total);
-  PFP_HIP(hipMemsetAsync(buf.p, 0, kFront - 1, c->stream));
-  PFP_HIP(hipMemsetAsync(buf.p + kFront - 1, kDollar, 1, c->stream));
-  if (n)
-    PFP_HIP(hipMemcpyAsync(buf.p + kFront, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                           c->stream));
-  restage_tail(c, n, w);
-}
-void StagedText::restage_tail(pfp_ctx *c, uint64_t new_n, int w_) const {
-  PFP_HIP(hipMemsetAsync(buf.p + kFront + new_n, kDollar, (size_t)w_, c->stream));
-  PFP_HIP(hipMemsetAsync(buf.p + kFront + new_n + w_, 0, kBack, c->stream));
-}
-
-// occ in lexicographic order and the parse as 1-based lexicographic ranks (newscan.cpp:436,456)
-__global__ void occ_lex_kernel(uint32_t d, const uint32_t *__restrict__ lexrank, const uint32_t *__restrict__ wocc,
-                               uint32_t *__restrict__ occ_lex, uint32_t *__restrict__ word_at_rank) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= d) return;
-  uint32_t r = lexrank[j];
-  occ_lex[r] = wocc[j];
-  if (word_at_rank) word_at_rank[r] = j;
-}
-__global__ void parse_sym_kernel(uint64_t P, const uint32_t *__restrict__ pid, const uint32_t *__restrict__ lexrank,
-                                 uint32_t *__restrict__ sym) {
-  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < P) sym[k] = lexrank[pid[k]] + 1;
-}
-__global__ void sorted_len1_kernel(uint32_t d, const uint32_t *__restrict__ word_at_rank,
-                                   const uint32_t *__restrict__ wlen, uint32_t *__restrict__ len1) {
-  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r == 0) len1[d] = 0;
-  if (r < d) len1[r] = wlen[word_at_rank[r]] + 1;
-}
-// .dict in lexicographic order (newscan.cpp:406-438): 8 lanes per word, 16-byte pieces
-__global__ __launch_bounds__(256) void dict_permute_kernel(uint32_t d, const uint32_t *__restrict__ word_at_rank,
-                                                           const uint64_t *__restrict__ woff,
-                                                           const uint32_t *__restrict__ wlen,
-                                                           const uint8_t *__restrict__ src,
-                                                           const uint64_t *__restrict__ doff, uint8_t *__restrict__ dst) {
-  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  uint64_t r = t >> 3;
-  int l8 = (int)(t & 7);
-  if (r >= d) return;
-  uint32_t j = word_at_rank[r];
-  uint64_t len = (uint64_t)wlen[j] + 1;   // with terminator
-  const uint8_t *s = src + woff[j];
-  uint8_t *o = dst + doff[r];
-  for (uint64_t off = (uint64_t)l8 * 16; off < len; off += 128) {
-    if (off + 16 <= len) st16u(o + off, ld16u(s + off));
-    else for (uint64_t b = off; b < len; b++) o[b] = s[b];
+// host-side copy with a few threads: one core moves ~10 GB/s, PCIe Gen5 x16 takes 50
+static void par_memcpy(void *dst, const void *src, size_t len) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t T = std::min<size_t>(std::min<size_t>(8, hw ? hw : 1), len >> 22);
+  if (T <= 1) { memcpy(dst, src, len); return; }
+  std::vector<std::thread> th;
+  const size_t part = (len / T + 4095) & ~size_t(4095);
+  for (size_t k = 0; k < T; k++) {
+    const size_t off = k * part;
+    if (off >= len) break;
+    const size_t l = std::min(part, len - off);
+    th.emplace_back([=]() { memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, l); });
   }
-}
-
-// suffix order of the dictionary in the index width the dictionary's size asks for (use_wide_index)
-struct DictOrder {
-  bool wide = false;
-  SuffixOrderT<uint32_t> so32;
-  SuffixOrderT<uint64_t> so64;
-  template <class I> SuffixOrderT<I> &get() {
-    if constexpr (sizeof(I) == 8) return so64; else return so32;
-  }
-  uint64_t rounds() const { return wide ? so64.rounds : so32.rounds; }
-};
-// f(I{}) with I = uint64_t (wide) or uint32_t
-template <class F> static void with_width(bool wide, F &&f) {
-  if (wide) f(uint64_t{}); else f(uint32_t{});
-}
-
-struct Chain {
-  StagedText tx;
-  DBuf<uint64_t> ends;
-  uint64_t n_ends = 0, n_used = 0;
-  Dictionary D;
-  DictIndex ix;
-  DictOrder ord;
-  DBuf<uint32_t> occ_lex, word_at_rank, sym;
-  ParseBWT pb;
-};
-
-// narrowing / widening copy of an index array to the host (the staged gsacak.h entry points fix their SA width)
-template <class A, class B>
-__global__ void convert_kernel(const A *__restrict__ in, uint64_t n, B *__restrict__ out) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (B)in[i];
-}
-template <class A, class B>
-static void fetch_converted(pfp_ctx *c, const A *d_in, uint64_t n, B *h_out) {
-  if constexpr (sizeof(A) == sizeof(B)) {
-    d2h(c, (A *)h_out, d_in, n);
-    sync(c);
-  } else {
-    DBuf<B> tmp(c, n);
-    hipLaunchKernelGGL((convert_kernel<A, B>), dim3(cdiv(n, TB)), dim3(TB), 0, c->stream, d_in, n, tmp.p);
-    PFP_HIP(hipGetLastError());
-    d2h(c, h_out, tmp.p, n);
-    sync(c);
-  }
-}
-
-static void check_args(int w, uint64_t p, int flags) {
-  PFP_REQUIRE(w >= 4, PFP_EINVAL, "Windows size must be at least 4 (newscan.cpp:537)");
-  PFP_REQUIRE(w <= 4096, PFP_EINVAL, "window size above 4096 is not supported");
-  PFP_REQUIRE(p >= 10, PFP_EINVAL, "Modulus must be at leas 10 (newscan.cpp:541)");
-  PFP_REQUIRE(!((flags & PFP_FLAG_SA) && (flags & (PFP_FLAG_SSA | PFP_FLAG_ESA))), PFP_EINVAL,
-              "You can either compute the full SA or a sample of it, not both (bigbwt:59-61)");
-  PFP_REQUIRE((flags & ~7) == 0, PFP_EINVAL, "unknown flag bits");
-}
-
-// stage 1 on a staged text: scan, dictionary, dictionary suffix order, lexicographic ranks
-static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool want_sai, bool exact_reference_parse,
-                      bool dense_sa = false) {
-  pfp_stats &st = c->stats;
-  {
-    PhaseTimer t(c, &st.ms_scan);
-    uint32_t n_extra = 0;
-    if (exact_reference_parse || !c->max_phrase) ch.n_ends = scan_text(c, ch.tx, n, w, p, ch.ends, &ch.n_used);
-    else ch.n_ends = scan_text_adaptive(c, ch.tx, n, w, p, c->max_phrase, ch.ends, &ch.n_used, &n_extra);
-    st.extra_triggers = n_extra;
-    if (c->debug) validate_scan(c, ch.ends, ch.n_ends, ch.n_used, w);
-  }
-  {
-    PhaseTimer t(c, &st.ms_phrases);
-    build_dictionary(c, ch.tx, ch.n_used, w, ch.ends, ch.n_ends, want_sai, ch.D);
-    if (c->debug) validate_dictionary(c, ch.D, w);
-    build_dict_index(c, ch.D, ch.ix);
-    if (c->debug) validate_index(c, ch.D, ch.ix);
-  }
-  {
-    PhaseTimer t(c, &st.ms_sa_dict);
-    // BWT only: the merge records ride in the spare bits of the first-round keys (SuffixOrder::paybits)
-    const SlotPayloadSrc pay{ch.ix.pos_word.p, ch.ix.slen.p, ch.D.wocc.p, (uint32_t)ch.D.d, w};
-    ch.ord.wide = use_wide_index(c, ch.D.dsize);      // 32- or 64-bit dictionary positions (bigbwt:130-151)
-    with_width(ch.ord.wide, [&](auto tag) {
-      using I = decltype(tag);
-      auto &so = ch.ord.get<I>();
-      sort_dict_suffixes<I>(c, ch.D.bytes.p, ch.D.dsize, ch.ix.slen.p, so, dense_sa ? nullptr : &pay);
-      if (c->debug) validate_suffix_order<I>(c, ch.D.bytes.p, so, true, "dict SA");
-      compute_lexrank<I>(c, ch.D, so, ch.ix);
-    });
-    if (c->debug) validate_lexrank(c, ch.D, ch.ix);
-    const uint32_t d = (uint32_t)ch.D.d;
-    ch.occ_lex.alloc(c, d); ch.word_at_rank.alloc(c, d);
-    hipLaunchKernelGGL(occ_lex_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ch.ix.lexrank.p, ch.D.wocc.p,
-                       ch.occ_lex.p, ch.word_at_rank.p);
-    ch.sym.alloc(c, ch.D.P);
-    hipLaunchKernelGGL(parse_sym_kernel, dim3(cdiv(ch.D.P, TB)), dim3(TB), 0, c->stream, ch.D.P, ch.D.pid.p,
-                       ch.ix.lexrank.p, ch.sym.p);
-    PFP_HIP(hipGetLastError());
-  }
-  st.n = ch.n_used; st.n_phrases = ch.D.P; st.n_words = ch.D.d; st.dict_size = ch.D.dsize;
-  st.sa_rounds_dict = ch.ord.rounds(); st.hash_reseeds = ch.D.reseeds; st.index_bits = ch.ord.wide ? 64 : 32;
-}
-
-static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, int flags, uint8_t *d_bwt,
-                          uint64_t *d_sa, uint64_t *n_used) {
-  pfp_stats &st = c->stats;
-  st = pfp_stats{};
-  auto t0 = std::chrono::steady_clock::now();
-  run_parse(c, ch, n, w, p, flags != 0, false, (flags & PFP_FLAG_SA) != 0);
-  {
-    PhaseTimer t(c, &st.ms_sa_parse);
-    parse_bwt(c, ch.sym.p, ch.D.P, ch.D.last.p, flags ? ch.D.sai.p : nullptr, ch.occ_lex.p, ch.D.d, ch.pb);
-    st.sa_rounds_parse = ch.pb.rounds;
-    if (c->debug) validate_parse_bwt(c, ch.pb);
-  }
-  {
-    PhaseTimer t(c, &st.ms_merge);
-    BwtOutputs bo;
-    bo.d_bwt = d_bwt; bo.d_sa = d_sa;
-    with_width(ch.ord.wide, [&](auto tag) {
-      using I = decltype(tag);
-      merge_bwt<I>(c, ch.D, ch.ix, ch.ord.get<I>(), ch.pb, ch.occ_lex.p, w, flags, ch.n_used + 1, bo);
-    });
-    st.hard_groups = bo.hard_groups; st.hard_chars = bo.hard_chars;
-    st.hard_big_groups = bo.hard_big_groups; st.hard_max_chars = bo.hard_max_chars; st.hard_max_members = bo.hard_max_members;
-    st.hard_minor_groups = bo.hard_minor_groups; st.hard_minor_chars = bo.hard_minor_chars;
-  }
-  sync(c);
-  st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  *n_used = ch.n_used;
+  for (auto &t : th) t.join();
 }
 
 static void ensure_pinned(pfp_ctx *c) {
@@ -244,6 +78,192 @@ static void stream_h2d(pfp_ctx *c, uint8_t *d_dst, uint64_t nbytes, Fill &&fill)
   }
 }
 
+void StagedText::stage(pfp_ctx *c, const void *src, bool src_on_device, uint64_t n_, int w_) {
+  n = n_; w = w_;
+  size_t total = kFront + n + (size_t)w + kBack;
+  buf.alloc(c, total);
+  PFP_HIP(hipMemsetAsync(buf.p, 0, kFront - 1, c->stream));
+  PFP_HIP(hipMemsetAsync(buf.p + kFront - 1, kDollar, 1, c->stream));
+  if (n && src_on_device) PFP_HIP(hipMemcpyAsync(buf.p + kFront, src, n, hipMemcpyDeviceToDevice, c->stream));
+  if (n && !src_on_device)      // pageable host text (a caller's buffer, an mmap of the input file): chunks through pinned buffers
+    stream_h2d(c, buf.p + kFront, n, [&](uint8_t *pin, uint64_t off, uint64_t len) { par_memcpy(pin, (const uint8_t *)src + off, len); });
+  restage_tail(c, n, w);
+}
+void StagedText::restage_tail(pfp_ctx *c, uint64_t new_n, int w_) const {
+  PFP_HIP(hipMemsetAsync(buf.p + kFront + new_n, kDollar, (size_t)w_, c->stream));
+  PFP_HIP(hipMemsetAsync(buf.p + kFront + new_n + w_, 0, kBack, c->stream));
+}
+
+// occ in lexicographic order and the parse as 1-based lexicographic ranks (newscan.cpp:436,456)
+__global__ void occ_lex_kernel(uint32_t d, const uint32_t *__restrict__ lexrank, const uint32_t *__restrict__ wocc,
+                               uint32_t *__restrict__ occ_lex, uint32_t *__restrict__ word_at_rank) {
+  uint32_t j = BID * blockDim.x + threadIdx.x;
+  if (j >= d) return;
+  uint32_t r = lexrank[j];
+  occ_lex[r] = wocc[j];
+  if (word_at_rank) word_at_rank[r] = j;
+}
+__global__ void parse_sym_kernel(uint64_t P, const uint32_t *__restrict__ pid, const uint32_t *__restrict__ lexrank,
+                                 uint32_t *__restrict__ sym) {
+  uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (k < P) sym[k] = lexrank[pid[k]] + 1;
+}
+__global__ void sorted_len1_kernel(uint32_t d, const uint32_t *__restrict__ word_at_rank,
+                                   const uint32_t *__restrict__ wlen, uint32_t *__restrict__ len1) {
+  uint32_t r = BID * blockDim.x + threadIdx.x;
+  if (r == 0) len1[d] = 0;
+  if (r < d) len1[r] = wlen[word_at_rank[r]] + 1;
+}
+// .dict in lexicographic order (newscan.cpp:406-438): 8 lanes per word, 16-byte pieces
+__global__ __launch_bounds__(256) void dict_permute_kernel(uint32_t d, const uint32_t *__restrict__ word_at_rank,
+                                                           const uint64_t *__restrict__ woff,
+                                                           const uint32_t *__restrict__ wlen,
+                                                           const uint8_t *__restrict__ src,
+                                                           const uint64_t *__restrict__ doff, uint8_t *__restrict__ dst) {
+  uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
+  uint64_t r = t >> 3;
+  int l8 = (int)(t & 7);
+  if (r >= d) return;
+  uint32_t j = word_at_rank[r];
+  uint64_t len = (uint64_t)wlen[j] + 1;   // with terminator
+  const uint8_t *s = src + woff[j];
+  uint8_t *o = dst + doff[r];
+  for (uint64_t off = (uint64_t)l8 * 16; off < len; off += 128) {
+    if (off + 16 <= len) st16u(o + off, ld16u(s + off));
+    else for (uint64_t b = off; b < len; b++) o[b] = s[b];
+  }
+}
+
+// suffix order of the dictionary in the index width the dictionary's size asks for (use_wide_index)
+struct DictOrder {
+  bool wide = false;
+  SuffixOrderT<uint32_t> so32;
+  SuffixOrderT<uint64_t> so64;
+  template <class I> SuffixOrderT<I> &get() {
+    if constexpr (sizeof(I) == 8) return so64; else return so32;
+  }
+  uint64_t rounds() const { return wide ? so64.rounds : so32.rounds; }
+};
+// f(I{}) with I = uint64_t (wide) or uint32_t
+template <class F> static void with_width(bool wide, F &&f) {
+  if (wide) f(uint64_t{}); else f(uint32_t{});
+}
+
+struct Chain {
+  StagedText tx;
+  DBuf<uint64_t> ends;
+  uint64_t n_ends = 0, n_used = 0;
+  Dictionary D;
+  DictIndex ix;
+  DictOrder ord;
+  DBuf<uint32_t> occ_lex, word_at_rank, sym;
+  ParseBWT pb;
+};
+
+// narrowing / widening copy of an index array to the host (the staged gsacak.h entry points fix their SA width)
+template <class A, class B>
+__global__ void convert_kernel(const A *__restrict__ in, uint64_t n, B *__restrict__ out) {
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (B)in[i];
+}
+template <class A, class B>
+static void fetch_converted(pfp_ctx *c, const A *d_in, uint64_t n, B *h_out) {
+  if constexpr (sizeof(A) == sizeof(B)) {
+    d2h(c, (A *)h_out, d_in, n);
+    sync(c);
+  } else {
+    DBuf<B> tmp(c, n);
+    hipLaunchKernelGGL((convert_kernel<A, B>), gdim(cdiv(n, TB)), gdim(TB), 0, c->stream, d_in, n, tmp.p);
+    PFP_HIP(hipGetLastError());
+    d2h(c, h_out, tmp.p, n);
+    sync(c);
+  }
+}
+
+static void check_args(int w, uint64_t p, int flags) {
+  PFP_REQUIRE(w >= 4, PFP_EINVAL, "Windows size must be at least 4 (newscan.cpp:537)");
+  PFP_REQUIRE(w <= 4096, PFP_EINVAL, "window size above 4096 is not supported");
+  PFP_REQUIRE(p >= 10, PFP_EINVAL, "Modulus must be at leas 10 (newscan.cpp:541)");
+  PFP_REQUIRE(!((flags & PFP_FLAG_SA) && (flags & (PFP_FLAG_SSA | PFP_FLAG_ESA))), PFP_EINVAL,
+              "You can either compute the full SA or a sample of it, not both (bigbwt:59-61)");
+  PFP_REQUIRE((flags & ~7) == 0, PFP_EINVAL, "unknown flag bits");
+}
+
+// stage 1 on a staged text: scan, dictionary, dictionary suffix order, lexicographic ranks
+static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool want_sai, bool exact_reference_parse,
+                      bool dense_sa = false) {
+  pfp_stats &st = c->stats;
+  {
+    PhaseTimer t(c, &st.ms_scan);
+    uint32_t n_extra = 0;
+    if (exact_reference_parse || !c->max_phrase) ch.n_ends = scan_text(c, ch.tx, n, w, p, ch.ends, &ch.n_used);
+    else ch.n_ends = scan_text_adaptive(c, ch.tx, n, w, p, c->max_phrase, ch.ends, &ch.n_used, &n_extra);
+    st.extra_triggers = n_extra;
+    if (c->debug) validate_scan(c, ch.ends, ch.n_ends, ch.n_used, w);
+  }
+  {
+    PhaseTimer t(c, &st.ms_phrases);
+    build_dictionary(c, ch.tx, ch.n_used, w, ch.ends, ch.n_ends, want_sai, ch.D);
+    if (c->debug) validate_dictionary(c, ch.D, w);
+    build_dict_index(c, ch.D, ch.ix);
+    if (c->debug) validate_index(c, ch.D, ch.ix);
+  }
+  {
+    PhaseTimer t(c, &st.ms_sa_dict);
+    // BWT only: the merge records ride in the spare bits of the first-round keys (SuffixOrder::paybits)
+    const SlotPayloadSrc pay{ch.ix.pos_word.p, ch.ix.slen.p, ch.D.wocc.p, (uint32_t)ch.D.d, w};
+    ch.ord.wide = use_wide_index(c, ch.D.dsize);      // 32- or 64-bit dictionary positions (bigbwt:130-151)
+    with_width(ch.ord.wide, [&](auto tag) {
+      using I = decltype(tag);
+      auto &so = ch.ord.get<I>();
+      sort_dict_suffixes<I>(c, ch.D.bytes.p, ch.D.dsize, ch.ix.slen.p, so, dense_sa ? nullptr : &pay);
+      if (c->debug) validate_suffix_order<I>(c, ch.D.bytes.p, so, true, "dict SA");
+      compute_lexrank<I>(c, ch.D, so, ch.ix);
+      if (!c->debug) { so.rank.release(); so.tab.release(); }      // the merge reads sa / grp / skeys only
+    });
+    if (c->debug) validate_lexrank(c, ch.D, ch.ix);
+    const uint32_t d = (uint32_t)ch.D.d;
+    ch.occ_lex.alloc(c, d); ch.word_at_rank.alloc(c, d);
+    hipLaunchKernelGGL(occ_lex_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ch.ix.lexrank.p, ch.D.wocc.p,
+                       ch.occ_lex.p, ch.word_at_rank.p);
+    ch.sym.alloc(c, ch.D.P);
+    hipLaunchKernelGGL(parse_sym_kernel, gdim(cdiv(ch.D.P, TB)), gdim(TB), 0, c->stream, ch.D.P, ch.D.pid.p,
+                       ch.ix.lexrank.p, ch.sym.p);
+    PFP_HIP(hipGetLastError());
+  }
+  st.n = ch.n_used; st.n_phrases = ch.D.P; st.n_words = ch.D.d; st.dict_size = ch.D.dsize;
+  st.sa_rounds_dict = ch.ord.rounds(); st.hash_reseeds = ch.D.reseeds; st.index_bits = ch.ord.wide ? 64 : 32;
+}
+
+static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, int flags, uint8_t *d_bwt,
+                          uint64_t *d_sa, uint64_t *n_used) {
+  pfp_stats &st = c->stats;
+  st = pfp_stats{};
+  auto t0 = std::chrono::steady_clock::now();
+  run_parse(c, ch, n, w, p, flags != 0, false, (flags & PFP_FLAG_SA) != 0);
+  {
+    PhaseTimer t(c, &st.ms_sa_parse);
+    parse_bwt(c, ch.sym.p, ch.D.P, ch.D.last.p, flags ? ch.D.sai.p : nullptr, ch.occ_lex.p, ch.D.d, ch.pb);
+    st.sa_rounds_parse = ch.pb.rounds;
+    if (c->debug) validate_parse_bwt(c, ch.pb);
+  }
+  {
+    PhaseTimer t(c, &st.ms_merge);
+    BwtOutputs bo;
+    bo.d_bwt = d_bwt; bo.d_sa = d_sa;
+    with_width(ch.ord.wide, [&](auto tag) {
+      using I = decltype(tag);
+      merge_bwt<I>(c, ch.D, ch.ix, ch.ord.get<I>(), ch.pb, ch.occ_lex.p, w, flags, ch.n_used + 1, bo);
+    });
+    st.hard_groups = bo.hard_groups; st.hard_chars = bo.hard_chars;
+    st.hard_big_groups = bo.hard_big_groups; st.hard_max_chars = bo.hard_max_chars; st.hard_max_members = bo.hard_max_members;
+    st.hard_minor_groups = bo.hard_minor_groups; st.hard_minor_chars = bo.hard_minor_chars;
+  }
+  sync(c);
+  st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  *n_used = ch.n_used;
+}
+
 template <class T>
 static T *host_alloc(size_t count) {
   T *p = (T *)malloc((count ? count : 1) * sizeof(T));
@@ -251,36 +271,72 @@ static T *host_alloc(size_t count) {
   return p;
 }
 
-// fetch device results of a finished chain into a pfp_bwt_result (reference file formats)
-static void fetch_outputs(pfp_ctx *c, const uint8_t *d_bwt, const uint64_t *d_sa, uint64_t n_out, int flags,
-                          pfp_bwt_result *out) {
-  out->bwt = host_alloc<uint8_t>(n_out);
-  out->bwt_size = n_out;
-  d2h(c, out->bwt, d_bwt, n_out);
+// device bytes -> a fresh host buffer, streamed through the pinned buffers (the first touch of the fresh pages
+// and the copy are spread over a few threads)
+static uint8_t *fetch_bytes(pfp_ctx *c, const uint8_t *d_src, uint64_t nbytes) {
+  uint8_t *h = nullptr;
+  if (nbytes >= (64u << 20)) {      // large result: 2 MiB pages where the kernel offers them (hundreds of first-touch faults, not hundreds of thousands)
+    void *q = nullptr;
+    if (posix_memalign(&q, 2u << 20, nbytes) == 0 && q) { (void)madvise(q, nbytes, MADV_HUGEPAGE); h = (uint8_t *)q; }
+  }
+  if (!h) h = host_alloc<uint8_t>(nbytes);
+  stream_d2h(c, d_src, nbytes, [&](const uint8_t *pin, uint64_t off, uint64_t len) { par_memcpy(h + off, pin, len); });
+  return h;
+}
+// the reference's output files from the device results of a finished chain, produced one after the other into
+// `sink(name, device pointer, bytes)` (host buffers of a pfp_bwt_result, or files)
+template <class Sink>
+static void emit_outputs(pfp_ctx *c, const uint8_t *d_bwt, const uint64_t *d_sa, uint64_t n_out, int flags, Sink &&sink) {
+  sink("bwt", d_bwt, n_out);
   if (flags & PFP_FLAG_SA) {                       // .sa: n entries, SA[0]=n omitted (pfbwt.cpp:158-162)
     uint64_t cnt = n_out - 1;
-    DBuf<uint8_t> packed(c, cnt * 5 + 1);
+    DBuf<uint8_t> packed(c, cnt * 5 + 16);
     pack5_dev(c, d_sa + 1, cnt, packed.p);
-    out->sa = host_alloc<uint8_t>(cnt * 5);
-    out->sa_bytes = cnt * 5;
-    d2h(c, out->sa, packed.p, cnt * 5);
+    sink("sa", packed.p, cnt * 5);
     sync(c);
   }
   if (flags & PFP_FLAG_SSA) {
     DBuf<uint8_t> pairs;
     uint64_t k = sample_runs_dev(c, d_bwt, d_sa, n_out, false, pairs);
-    out->ssa = host_alloc<uint8_t>(k * 10); out->ssa_bytes = k * 10;
-    d2h(c, out->ssa, pairs.p, k * 10);
+    sink("ssa", pairs.p, k * 10);
     sync(c);
   }
   if (flags & PFP_FLAG_ESA) {
     DBuf<uint8_t> pairs;
     uint64_t k = sample_runs_dev(c, d_bwt, d_sa, n_out, true, pairs);
-    out->esa = host_alloc<uint8_t>(k * 10); out->esa_bytes = k * 10;
-    d2h(c, out->esa, pairs.p, k * 10);
+    sink("esa", pairs.p, k * 10);
     sync(c);
   }
   sync(c);
+}
+static void fetch_outputs(pfp_ctx *c, const uint8_t *d_bwt, const uint64_t *d_sa, uint64_t n_out, int flags,
+                          pfp_bwt_result *out) {
+  emit_outputs(c, d_bwt, d_sa, n_out, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
+    uint8_t *h = fetch_bytes(c, d, bytes);
+    if (name[0] == 'b') { out->bwt = h; out->bwt_size = bytes; }
+    else if (name[0] == 's' && name[1] == 'a') { out->sa = h; out->sa_bytes = bytes; }
+    else if (name[0] == 's') { out->ssa = h; out->ssa_bytes = bytes; }
+    else { out->esa = h; out->esa_bytes = bytes; }
+  });
+}
+// device bytes -> file (created / truncated), streamed through the pinned buffers
+static void write_dev_file(pfp_ctx *c, const std::string &path, uint64_t file_offset, const uint8_t *d_src, uint64_t nbytes, bool trunc) {
+  const int fd = open(path.c_str(), O_WRONLY | O_CREAT | (trunc ? O_TRUNC : 0), 0644);
+  PFP_REQUIRE(fd >= 0, PFP_EINVAL, "cannot open " + path + ": " + strerror(errno));
+  bool ok = true;
+  std::string werr;
+  try {
+    stream_d2h(c, d_src, nbytes, [&](const uint8_t *h, uint64_t off, uint64_t len) {
+      uint64_t done = 0;
+      while (ok && done < len) {
+        const ssize_t w = pwrite(fd, h + done, len - done, (off_t)(file_offset + off + done));
+        if (w <= 0) { ok = false; werr = strerror(errno); break; }
+        done += (uint64_t)w;
+      }
+    });
+  } catch (...) { close(fd); throw; }
+  sync(c);
+  PFP_REQUIRE(close(fd) == 0 && ok, PFP_EINVAL, "error writing " + path + ": " + werr);
 }
 
 }  // namespace pfp
@@ -470,12 +526,12 @@ int pfp_parse(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, in
   // .dict in lexicographic order
   DBuf<uint32_t> len1(c, (size_t)d + 1);
   DBuf<uint64_t> doff(c, (size_t)d + 1);
-  hipLaunchKernelGGL(sorted_len1_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ch.word_at_rank.p, ch.D.wlen.p,
+  hipLaunchKernelGGL(sorted_len1_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ch.word_at_rank.p, ch.D.wlen.p,
                      len1.p);
   exclusive_sum_u32_u64(c, len1.p, doff.p, (size_t)d + 1);
   DBuf<uint8_t> sdict(c, ch.D.dsize + 64);
   PFP_HIP(hipMemsetAsync(sdict.p + ch.D.dsize - 1, 0, 1, c->stream));
-  hipLaunchKernelGGL(dict_permute_kernel, dim3(cdiv((uint64_t)d * 8, TB)), dim3(TB), 0, c->stream, d, ch.word_at_rank.p,
+  hipLaunchKernelGGL(dict_permute_kernel, gdim(cdiv((uint64_t)d * 8, TB)), gdim(TB), 0, c->stream, d, ch.word_at_rank.p,
                      ch.D.woff.p, ch.D.wlen.p, ch.D.bytes.p, doff.p, sdict.p);
   PFP_HIP(hipGetLastError());
   out->n_used = ch.n_used;
@@ -688,7 +744,7 @@ int pfp_merge(pfp_ctx *c, const uint8_t *dict, uint64_t dict_size, const uint32_
   });
   if (c->debug) validate_lexrank(c, D, ix);
   DBuf<uint32_t> occ_lex(c, D.d);
-  hipLaunchKernelGGL(occ_lex_kernel, dim3(cdiv(D.d, TB)), dim3(TB), 0, c->stream, (uint32_t)D.d, ix.lexrank.p, D.wocc.p,
+  hipLaunchKernelGGL(occ_lex_kernel, gdim(cdiv(D.d, TB)), gdim(TB), 0, c->stream, (uint32_t)D.d, ix.lexrank.p, D.wocc.p,
                      occ_lex.p, (uint32_t *)nullptr);
   ParseBWT pb;
   pb.P = n_plus_1 - 1;
@@ -751,22 +807,7 @@ int pfp_pwrite_dev(pfp_ctx *c, const char *path, uint64_t file_offset, const voi
   if (!c || !path || (!d_src && nbytes)) return PFP_EINVAL;
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
-  const int fd = open(path, O_WRONLY | O_CREAT, 0644);
-  PFP_REQUIRE(fd >= 0, PFP_EINVAL, std::string("cannot open ") + path + ": " + strerror(errno));
-  bool ok = true;
-  std::string werr;
-  try {
-    stream_d2h(c, (const uint8_t *)d_src, nbytes, [&](const uint8_t *h, uint64_t off, uint64_t len) {
-      uint64_t done = 0;
-      while (ok && done < len) {
-        const ssize_t w = pwrite(fd, h + done, len - done, (off_t)(file_offset + off + done));
-        if (w <= 0) { ok = false; werr = strerror(errno); break; }
-        done += (uint64_t)w;
-      }
-    });
-  } catch (...) { close(fd); throw; }
-  sync(c);
-  PFP_REQUIRE(close(fd) == 0 && ok, PFP_EINVAL, std::string("error writing ") + path + ": " + werr);
+  write_dev_file(c, path, file_offset, (const uint8_t *)d_src, nbytes, false);
   return PFP_OK;
   PFP_CATCH(c)
 }
@@ -806,6 +847,31 @@ int pfp_bigbwt(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, i
   PFP_CATCH(c)
 }
 
+// file to files: the host text (an mmap of the input works) is streamed in, the outputs are streamed from HBM
+// straight into <base>.bwt / .sa / .ssa / .esa - no host copy of any output is held
+int pfp_bigbwt_files(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags, const char *base,
+                     uint64_t out_bytes[4]) {
+  if (!c || (!text && n) || !base) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  check_args(w, p, flags);
+  Chain ch;
+  ch.tx.stage(c, text, false, n, w);
+  DBuf<uint8_t> d_bwt(c, n + 1 + 16);
+  DBuf<uint64_t> d_sa;
+  if (flags) d_sa.alloc(c, n + 1);
+  uint64_t used = 0;
+  run_chain_dev(c, ch, n, w, p, flags, d_bwt.p, flags ? d_sa.p : nullptr, &used);
+  uint64_t sizes[4] = {0, 0, 0, 0};
+  emit_outputs(c, d_bwt.p, d_sa.p, used + 1, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
+    write_dev_file(c, std::string(base) + "." + name, 0, d, bytes, true);
+    sizes[name[0] == 'b' ? 0 : (name[1] == 'a' ? 1 : (name[0] == 's' ? 2 : 3))] = bytes;
+  });
+  if (out_bytes) memcpy(out_bytes, sizes, sizeof sizes);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------- multi-GPU chain (one rank's share)
@@ -833,6 +899,12 @@ struct DistState {
   uint64_t local_total = 0;     // BWT positions the held slots emit
   bool want_sai = false;
   int flags = 0;                // output flags announced at pfp_dist_local_parse (0: BWT only)
+  // hash-partitioned dedup (pfp_dist_partition_words ...): local words in owner order, the words this rank owns,
+  // and the global id of every local word once the owners have answered
+  DBuf<uint32_t> part_order;    // [L.d] local word ids, grouped by owner
+  Dictionary Own;               // distinct words of this rank's hash class (first-arrival order) with summed occ
+  DBuf<uint32_t> gid_local;     // [L.d] global word id of local word j
+  bool have_gid = false;
 };
 static DistState *dist_of(pfp_ctx *c) {
   if (!c->dist) c->dist = new DistState();
@@ -848,13 +920,41 @@ __global__ void count_below_kernel(const uint64_t *__restrict__ ends, uint64_t n
 __global__ void dist_sym_kernel(uint64_t P, const uint32_t *__restrict__ lpid, uint64_t word_base,
                                 const uint32_t *__restrict__ gid_of_union, const uint32_t *__restrict__ lexrank,
                                 uint32_t *__restrict__ sym) {
-  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (k < P) sym[k] = lexrank[gid_of_union[word_base + lpid[k]]] + 1;
+}
+// hash class of every local word: owner = (hash >> 20) % parts; per-owner word and byte counts
+__global__ void word_owner_kernel(uint32_t d, const uint64_t *__restrict__ hash, const uint32_t *__restrict__ wlen, uint32_t parts,
+                                  uint32_t *__restrict__ owner, uint32_t *__restrict__ ids, unsigned long long *__restrict__ counts) {
+  uint32_t j = BID * blockDim.x + threadIdx.x;
+  if (j >= d) return;
+  const uint32_t o = (uint32_t)((hash[j] >> 20) % parts);
+  owner[j] = o; ids[j] = j;
+  atomicAdd(&counts[2 * o], 1ull);
+  atomicAdd(&counts[2 * o + 1], (unsigned long long)wlen[j] + 1);
+}
+__global__ void gather_u32_kernel(uint32_t n, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) {
+  uint32_t i = BID * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void scatter_u32_kernel(uint32_t n, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) {
+  uint32_t i = BID * blockDim.x + threadIdx.x;
+  if (i < n) dst[idx[i]] = src[i];
+}
+__global__ void len1_of_kernel(uint32_t n, const uint32_t *__restrict__ order, const uint32_t *__restrict__ wlen, uint32_t *__restrict__ len1) {
+  uint32_t i = BID * blockDim.x + threadIdx.x;
+  if (i == 0) len1[n] = 0;
+  if (i < n) len1[i] = wlen[order[i]] + 1;
+}
+__global__ void dist_sym_gid_kernel(uint64_t P, const uint32_t *__restrict__ lpid, const uint32_t *__restrict__ gid_local,
+                                    const uint32_t *__restrict__ lexrank, uint32_t *__restrict__ sym) {
+  uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (k < P) sym[k] = lexrank[gid_local[lpid[k]]] + 1;
 }
 
 template <class I>
 __global__ void add_one_kernel(uint32_t n, const I *__restrict__ in, uint64_t *__restrict__ out) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = BID * blockDim.x + threadIdx.x;
   if (j < n) out[j] = (uint64_t)in[j] + 1;
 }
 
@@ -903,7 +1003,7 @@ int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t ha
   ds->n_ends = scan_text(c, ds->tx, n, w, p, ds->ends, &used, &kp);
   PFP_REQUIRE(used == n, PFP_EFORMAT, "bytes <= 2 inside a text shard are not supported in the multi-GPU chain");
   DBuf<uint64_t> tmp(c, 2);
-  hipLaunchKernelGGL(count_below_kernel, dim3(1), dim3(1), 0, c->stream, ds->ends.p, ds->n_ends, halo_len, tmp.p);
+  hipLaunchKernelGGL(count_below_kernel, gdim(1), gdim(1), 0, c->stream, ds->ends.p, ds->n_ends, halo_len, tmp.p);
   PFP_HIP(hipMemcpyAsync(c->h_scalars, tmp.p, 16, hipMemcpyDeviceToHost, c->stream));
   sync(c);
   ds->k0 = is_first ? 0 : c->h_scalars[0];
@@ -942,6 +1042,44 @@ int pfp_dist_export_local(pfp_ctx *c, void *d_dict, void *d_occ, void *d_last, v
   PFP_CATCH(c)
 }
 
+}  // extern "C"
+// the global dictionary ds->G is in place: index it and sort its suffixes (replicated, or this rank's key range)
+static void dist_sort_global(pfp_ctx *c, DistState *ds, uint32_t part, uint32_t parts, void *d_wslot_out, uint64_t out_info[8]) {
+  ds->ix = DictIndex();
+  ds->ord = DictOrder();
+  build_dict_index(c, ds->G, ds->ix);
+  const uint32_t d = (uint32_t)ds->G.d;
+  const SlotPayloadSrc pay{ds->ix.pos_word.p, ds->ix.slen.p, ds->G.wocc.p, d, ds->w};
+  const SlotPayloadSrc *payp = (ds->flags & PFP_FLAG_SA) ? nullptr : &pay;      // full SA: the merge gathers wider records itself
+  ds->ord.wide = use_wide_index(c, ds->G.dsize);
+  uint64_t info_rounds = 0, info_complete = 1, info_N = 0, info_base = 0;
+  with_width(ds->ord.wide, [&](auto tag) {
+    using I = decltype(tag);
+    auto &so = ds->ord.get<I>();
+    if (parts == 1) {
+      sort_dict_suffixes<I>(c, ds->G.bytes.p, ds->G.dsize, ds->ix.slen.p, so, payp);
+      if (c->debug) validate_suffix_order<I>(c, ds->G.bytes.p, so, true, "global dict SA");
+      DBuf<I> slots(c, d);
+      gather_ranks<I>(c, so, ds->G.woff.p, d, slots.p);
+      hipLaunchKernelGGL(add_one_kernel<I>, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, slots.p, (uint64_t *)d_wslot_out);
+      ds->local_total = 0;
+    } else {
+      sort_dict_suffixes_range<I>(c, ds->G.bytes.p, ds->G.dsize, ds->ix.slen.p, part, parts, so, payp, &pay);
+      gather_slots_range<I>(c, so, ds->G.woff.p, d, (uint64_t *)d_wslot_out);
+      ds->local_total = so.complete ? so.range_emits : 0;
+      if (c->debug && so.complete)
+        PFP_REQUIRE(count_slot_outputs<I>(c, ds->G, ds->ix, so, ds->w) == ds->local_total, PFP_EHIP,
+                    "emit count by position differs from the count by slot");
+    }
+    info_rounds = so.rounds; info_complete = so.complete ? 1 : 0; info_N = so.N; info_base = so.slot_base;
+  });
+  PFP_HIP(hipGetLastError());
+  sync(c);
+  out_info[0] = ds->G.d; out_info[1] = ds->G.dsize; out_info[2] = info_rounds; out_info[3] = info_complete;
+  out_info[4] = info_N; out_info[5] = info_base; out_info[6] = ds->local_total; out_info[7] = ds->ord.wide ? 64 : 32;
+}
+extern "C" {
+
 int pfp_dist_global_sort(pfp_ctx *c, const void *d_union, uint64_t union_bytes, const void *d_union_occ, uint64_t n_union,
                          uint32_t part, uint32_t parts, void *d_wslot_out, uint64_t out_info[8]) {
   if (!c || !c->dist || !d_union || !d_union_occ || !d_wslot_out || !out_info || parts < 1 || part >= parts) return PFP_EINVAL;
@@ -958,39 +1096,120 @@ int pfp_dist_global_sort(pfp_ctx *c, const void *d_union, uint64_t union_bytes, 
   word_table_from_bytes(c, U, n_union);           // only the word boundaries of the union are needed
   PFP_REQUIRE(U.d == n_union, PFP_EFORMAT, "the union holds a different number of words than occ entries");
   ds->G = Dictionary();
-  ds->ix = DictIndex();
-  ds->ord = DictOrder();
+  ds->have_gid = false;
   build_dictionary_words(c, U.bytes.p, U.woff.p, U.wlen.p, n_union, (const uint32_t *)d_union_occ, union_bytes, ds->G);
-  build_dict_index(c, ds->G, ds->ix);
-  const uint32_t d = (uint32_t)ds->G.d;
-  const SlotPayloadSrc pay{ds->ix.pos_word.p, ds->ix.slen.p, ds->G.wocc.p, d, ds->w};
-  const SlotPayloadSrc *payp = (ds->flags & PFP_FLAG_SA) ? nullptr : &pay;      // full SA: the merge gathers wider records itself
-  ds->ord.wide = use_wide_index(c, ds->G.dsize);
-  uint64_t info_rounds = 0, info_complete = 1, info_N = 0, info_base = 0;
-  with_width(ds->ord.wide, [&](auto tag) {
-    using I = decltype(tag);
-    auto &so = ds->ord.get<I>();
-    if (parts == 1) {
-      sort_dict_suffixes<I>(c, ds->G.bytes.p, ds->G.dsize, ds->ix.slen.p, so, payp);
-      if (c->debug) validate_suffix_order<I>(c, ds->G.bytes.p, so, true, "global dict SA");
-      DBuf<I> slots(c, d);
-      gather_ranks<I>(c, so, ds->G.woff.p, d, slots.p);
-      hipLaunchKernelGGL(add_one_kernel<I>, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, slots.p, (uint64_t *)d_wslot_out);
-      ds->local_total = 0;
-    } else {
-      sort_dict_suffixes_range<I>(c, ds->G.bytes.p, ds->G.dsize, ds->ix.slen.p, part, parts, so, payp, &pay);
-      gather_slots_range<I>(c, so, ds->G.woff.p, d, (uint64_t *)d_wslot_out);
-      ds->local_total = so.complete ? so.range_emits : 0;
-      if (c->debug && so.complete)
-        PFP_REQUIRE(count_slot_outputs<I>(c, ds->G, ds->ix, so, ds->w) == ds->local_total, PFP_EHIP,
-                    "emit count by position differs from the count by slot");
-    }
-    info_rounds = so.rounds; info_complete = so.complete ? 1 : 0; info_N = so.N; info_base = so.slot_base;
-  });
+  dist_sort_global(c, ds, part, parts, d_wslot_out, out_info);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// ---- hash-partitioned dedup: every distinct word is owned by the rank its hash points at (SURVEY 8e exchange A; the
+//      reference's threaded parser shards its maps by hash % (3 N) the same way, pscan.cpp:137-205)
+int pfp_dist_partition_words(pfp_ctx *c, uint32_t parts, uint64_t *counts /* [2 * parts]: words, bytes (+1 per word) per owner */) {
+  if (!c || !c->dist || !counts || parts < 1) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  const uint32_t d = (uint32_t)ds->L.d;
+  PFP_REQUIRE(d >= 1, PFP_EINVAL, "pfp_dist_local_parse has not run");
+  DBuf<uint64_t> hash(c, d);
+  hash_word_list(c, ds->L.bytes.p, ds->L.woff.p, ds->L.wlen.p, d, 0x6A09E667F3BCC909ULL, hash.p);
+  DBuf<uint32_t> owner(c, d), ownero(c, d), ids(c, d);
+  DBuf<unsigned long long> cnt(c, 2 * (size_t)parts);
+  cnt.zero();
+  hipLaunchKernelGGL(word_owner_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, hash.p, ds->L.wlen.p, parts, owner.p, ids.p, cnt.p);
+  ds->part_order.alloc(c, d);
+  sort_pairs_u32_u32(c, owner.p, ownero.p, ids.p, ds->part_order.p, d, 0, bits_for(parts));      // stable: local order inside an owner
+  PFP_HIP(hipGetLastError());
+  PFP_HIP(hipMemcpyAsync(counts, cnt.p, 2 * (size_t)parts * 8, hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_dist_export_partition(pfp_ctx *c, void *d_bytes, void *d_occ) {
+  if (!c || !c->dist || !d_bytes || !d_occ) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  const uint32_t d = (uint32_t)ds->L.d;
+  PFP_REQUIRE(ds->part_order.p, PFP_EINVAL, "pfp_dist_partition_words has not run");
+  DBuf<uint32_t> len1(c, (size_t)d + 1);
+  DBuf<uint64_t> doff(c, (size_t)d + 1);
+  hipLaunchKernelGGL(len1_of_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ds->part_order.p, ds->L.wlen.p, len1.p);
+  exclusive_sum_u32_u64(c, len1.p, doff.p, (size_t)d + 1);
+  hipLaunchKernelGGL(dict_permute_kernel, gdim(cdiv((uint64_t)d * 8, TB)), gdim(TB), 0, c->stream, d, ds->part_order.p, ds->L.woff.p,
+                     ds->L.wlen.p, ds->L.bytes.p, doff.p, (uint8_t *)d_bytes);
+  hipLaunchKernelGGL(gather_u32_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ds->part_order.p, ds->L.wocc.p, (uint32_t *)d_occ);
   PFP_HIP(hipGetLastError());
   sync(c);
-  out_info[0] = ds->G.d; out_info[1] = ds->G.dsize; out_info[2] = info_rounds; out_info[3] = info_complete;
-  out_info[4] = info_N; out_info[5] = info_base; out_info[6] = ds->local_total; out_info[7] = ds->ord.wide ? 64 : 32;
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_dist_owner_dedup(pfp_ctx *c, const void *d_bytes, uint64_t nbytes, const void *d_occ, uint64_t n_words, void *d_pid_out,
+                         uint64_t out[2]) {
+  if (!c || !c->dist || !out || (n_words && (!d_bytes || !d_occ || !d_pid_out))) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  ds->Own = Dictionary();
+  out[0] = out[1] = 0;
+  if (!n_words) return PFP_OK;                 // nobody sent a word of this hash class
+  Dictionary U;
+  U.dsize = nbytes + 1;
+  U.bytes.alloc(c, U.dsize + 64);
+  PFP_HIP(hipMemcpyAsync(U.bytes.p, d_bytes, nbytes, hipMemcpyDeviceToDevice, c->stream));
+  PFP_HIP(hipMemsetAsync(U.bytes.p + nbytes, 0, 65, c->stream));
+  word_table_from_bytes(c, U, n_words);
+  PFP_REQUIRE(U.d == n_words, PFP_EFORMAT, "the received words do not match their occ entries");
+  build_dictionary_words(c, U.bytes.p, U.woff.p, U.wlen.p, n_words, (const uint32_t *)d_occ, nbytes, ds->Own);
+  PFP_HIP(hipMemcpyAsync(d_pid_out, ds->Own.pid.p, n_words * 4, hipMemcpyDeviceToDevice, c->stream));
+  sync(c);
+  out[0] = ds->Own.d; out[1] = ds->Own.dsize - 1;
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_dist_export_owned(pfp_ctx *c, void *d_bytes, void *d_occ) {
+  if (!c || !c->dist) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  if (!ds->Own.d) return PFP_OK;
+  PFP_REQUIRE(d_bytes && d_occ, PFP_EINVAL, "null output");
+  PFP_HIP(hipMemcpyAsync(d_bytes, ds->Own.bytes.p, ds->Own.dsize - 1, hipMemcpyDeviceToDevice, c->stream));
+  PFP_HIP(hipMemcpyAsync(d_occ, ds->Own.wocc.p, ds->Own.d * 4, hipMemcpyDeviceToDevice, c->stream));
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+// d_dict / d_occ: the owners' distinct words back to back (owner 0 first) = the global dictionary, duplicate free by
+// construction; d_gid_sent: the global id of every local word in the order pfp_dist_export_partition sent them
+int pfp_dist_global_sort_distinct(pfp_ctx *c, const void *d_dict, uint64_t dict_bytes, const void *d_occ, uint64_t n_words,
+                                  const void *d_gid_sent, uint32_t part, uint32_t parts, void *d_wslot_out, uint64_t out_info[8]) {
+  if (!c || !c->dist || !d_dict || !d_occ || !d_gid_sent || !d_wslot_out || !out_info || parts < 1 || part >= parts) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  PFP_REQUIRE(n_words >= 1 && n_words < 0xFFFFFFFFull, PFP_EINVAL, "bad word count");
+  PFP_REQUIRE(ds->part_order.p, PFP_EINVAL, "pfp_dist_partition_words has not run");
+  ds->G = Dictionary();
+  ds->G.dsize = dict_bytes + 1;
+  ds->G.bytes.alloc(c, ds->G.dsize + 64);
+  PFP_HIP(hipMemcpyAsync(ds->G.bytes.p, d_dict, dict_bytes, hipMemcpyDeviceToDevice, c->stream));
+  PFP_HIP(hipMemsetAsync(ds->G.bytes.p + dict_bytes, 0, 65, c->stream));
+  word_table_from_bytes(c, ds->G, n_words);
+  PFP_REQUIRE(ds->G.d == n_words, PFP_EFORMAT, "the global dictionary holds a different number of words than occ entries");
+  ds->G.wocc.alloc(c, n_words);
+  PFP_HIP(hipMemcpyAsync(ds->G.wocc.p, d_occ, n_words * 4, hipMemcpyDeviceToDevice, c->stream));
+  const uint32_t dl = (uint32_t)ds->L.d;
+  ds->gid_local.alloc(c, dl);
+  hipLaunchKernelGGL(scatter_u32_kernel, gdim(cdiv(dl, TB)), gdim(TB), 0, c->stream, dl, ds->part_order.p, (const uint32_t *)d_gid_sent,
+                     ds->gid_local.p);
+  ds->have_gid = true;
+  dist_sort_global(c, ds, part, parts, d_wslot_out, out_info);
   return PFP_OK;
   PFP_CATCH(c)
 }
@@ -1005,10 +1224,14 @@ int pfp_dist_global_finish(pfp_ctx *c, const void *d_wslot_all, uint32_t parts, 
   compute_lexrank_from_slots(c, ds->G, (const uint64_t *)d_wslot_all, parts, ds->ix);
   if (c->debug) validate_lexrank(c, ds->G, ds->ix);
   ds->occ_lex.alloc(c, d);
-  hipLaunchKernelGGL(occ_lex_kernel, dim3(cdiv(d, TB)), dim3(TB), 0, c->stream, d, ds->ix.lexrank.p, ds->G.wocc.p,
+  hipLaunchKernelGGL(occ_lex_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ds->ix.lexrank.p, ds->G.wocc.p,
                      ds->occ_lex.p, (uint32_t *)nullptr);
-  hipLaunchKernelGGL(dist_sym_kernel, dim3(cdiv(ds->P_local, TB)), dim3(TB), 0, c->stream, ds->P_local, ds->L.pid.p,
-                     my_word_base, ds->G.pid.p, ds->ix.lexrank.p, (uint32_t *)d_sym_out);
+  if (ds->have_gid)
+    hipLaunchKernelGGL(dist_sym_gid_kernel, gdim(cdiv(ds->P_local, TB)), gdim(TB), 0, c->stream, ds->P_local, ds->L.pid.p,
+                       ds->gid_local.p, ds->ix.lexrank.p, (uint32_t *)d_sym_out);
+  else
+    hipLaunchKernelGGL(dist_sym_kernel, gdim(cdiv(ds->P_local, TB)), gdim(TB), 0, c->stream, ds->P_local, ds->L.pid.p,
+                       my_word_base, ds->G.pid.p, ds->ix.lexrank.p, (uint32_t *)d_sym_out);
   PFP_HIP(hipGetLastError());
   sync(c);
   return PFP_OK;

@@ -123,20 +123,21 @@ __device__ __forceinline__ void load_sel16(const uint8_t *__restrict__ flags, ui
 __global__ __launch_bounds__(256) void flag_count_kernel(const uint8_t *__restrict__ flags, uint64_t n, int eq,
                                                          uint32_t *__restrict__ blocksum) {
   __shared__ uint32_t ws[4];
-  const uint64_t base = (uint64_t)blockIdx.x * kSelTile + (uint64_t)threadIdx.x * 16;
+  const uint64_t base = (uint64_t)BID * kSelTile + (uint64_t)threadIdx.x * 16;
   uint32_t w[4];
   load_sel16(flags, base, n, eq, w);
   uint32_t cnt = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0) blocksum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+  if (threadIdx.x == 0 && (uint64_t)BID * kSelTile < n) blocksum[BID] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 template <class I>
 __global__ __launch_bounds__(256) void flag_place_kernel(const uint8_t *__restrict__ flags, uint64_t n, int eq,
                                                          const uint64_t *__restrict__ blockoff, I *__restrict__ out) {
   __shared__ uint32_t ws[4];
-  const uint64_t base = (uint64_t)blockIdx.x * kSelTile + (uint64_t)threadIdx.x * 16;
+  if ((uint64_t)BID * kSelTile >= n) return;      // a workgroup of the padded last grid row
+  const uint64_t base = (uint64_t)BID * kSelTile + (uint64_t)threadIdx.x * 16;
   uint32_t w[4];
   load_sel16(flags, base, n, eq, w);
   const uint32_t cnt = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void flag_place_kernel(const uint8_t *__restri
   for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
   if (lane == 63) ws[wv] = inc;
   __syncthreads();
-  uint64_t pos = blockoff[blockIdx.x] + inc - cnt;
+  uint64_t pos = blockoff[BID] + inc - cnt;
   for (int q = 0; q < wv; q++) pos += ws[q];
   if (!cnt) return;
 #pragma unroll
@@ -160,9 +161,9 @@ static void select_bytes(pfp_ctx *c, const uint8_t *flags, int eq, I *out, uint6
   DBuf<uint64_t> boff(c, nblk + 1);
   PFP_HIP(hipMemsetAsync(bsum.p + nblk, 0, 4, c->stream));
   KScope ks(c, "pfp::select_flags_kernel", n * 2);
-  hipLaunchKernelGGL(flag_count_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, flags, (uint64_t)n, eq, bsum.p);
+  hipLaunchKernelGGL(flag_count_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, flags, (uint64_t)n, eq, bsum.p);
   exclusive_sum_u32_u64(c, bsum.p, boff.p, nblk + 1);
-  hipLaunchKernelGGL(flag_place_kernel<I>, dim3((unsigned)nblk), dim3(256), 0, c->stream, flags, (uint64_t)n, eq, boff.p, out);
+  hipLaunchKernelGGL(flag_place_kernel<I>, gdim((unsigned)nblk), gdim(256), 0, c->stream, flags, (uint64_t)n, eq, boff.p, out);
   PFP_HIP(hipGetLastError());
   PFP_HIP(hipMemcpyAsync(d_count, boff.p + nblk, 8, hipMemcpyDeviceToDevice, c->stream));
 }
@@ -180,7 +181,7 @@ template void select_byte_index<uint64_t>(pfp_ctx *, const uint8_t *, uint8_t, u
 __global__ __launch_bounds__(256) void sum_u32_kernel(const uint32_t *__restrict__ a, uint64_t n, unsigned long long *__restrict__ out) {
   __shared__ unsigned long long ws[4];
   unsigned long long x = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) x += a[i];
+  for (uint64_t i = (uint64_t)BID * 256 + threadIdx.x; i < n; i += (uint64_t)GDIM * 256) x += a[i];
   for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = x;
   __syncthreads();
@@ -192,8 +193,8 @@ uint64_t count_flags(pfp_ctx *c, const uint8_t *flags, size_t n) {
   DBuf<uint32_t> bsum(c, nblk);
   DBuf<unsigned long long> tot(c, 1);
   tot.zero();
-  hipLaunchKernelGGL(flag_count_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, flags, (uint64_t)n, -1, bsum.p);
-  hipLaunchKernelGGL(sum_u32_kernel, dim3((unsigned)std::min<size_t>((nblk + 255) / 256, 256)), dim3(256), 0, c->stream, bsum.p, (uint64_t)nblk, tot.p);
+  hipLaunchKernelGGL(flag_count_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, flags, (uint64_t)n, -1, bsum.p);
+  hipLaunchKernelGGL(sum_u32_kernel, gdim((unsigned)std::min<size_t>((nblk + 255) / 256, 256)), gdim(256), 0, c->stream, bsum.p, (uint64_t)nblk, tot.p);
   PFP_HIP(hipGetLastError());
   return read_scalar(c, (const uint64_t *)tot.p);
 }

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void kr_flag_kernel(const uint8_t *__restrict_
                                                       uint32_t *__restrict__ block_counts,
                                                       unsigned long long *__restrict__ first_bad) {
   static_assert(W >= 2 && W <= 17, "register path needs w-1 <= 16");
-  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // 16-byte chunk index
+  const uint64_t c = (uint64_t)BID * 256 + threadIdx.x;  // 16-byte chunk index
   const uint64_t pos0 = c * 16;
   uint32_t mask = 0;
   if (pos0 < n) {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void kr_flag_kernel(const uint8_t *__restrict_
   __shared__ uint32_t wsum[4];
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (threadIdx.x == 0 && (uint64_t)BID * 4096 < n) block_counts[BID] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // generic window size (w > 17): same arithmetic, bytes fetched from memory
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void kr_flag_generic_kernel(const uint8_t *__r
                                                               KRParams kp, uint16_t *__restrict__ flags16,
                                                               uint32_t *__restrict__ block_counts,
                                                               unsigned long long *__restrict__ first_bad) {
-  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t c = (uint64_t)BID * 256 + threadIdx.x;
   const uint64_t pos0 = c * 16;
   uint32_t mask = 0;
   if (pos0 < n) {
@@ -161,14 +161,15 @@ __global__ __launch_bounds__(256) void kr_flag_generic_kernel(const uint8_t *__r
   __shared__ uint32_t wsum[4];
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (threadIdx.x == 0 && (uint64_t)BID * 4096 < n) block_counts[BID] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // K2: masks -> dense ordered phrase ends (text positions)
 __global__ __launch_bounds__(256) void kr_compact_kernel(const uint16_t *__restrict__ flags16, uint64_t nchunks,
                                                          const uint32_t *__restrict__ block_offsets,
                                                          uint64_t *__restrict__ ends) {
-  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if ((uint64_t)BID * 256 >= nchunks) return;      // a workgroup of the padded last grid row
+  const uint64_t c = (uint64_t)BID * 256 + threadIdx.x;
   uint32_t mask = (c < nchunks) ? flags16[c] : 0u;
   uint32_t cnt = __popc(mask);
   // inclusive wave scan
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void kr_compact_kernel(const uint16_t *__restr
   __syncthreads();
   uint32_t wbase = 0;
   for (int i = 0; i < (int)(threadIdx.x >> 6); i++) wbase += wsum[i];
-  uint64_t o = (uint64_t)block_offsets[blockIdx.x] + wbase + (incl - cnt);
+  uint64_t o = (uint64_t)block_offsets[BID] + wbase + (incl - cnt);
   while (mask) {
     int b = __ffs(mask) - 1;
     mask &= mask - 1;
@@ -219,7 +220,7 @@ KRParams make_kr_params(int w, uint64_t p) {
 template <int W>
 static void launch_flag(pfp_ctx *c, int nblocks, const uint8_t *tbase, uint64_t n, const KRParams &kp,
                         uint16_t *flags16, uint32_t *bc, unsigned long long *fb) {
-  hipLaunchKernelGGL(kr_flag_kernel<W>, dim3(nblocks), dim3(256), 0, c->stream, tbase, n, kp, flags16, bc, fb);
+  hipLaunchKernelGGL(kr_flag_kernel<W>, gdim(nblocks), gdim(256), 0, c->stream, tbase, n, kp, flags16, bc, fb);
 }
 
 void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p, uint16_t *flags16,
@@ -234,7 +235,7 @@ void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p,
     CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17)
 #undef CASE
     default:
-      hipLaunchKernelGGL(kr_flag_generic_kernel, dim3(nblocks), dim3(256), 0, c->stream, tbase, n, w, kp, flags16,
+      hipLaunchKernelGGL(kr_flag_generic_kernel, gdim(nblocks), gdim(256), 0, c->stream, tbase, n, w, kp, flags16,
                          block_counts, first_bad);
   }
   PFP_HIP(hipGetLastError());
@@ -275,7 +276,7 @@ uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t
     d_ends.alloc(c, (size_t)total + 1);
     KScope ks(c, "pfp::kr_compact_kernel", nchunks * 2 + (uint64_t)total * 8);
     if (total)
-      hipLaunchKernelGGL(kr_compact_kernel, dim3(nblocks), dim3(256), 0, c->stream, flags16.p, nchunks, boff.p, d_ends.p);
+      hipLaunchKernelGGL(kr_compact_kernel, gdim(nblocks), gdim(256), 0, c->stream, flags16.p, nchunks, boff.p, d_ends.p);
     PFP_HIP(hipGetLastError());
     return total;
   }
@@ -297,7 +298,7 @@ uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t
 __global__ void giant_phrases_kernel(const uint64_t *__restrict__ ends, uint64_t ne, uint64_t n, int w,
                                      uint64_t max_len, uint32_t *__restrict__ count, uint64_t *__restrict__ picks,
                                      uint32_t cap) {
-  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (k > ne) return;
   uint64_t e = k < ne ? ends[k] + 1 : n + (uint64_t)w;             // T' index of the last byte
   uint64_t s = k == 0 ? 0 : ends[k - 1] + 2 - (uint64_t)w;         // T' index of the first byte
@@ -310,10 +311,10 @@ __global__ void giant_phrases_kernel(const uint64_t *__restrict__ ends, uint64_t
 constexpr uint32_t kCand = 256;
 __global__ void window_hash_kernel(const uint8_t *__restrict__ tbase, int w, const uint64_t *__restrict__ picks,
                                    uint32_t *__restrict__ out) {
-  uint64_t e = picks[blockIdx.x] + threadIdx.x;
+  uint64_t e = picks[BID] + threadIdx.x;
   uint32_t h = 0;
   for (int k = 0; k < w; k++) h = kr_reduce<8>(((uint64_t)h << 8) | tbase[e - (uint64_t)(w - 1) + (uint64_t)k]);
-  out[blockIdx.x * kCand + threadIdx.x] = h;
+  out[BID * kCand + threadIdx.x] = h;
 }
 
 // one proposal round: window hashes (at most 8) that would split the phrases of this scan result
@@ -326,12 +327,12 @@ uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_use
   DBuf<uint64_t> picks(c, cap);
   std::vector<uint32_t> hv(cap * kCand);
   cnt.zero();
-  hipLaunchKernelGGL(giant_phrases_kernel, dim3(cdiv(ne + 1, 256)), dim3(256), 0, c->stream, d_ends.p, ne, n_used, w,
+  hipLaunchKernelGGL(giant_phrases_kernel, gdim(cdiv(ne + 1, 256)), gdim(256), 0, c->stream, d_ends.p, ne, n_used, w,
                      max_phrase, cnt.p, picks.p, cap);
   uint32_t ng = read_scalar(c, cnt.p);
   if (!ng) return 0;
   uint32_t take = ng < cap ? ng : cap;
-  hipLaunchKernelGGL(window_hash_kernel, dim3(take), dim3(kCand), 0, c->stream, tx.tbase(), w, picks.p, hashes.p);
+  hipLaunchKernelGGL(window_hash_kernel, gdim(take), gdim(kCand), 0, c->stream, tx.tbase(), w, picks.p, hashes.p);
   PFP_HIP(hipMemcpyAsync(hv.data(), hashes.p, (size_t)take * kCand * 4, hipMemcpyDeviceToHost, c->stream));
   sync(c);
   // The first window of the text must never become a trigger by this route: the reference writes 0x02

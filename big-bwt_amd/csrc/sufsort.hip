@@ -52,12 +52,12 @@ struct KeyCode {
 };
 
 __global__ __launch_bounds__(256) void byte_histogram_kernel(const uint8_t *__restrict__ s, uint64_t N,
-                                                             uint32_t *__restrict__ hist /*[256]*/) {
+                                                             unsigned long long *__restrict__ hist /*[256]*/) {
   __shared__ uint32_t h[4][256];
   for (int q = threadIdx.x; q < 1024; q += 256) (&h[0][0])[q] = 0;
   __syncthreads();
   uint32_t *mine = h[threadIdx.x >> 6];
-  for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; i < N; i += (uint64_t)gridDim.x * 256 * 16) {
+  for (uint64_t i = ((uint64_t)BID * 256 + threadIdx.x) * 16; i < N; i += (uint64_t)GDIM * 256 * 16) {
     uint4 v = *reinterpret_cast<const uint4 *>(s + i);     // buffer is zero padded past N
     uint32_t w4[4] = {v.x, v.y, v.z, v.w};
     const int nb = (N - i) >= 16 ? 16 : (int)(N - i);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void byte_histogram_kernel(const uint8_t *__re
   }
   __syncthreads();
   const uint32_t t = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
-  if (t) atomicAdd(&hist[threadIdx.x], t);
+  if (t) atomicAdd(&hist[threadIdx.x], (unsigned long long)t);
 }
 
 // Alphabetic code by recursive weight-balanced splitting of the symbols in byte order (every split
@@ -89,7 +89,7 @@ static void balanced_code(const std::vector<uint64_t> &w, int lo, int hi, uint32
   balanced_code(w, lo, cut, code << 1, len + 1, codes, lens);
   balanced_code(w, cut, hi, (code << 1) | 1u, len + 1, codes, lens);
 }
-static KeyCode make_key_code(const uint32_t hist[256]) {
+static KeyCode make_key_code(const uint64_t hist[256]) {
   KeyCode kc{};
   std::vector<int> sym;
   for (int b2 = 0; b2 < 256; b2++) if (hist[b2] || b2 <= 1) sym.push_back(b2);       // 0x00 / 0x01 always coded
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__
                                                                int paybits, uint64_t *__restrict__ key,
                                                                I *__restrict__ val) {
   __shared__ KeyStreamLds L;
-  const uint64_t B0 = (uint64_t)blockIdx.x * kKeyPos;
+  const uint64_t B0 = (uint64_t)BID * kKeyPos;
   uint64_t k = block_stream_key(L, s, N, kp, slen, B0);
   const uint64_t pos = B0 + threadIdx.x;
   if (threadIdx.x >= kKeyPos || pos >= N) return;
@@ -261,21 +261,21 @@ __global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__
 // PFP_DEBUG: the bit-stream keys against the character-by-character ones
 __global__ void check_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp, const uint64_t *__restrict__ key,
                                   uint64_t keymask, unsigned long long *__restrict__ bad) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i >= N) return;
   if ((key[i] & keymask) != packed_key_at(s, i, kp.kbits, kp.lut)) atomicAdd(bad, 1ull);
 }
 template <class I>
 __global__ void init_keys_bytes_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
                                        I *__restrict__ val) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i >= N) return;
   key[i] = __builtin_bswap64(ld8u(s + i));         // buffer is zero padded past N
   val[i] = (I)i;
 }
 __global__ void init_keys_int_kernel(const uint32_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
                                      uint32_t *__restrict__ val) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i >= N) return;
   uint64_t a = s[i], b = (i + 1 < N) ? s[i + 1] : 0;
   key[i] = (a << 32) | b; val[i] = (uint32_t)i;
@@ -286,19 +286,19 @@ __global__ void init_keys_int_kernel(const uint32_t *__restrict__ s, uint64_t N,
 // a long N run holds a run of 300 k equal phrases (18 rounds; with the run key 8).
 __global__ __launch_bounds__(256) void max_u32_kernel(const uint32_t *__restrict__ s, uint64_t N, uint32_t *__restrict__ out) {
   uint32_t m = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256) m = s[i] > m ? s[i] : m;
+  for (uint64_t i = (uint64_t)BID * 256 + threadIdx.x; i < N; i += (uint64_t)GDIM * 256) m = s[i] > m ? s[i] : m;
   for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_down(m, o, 64); m = v > m ? v : m; }
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 __global__ void run_marks_kernel(const uint32_t *__restrict__ s, uint32_t N, uint32_t *__restrict__ v) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;      // reversed index
+  uint32_t j = BID * blockDim.x + threadIdx.x;      // reversed index
   if (j >= N) return;
   const uint32_t i = N - 1 - j;
   v[j] = (i == N - 1 || s[i] != s[i + 1]) ? j : 0u;
 }
 __global__ void init_keys_int_run_kernel(const uint32_t *__restrict__ s, uint32_t N, const uint32_t *__restrict__ pm, int sb,
                                          uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t i = BID * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const uint64_t a = s[i], b = (i + 1 < N) ? s[i + 1] : 0;
   const int eb = 64 - 2 * sb;
@@ -316,7 +316,7 @@ __global__ void init_keys_int_run_kernel(const uint32_t *__restrict__ s, uint32_
 }
 template <class I>
 __global__ void iota_kernel(I *p, uint64_t n) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i < n) p[i] = (I)i;
 }
 
@@ -329,7 +329,7 @@ __global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const I *__
                                   const I *__restrict__ act_grp, RankViewT<I> L, int nb,
                                   typename IdxTraits<I>::DKey *__restrict__ key, I *__restrict__ val) {
   using K = typename IdxTraits<I>::DKey;
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const I i = act_i[a];
   const K grp = act_grp[a];
@@ -343,12 +343,12 @@ __global__ void build_keys_kernel(SufGeom g, uint64_t m, uint64_t h, const I *__
 // list is in slot order), so only the 32-bit "next" key has to be sorted, inside every group
 template <class I>
 __global__ void group_starts_kernel(uint64_t m, const I *__restrict__ act_grp, uint8_t *__restrict__ gs) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a < m) gs[a] = (a == 0 || act_grp[a] != act_grp[a - 1]) ? 1 : 0;
 }
 __global__ void build_keys32_kernel(SufGeom g, uint64_t m, uint64_t h, const uint32_t *__restrict__ act_i,
                                     RankViewT<uint32_t> L, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const uint32_t i = act_i[a];
   bool settled = false;
@@ -358,53 +358,51 @@ __global__ void build_keys32_kernel(SufGeom g, uint64_t m, uint64_t h, const uin
 // Small segments.  The unresolved suffixes of a dictionary of variants come in families of a handful of members
 // (a phrase and the variants that agree with it over the first-round prefix): a device-wide radix sort of
 // (group, order key) moves every element 7 times to reorder it inside a group of six.  Here every element
-// finds its place directly: start of its group in the (grouped) active list from a max-scan of the group
-// starts, rank inside the group by comparing with the group's members (a few neighbouring, cached loads).
-// Stable: equal keys keep their list order.  Used while the longest group has at most kSmallSeg members.
-constexpr uint32_t kSmallSeg = 256;
+// finds its place directly: the group ids and keys of 256 list positions plus kSmallSeg on either side are
+// staged in LDS, an element walks back to the start of its group and forward over its members, counting the
+// keys that sort before its own (stable: equal keys keep their list order).  A group longer than kSmallSeg does
+// not fit the window: the kernel then only raises *overflow and the caller sorts that round with the library.
+// Also writes the group-start flags gs[] the head detection of the round reads.
+constexpr uint32_t kSmallSeg = 64;
 template <class I>
-__global__ void seg_marks_kernel(uint64_t m, const I *__restrict__ act_grp, uint8_t *__restrict__ gs, I *__restrict__ mark) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= m) return;
-  const bool h = a == 0 || act_grp[a] != act_grp[a - 1];
-  gs[a] = h ? 1 : 0;
-  mark[a] = h ? (I)a : (I)0;
-}
-template <class I>
-__global__ __launch_bounds__(256) void seg_maxlen_kernel(uint64_t m, const uint8_t *__restrict__ gs, const I *__restrict__ start_of,
-                                                         unsigned long long *__restrict__ maxlen) {
-  __shared__ unsigned long long ws[4];
-  uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned long long len = 0;
-  if (a < m && (a + 1 == m || gs[a + 1])) len = a - (uint64_t)start_of[a] + 1;
-  for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_down(len, o, 64); len = v > len ? v : len; }
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = len;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long v = ws[0];
-    for (int q = 1; q < 4; q++) v = ws[q] > v ? ws[q] : v;
-    if (v) atomicMax(maxlen, v);
-  }
-}
-template <class I>
-__global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const uint8_t *__restrict__ gs, const I *__restrict__ start_of,
+__global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const I *__restrict__ act_grp,
                                                              const uint32_t *__restrict__ key, const I *__restrict__ val,
-                                                             uint32_t *__restrict__ keyo, I *__restrict__ valo) {
-  uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (a >= m) return;
-  const uint64_t s0 = start_of[a];
-  const uint32_t ka = key[a];
-  uint64_t r = 0;
-  for (uint64_t j = s0; j < m && (j == s0 || !gs[j]); j++) {
-    const uint32_t kj = key[j];
-    r += (kj < ka || (kj == ka && j < a)) ? 1 : 0;
+                                                             uint8_t *__restrict__ gs, uint32_t *__restrict__ keyo,
+                                                             I *__restrict__ valo, uint32_t *__restrict__ overflow) {
+  constexpr int K = (int)kSmallSeg, W = 256 + 2 * K;
+  __shared__ uint32_t lkey[W];
+  __shared__ I lgrp[W];
+  const uint64_t B = (uint64_t)BID * 256;
+  for (int idx = threadIdx.x; idx < W; idx += 256) {
+    const uint64_t j = B + idx;                   // list position + K
+    const bool ok = j >= (uint64_t)K && j - K < m;
+    lkey[idx] = ok ? key[j - K] : 0u;
+    lgrp[idx] = ok ? act_grp[j - K] : IdxTraits<I>::kNone;      // outside the list: no group
   }
+  __syncthreads();
+  const uint64_t a = B + threadIdx.x;
+  if (a >= m) return;
+  const int la = (int)threadIdx.x + K;
+  const I g = lgrp[la];
+  gs[a] = lgrp[la - 1] != g ? 1 : 0;
+  int ls = la;
+  while (ls > la - (K - 1) && lgrp[ls - 1] == g) ls--;
+  if (lgrp[ls - 1] == g) { atomicOr(overflow, 1u); return; }      // the group starts K or more positions back
+  const uint32_t ka = lkey[la];
+  uint32_t r = 0;
+  int j = ls;
+  for (; j < ls + K && j < W && lgrp[j] == g; j++) {
+    const uint32_t kj = lkey[j];
+    r += (kj < ka || (kj == ka && j < la)) ? 1u : 0u;
+  }
+  if (lgrp[j] == g) { atomicOr(overflow, 1u); return; }      // more than K members (j <= ls + K < W)
+  const uint64_t s0 = a - (uint64_t)(la - ls);
   keyo[s0 + r] = ka;
   valo[s0 + r] = val[a];
 }
 __global__ void seg_end_kernel(uint32_t ng, uint32_t m, const uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
                                uint32_t *__restrict__ maxlen) {
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t k = BID * blockDim.x + threadIdx.x;
   uint32_t len = 0;
   if (k < ng) { uint32_t e = (k + 1 < ng) ? seg_begin[k + 1] : m; seg_end[k] = e; len = e - seg_begin[k]; }
   for (int o = 32; o > 0; o >>= 1) { uint32_t v = __shfl_down(len, o, 64); len = v > len ? v : len; }
@@ -413,7 +411,7 @@ __global__ void seg_end_kernel(uint32_t ng, uint32_t m, const uint32_t *__restri
 template <class I>
 __global__ void heads32_kernel(uint64_t m, const uint8_t *__restrict__ gs, const uint32_t *__restrict__ key,
                                const I *__restrict__ aslot, uint8_t *__restrict__ hd, I *__restrict__ hv) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= m) return;
   bool h = gs[a] || key[a] != key[a - 1];
   hd[a] = h ? 1 : 0;
@@ -429,7 +427,7 @@ __global__ __launch_bounds__(256) void active_count_kernel(const uint8_t *__rest
                                                            uint64_t m, uint32_t *__restrict__ tile_keep,
                                                            uint32_t *__restrict__ tile_heads) {
   // thread = 16 flags, 16 threads = one tile of 256
-  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
   const uint64_t base = t * 16;
   uint32_t k[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0};
   if (base < m) { load_flags16(keep, base, m, k); load_flags16(hd, base, m, h); }
@@ -448,15 +446,16 @@ __global__ __launch_bounds__(256) void active_place_kernel(const uint8_t *__rest
                                                            I *__restrict__ aslot2, I *__restrict__ act_i,
                                                            I *__restrict__ act_grp) {
   __shared__ uint32_t ws[4];
-  if (tile_keep[blockIdx.x] == 0) return;       // nothing kept in these 256 positions (most tiles after the first round)
-  const uint64_t a = (uint64_t)blockIdx.x * kTile + threadIdx.x;
+  if ((uint64_t)BID * kTile >= m) return;      // a workgroup of the padded last grid row
+  if (tile_keep[BID] == 0) return;       // nothing kept in these 256 positions (most tiles after the first round)
+  const uint64_t a = (uint64_t)BID * kTile + threadIdx.x;
   const bool k = a < m && keep[a];
   const unsigned long long mask = __ballot(k);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) ws[wv] = (uint32_t)__popcll(mask);
   __syncthreads();
   if (!k) return;
-  I pos = tile_off[blockIdx.x] + (I)__popcll(mask & ((1ull << lane) - 1ull));
+  I pos = tile_off[BID] + (I)__popcll(mask & ((1ull << lane) - 1ull));
   for (int q = 0; q < wv; q++) pos += ws[q];
   aslot2[pos] = aslot ? aslot[a] : (I)a; act_i[pos] = val[a] & ~finbit; act_grp[pos] = newhead[a];      // no list yet: slot == index
 }
@@ -464,7 +463,7 @@ __global__ __launch_bounds__(256) void active_place_kernel(const uint8_t *__rest
 template <class I, class K>
 __global__ void heads_kernel(uint64_t m, const K *__restrict__ key, const I *__restrict__ aslot,
                              uint8_t *__restrict__ hd, I *__restrict__ hv) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= m) return;
   bool h = (a == 0) || key[a] != key[a - 1];
   hd[a] = h ? 1 : 0;
@@ -481,7 +480,8 @@ __global__ __launch_bounds__(256) void heads0_kernel(uint64_t m, const uint64_t 
                                                      uint32_t T, uint8_t *__restrict__ hd, I *__restrict__ tile_last,
                                                      I *__restrict__ tab) {
   __shared__ I wl[4];
-  const uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if ((uint64_t)BID * 256 >= m) return;      // a workgroup of the padded last grid row
+  const uint64_t a = (uint64_t)BID * 256 + threadIdx.x;
   bool h = false;
   if (a < m) {
     const uint64_t k = key[a] & keymask, kprev = a ? (key[a - 1] & keymask) : ~k;
@@ -491,17 +491,17 @@ __global__ __launch_bounds__(256) void heads0_kernel(uint64_t m, const uint64_t 
   }
   const unsigned long long mask = __ballot(h);
   if ((threadIdx.x & 63) == 0)
-    wl[threadIdx.x >> 6] = mask ? (I)(blockIdx.x * 256ull + (threadIdx.x & ~63) + (63 - __clzll((long long)mask))) : (I)0;
+    wl[threadIdx.x >> 6] = mask ? (I)(BID * 256ull + (threadIdx.x & ~63) + (63 - __clzll((long long)mask))) : (I)0;
   __syncthreads();
   if (threadIdx.x == 0) {
     I v = wl[0];
     for (int q = 1; q < 4; q++) v = wl[q] > v ? wl[q] : v;
-    tile_last[blockIdx.x] = v;
+    tile_last[BID] = v;
   }
 }
 template <class I>
 __global__ void fill_kernel(I *p, uint64_t n, I v) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
 // First round of dictionary mode: sa and grp are the sorted values / scanned heads themselves
@@ -511,9 +511,10 @@ __global__ __launch_bounds__(256) void write_back0_kernel(uint64_t m, const I *_
                                                           const I *__restrict__ tile_scan,
                                                           const uint8_t *__restrict__ hd, const uint64_t *__restrict__ key0,
                                                           I *__restrict__ rank,
-                                                          I *__restrict__ grp, uint8_t *__restrict__ keep) {
+                                                          I *__restrict__ grp, uint8_t *__restrict__ keep, int write_ranks) {
   __shared__ I wl[4];
-  const uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if ((uint64_t)BID * 256 >= m) return;      // a workgroup of the padded last grid row
+  const uint64_t a = (uint64_t)BID * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // all loads first: nothing below the barrier waits on memory except the carry-in
   const bool in = a < m;
@@ -521,9 +522,9 @@ __global__ __launch_bounds__(256) void write_back0_kernel(uint64_t m, const I *_
   const bool hnext = in && (a + 1 == m || hd[a + 1]);
   const I i = in ? val[a] : (I)0;
   const uint32_t flagbit = in ? (uint32_t)(key0[a] & 1ull) : 0u;
-  const I carry = blockIdx.x ? tile_scan[blockIdx.x - 1] : (I)0;
+  const I carry = BID ? tile_scan[BID - 1] : (I)0;
   const unsigned long long mask = __ballot(h);
-  const I wbase = (I)(blockIdx.x * 256ull + (threadIdx.x & ~63));
+  const I wbase = (I)(BID * 256ull + (threadIdx.x & ~63));
   if (lane == 0) wl[wv] = mask ? wbase + (63 - __clzll((long long)mask)) : (I)0;
   __syncthreads();
   if (!in) return;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256) void write_back0_kernel(uint64_t m, const I *_
   const bool single = h && hnext;
   const bool fin = !single && flagbit;       // the terminator is inside the key: the tied strings are identical
   const bool k = !single && !fin;
-  if (k) rank[i] = head;
+  if (k && write_ranks) rank[i] = head;       // lazy mode: rank[] of an unresolved suffix is filled in when a doubling round asks
   keep[a] = k ? 1 : 0;
 }
 
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256) void write_back0_kernel(uint64_t m, const I *_
 template <class I>
 __global__ void scatter_settled_kernel(uint64_t N, const I *__restrict__ sa, const I *__restrict__ grp,
                                        const uint8_t *__restrict__ keep, I finbit, I *__restrict__ rank) {
-  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (t < N && !keep[t]) rank[sa[t]] = grp[t] | finbit;
 }
 
@@ -573,8 +574,8 @@ template <class I>
 __global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t m, uint64_t from, uint32_t cap,
                                         const I *__restrict__ act_i, const I *__restrict__ act_grp,
                                         const I *__restrict__ sa, I finbit, uint64_t *__restrict__ key,
-                                        uint32_t *__restrict__ key32, I *__restrict__ val) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                        uint32_t *__restrict__ key32, I *__restrict__ val, int both = 0) {
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const I i = act_i[a], grp = act_grp[a];
   const I piv = sa[grp];
@@ -620,7 +621,7 @@ __global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t 
     // not done: still equal to P after cap bytes -> P's class, without the settled bit
   }
   if (key32) key32[a] = ok;                 // segmented sort: the group is the segment, only the order key is sorted
-  else key[a] = ((uint64_t)grp << kPivBits) | ok;
+  if (!key32 || both) key[a] = ((uint64_t)grp << kPivBits) | ok;
   val[a] = i | settled;
 }
 // a member of P's class without the settled bit (equal to P for cap bytes, unknown beyond): nobody in
@@ -629,7 +630,7 @@ template <class I>
 __global__ void pivot_veto_kernel(uint64_t m, const uint64_t *__restrict__ key, const uint32_t *__restrict__ key32,
                                   const I *__restrict__ val, const I *__restrict__ newhead, I finbit,
                                   uint8_t *__restrict__ veto) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const uint32_t ok = key32 ? key32[a] : ((uint32_t)key[a] & ((1u << kPivBits) - 1));
   if (ok == kPivEq && !(val[a] & finbit)) veto[newhead[a]] = 1;
@@ -646,7 +647,7 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
                                   int prevshift, const I *__restrict__ prevgrp, const uint8_t *__restrict__ veto,
                                   const uint8_t *__restrict__ lazy_bytes, I *__restrict__ sa,
                                   I *__restrict__ rank, I *__restrict__ grp, uint8_t *__restrict__ keep) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const I iv = val[a], i = iv & ~finbit;
   const I slot = aslot[a];
@@ -667,23 +668,29 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
   // (compute_lexrank); every other settled rank is filled in by repair_ranks_kernel if a doubling
   // round follows after all.  One byte read replaces the scattered 4-byte store.
   bool wr = k ? old != newhead[a] : true;
-  if (!k && lazy_bytes) wr = i == 0 || lazy_bytes[i - 1] == kEndOfWord;
+  if (lazy_bytes) wr = !k && (i == 0 || lazy_bytes[i - 1] == kEndOfWord);
   if (wr) rank[i] = newhead[a] | (k ? (I)0 : finbit);
   keep[a] = k ? 1 : 0;
 }
 
 // ranks that pivot rounds left unwritten: every slot re-ordered after the first round that is not in
 // the active list any more holds a settled suffix
+// lazy ranks: the unresolved suffixes get theirs (= their group's head slot) from the active list
+template <class I>
+__global__ void active_ranks_kernel(uint64_t m, const I *__restrict__ act_i, const I *__restrict__ act_grp, I *__restrict__ rank) {
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (a < m) rank[act_i[a]] = act_grp[a];
+}
 template <class I>
 __global__ void mark_slots_kernel(uint64_t m, const I *__restrict__ aslot, uint8_t *__restrict__ flag) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a < m) flag[aslot[a]] = 1;
 }
 template <class I>
 __global__ void repair_ranks_kernel(uint64_t N, const uint8_t *__restrict__ refined, const uint8_t *__restrict__ active,
                                     const I *__restrict__ sa, const I *__restrict__ grp, I finbit,
                                     I *__restrict__ rank) {
-  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (t < N && refined[t] && !active[t]) rank[sa[t]] = grp[t] | finbit;
 }
 
@@ -738,7 +745,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   if (!lazy) {
     out.sa.alloc(c, N);
     alloc_lists(N);
-    hipLaunchKernelGGL(iota_kernel<I>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, aslot.p, N);
+    hipLaunchKernelGGL(iota_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, aslot.p, N);
   }
   uint64_t m = N, h = h0;
   bool first = true;
@@ -747,7 +754,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     out.shift = key0_bits - tb;
     out.T = 1u << tb;
     out.tab.alloc(c, out.T);
-    hipLaunchKernelGGL(fill_kernel<I>, dim3(cdiv(out.T, TB)), dim3(TB), 0, c->stream, out.tab.p, (uint64_t)out.T,
+    hipLaunchKernelGGL(fill_kernel<I>, gdim(cdiv(out.T, TB)), gdim(TB), 0, c->stream, out.tab.p, (uint64_t)out.T,
                        (I)(IdxTraits<I>::kNone - (I)N));
     PFP_HIP(hipMemsetAsync(out.rank.p, 0xff, NP * sizeof(I), c->stream));
   }
@@ -768,43 +775,40 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   DBuf<uint8_t> veto, keep0;
   static const bool lazy_pivot_ranks = getenv("PFP_EAGER_PIVOT_RANKS") == nullptr;
   bool ranks_stale = false;     // pivot rounds skipped rank[] of settled suffixes that are not whole words
+  bool active_stale = false;    // ... and the first round / pivot rounds skipped rank[] of the suffixes that stay unresolved
+  // lazy ranks are possible when pivot rounds (which never read rank[]) can follow the first round
+  const bool lazy_active = lazy && lazy_pivot_ranks && out.finbit && g.mode == MODE_DICT && kPivotCap >= 16 && (uint64_t)nb + kPivBits <= 64;
   auto repair_ranks = [&](uint64_t m_active, const I *aslot_list) {
     if (!ranks_stale) return;
     DBuf<uint8_t> act(c, N);
     act.zero();
-    if (m_active) hipLaunchKernelGGL(mark_slots_kernel<I>, dim3(cdiv(m_active, TB)), dim3(TB), 0, c->stream, m_active, aslot_list, act.p);
+    if (m_active) hipLaunchKernelGGL(mark_slots_kernel<I>, gdim(cdiv(m_active, TB)), gdim(TB), 0, c->stream, m_active, aslot_list, act.p);
     KScope ks(c, "pfp::write_back_kernel", N * 6);
-    hipLaunchKernelGGL(repair_ranks_kernel<I>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, keep0.p, act.p, out.sa.p, out.grp.p,
+    hipLaunchKernelGGL(repair_ranks_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, keep0.p, act.p, out.sa.p, out.grp.p,
                        out.finbit, out.rank.p);
     ranks_stale = false;
   };
-  DBuf<unsigned long long> maxlen_d;
+  DBuf<uint32_t> ovf_d;
   auto seg_bufs = [&]() {
-    if (!gs.p) { gs.alloc(c, list_cap + 1); k32.alloc(c, list_cap); k32o.alloc(c, list_cap); nseg_d.alloc(c, 2); nsel_d.alloc(c, 1); maxlen_d.alloc(c, 1); }
+    if (!gs.p) { gs.alloc(c, list_cap + 1); k32.alloc(c, list_cap); k32o.alloc(c, list_cap); nseg_d.alloc(c, 2); nsel_d.alloc(c, 1); ovf_d.alloc(c, 1); }
   };
-  // group starts of the active list, start index of every element's group (-> newhead, scratch at this point of
-  // a round) and the longest group
-  auto seg_starts = [&](uint64_t mm) -> uint64_t {
-    seg_bufs();
-    maxlen_d.zero();
-    KScope ks(c, "pfp::seg_small_sort_kernel", mm * (sizeof(I) * 3 + 2));
-    hipLaunchKernelGGL(seg_marks_kernel<I>, dim3(cdiv(mm, TB)), dim3(TB), 0, c->stream, mm, act_grp.p, gs.p, hv.p);
-    inclusive_max<I>(c, hv.p, newhead.p, mm);
-    hipLaunchKernelGGL(seg_maxlen_kernel<I>, dim3(cdiv(mm, TB)), dim3(TB), 0, c->stream, mm, gs.p, newhead.p, maxlen_d.p);
-    return read_scalar(c, (const uint64_t *)maxlen_d.p);
-  };
-  auto seg_small_sort = [&](uint64_t mm) {      // k32/val -> k32o/valo, every group sorted by its 32-bit key
-    KScope ks(c, "pfp::seg_small_sort_kernel", mm * (8 + 2 * sizeof(I) + sizeof(I) + 1));
-    hipLaunchKernelGGL(seg_small_sort_kernel<I>, dim3(cdiv(mm, TB)), dim3(TB), 0, c->stream, mm, gs.p, newhead.p, k32.p, val.p, k32o.p, valo.p);
+  // k32/val -> k32o/valo, every group of the (grouped) active list sorted by its 32-bit key; false: some group has
+  // more than kSmallSeg members (nothing usable was written)
+  auto seg_small_sort = [&](uint64_t mm) -> bool {
+    ovf_d.zero();
+    { KScope ks(c, "pfp::seg_small_sort_kernel", mm * (8 + 3 * sizeof(I) + 1));
+      hipLaunchKernelGGL(seg_small_sort_kernel<I>, gdim(cdiv(mm, TB)), gdim(TB), 0, c->stream, mm, act_grp.p, k32.p, val.p, gs.p, k32o.p,
+                         valo.p, ovf_d.p); }
+    return read_scalar(c, ovf_d.p) == 0;
   };
   auto seg_setup = [&](uint64_t mm, uint32_t &ng, uint32_t &maxlen) {      // segments = groups of the (grouped) active list
     seg_bufs();
     if (!segb.p) { segb.alloc(c, list_cap + 1); sege.alloc(c, list_cap + 1); }
-    hipLaunchKernelGGL(group_starts_kernel<I>, dim3(cdiv(mm, TB)), dim3(TB), 0, c->stream, mm, act_grp.p, gs.p);
+    hipLaunchKernelGGL(group_starts_kernel<I>, gdim(cdiv(mm, TB)), gdim(TB), 0, c->stream, mm, act_grp.p, gs.p);
     select_index<uint32_t>(c, gs.p, segb.p, nsel_d.p, mm);
     PFP_HIP(hipMemsetAsync(nseg_d.p + 1, 0, 4, c->stream));
     ng = (uint32_t)read_scalar(c, nsel_d.p);
-    hipLaunchKernelGGL(seg_end_kernel, dim3(cdiv(ng, TB)), dim3(TB), 0, c->stream, ng, (uint32_t)mm, segb.p, sege.p, nseg_d.p + 1);
+    hipLaunchKernelGGL(seg_end_kernel, gdim(cdiv(ng, TB)), gdim(TB), 0, c->stream, ng, (uint32_t)mm, segb.p, sege.p, nseg_d.p + 1);
     maxlen = read_scalar(c, nseg_d.p + 1);
   };
   DBuf<uint32_t> tile_keep, tile_heads;
@@ -816,27 +820,28 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     if (first && lazy) {
       tile_last.alloc(c, cdiv64(m, 256)); tile_scan.alloc(c, cdiv64(m, 256));
       { KScope ks(c, "pfp::heads_kernel", m * 13);
-        hipLaunchKernelGGL(heads0_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, out.keymask, out.shift, out.T,
+        hipLaunchKernelGGL(heads0_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, keyo.p, out.keymask, out.shift, out.T,
                            hd.p, tile_last.p, out.tab.p); }
       inclusive_max<I>(c, out.tab.p, out.tab.p, out.T);
       inclusive_max<I>(c, tile_last.p, tile_scan.p, cdiv64(m, 256));
     } else if (seg_round) {
       KScope ks(c, "pfp::heads_kernel", m * 14);
-      hipLaunchKernelGGL(heads32_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, gs.p, k32o.p, aslot.p, hd.p, hv.p);
+      hipLaunchKernelGGL(heads32_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, gs.p, k32o.p, aslot.p, hd.p, hv.p);
     } else if (dbl_round && kWide) {
       KScope ks(c, "pfp::heads_kernel", m * 25);
-      hipLaunchKernelGGL((heads_kernel<I, K>), dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, dkeyo.p, aslot.p, hd.p, hv.p);
+      hipLaunchKernelGGL((heads_kernel<I, K>), gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, dkeyo.p, aslot.p, hd.p, hv.p);
     } else {
       KScope ks(c, "pfp::heads_kernel", m * 17);
-      hipLaunchKernelGGL((heads_kernel<I, uint64_t>), dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p);
+      hipLaunchKernelGGL((heads_kernel<I, uint64_t>), gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, keyo.p, aslot.p, hd.p, hv.p);
     }
     const bool round0 = first && lazy;
     first = false;
     if (!round0) inclusive_max<I>(c, hv.p, newhead.p, m);
     if (round0) {
       { KScope ks(c, "pfp::write_back_kernel", m * (4 + 4 + 1 + 8 + 4 + 1));
-        hipLaunchKernelGGL(write_back0_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, valo.p, tile_scan.p, hd.p, keyo.p,
-                           out.rank.p, out.grp.p, keep.p); }
+        hipLaunchKernelGGL(write_back0_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, valo.p, tile_scan.p, hd.p, keyo.p,
+                           out.rank.p, out.grp.p, keep.p, lazy_active ? 0 : 1); }
+      if (lazy_active) active_stale = true;
       // the sorted keys and the sorted positions stay with the result; later rounds sort the (smaller) active set elsewhere
       out.skeys = std::move(keyo);
       out.sa = std::move(valo);
@@ -844,7 +849,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       if (pivot_round) {
         if (!veto.p) veto.alloc(c, N);
         veto.zero();
-        hipLaunchKernelGGL(pivot_veto_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, m, keyo.p,
+        hipLaunchKernelGGL(pivot_veto_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, keyo.p,
                            seg_round ? k32o.p : (const uint32_t *)nullptr, valo.p, newhead.p, out.finbit, veto.p);
       }
       // previous group head of the element now at a: the high part of its sort key, or (segmented
@@ -856,14 +861,14 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       const uint8_t *lazyb = (pivot_round && lazy_pivot_ranks) ? out.bytes : (const uint8_t *)nullptr;
       const I *prevgrp = (have_prev && seg_round) ? act_grp.p : (const I *)nullptr;
       if (dbl_round && kWide && !seg_round)
-        hipLaunchKernelGGL((write_back_kernel<I, K>), dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p, hd.p,
+        hipLaunchKernelGGL((write_back_kernel<I, K>), gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p, hd.p,
                            out.finbit, have_prev ? dkeyo.p : (const K *)nullptr, nb, prevgrp, vetop, lazyb, out.sa.p, out.rank.p,
                            out.grp.p, keep.p);
       else
-        hipLaunchKernelGGL((write_back_kernel<I, uint64_t>), dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p,
+        hipLaunchKernelGGL((write_back_kernel<I, uint64_t>), gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p,
                            hd.p, out.finbit, (have_prev && !seg_round) ? keyo.p : (const uint64_t *)nullptr, pivot_round ? kPivBits : nb,
                            prevgrp, vetop, lazyb, out.sa.p, out.rank.p, out.grp.p, keep.p);
-      if (pivot_round && lazy_pivot_ranks) ranks_stale = true;
+      if (pivot_round && lazy_pivot_ranks) { ranks_stale = true; active_stale = true; }
     }
     uint64_t m2 = 0, ngrp = 0;
     {
@@ -874,7 +879,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       PFP_HIP(hipMemsetAsync(tile_keep.p + ntile, 0, 4, c->stream));
       PFP_HIP(hipMemsetAsync(tile_heads.p + ntile, 0, 4, c->stream));
       KScope ks(c, "pfp::compact3_kernel", m * 2 + 0);      // label kept from the kernel this replaced (profiles compare rounds)
-      hipLaunchKernelGGL(active_count_kernel, dim3((unsigned)cdiv64(ntile, 16)), dim3(256), 0, c->stream, keep.p, hd.p, m,
+      hipLaunchKernelGGL(active_count_kernel, gdim((unsigned)cdiv64(ntile, 16)), gdim(256), 0, c->stream, keep.p, hd.p, m,
                          tile_keep.p, tile_heads.p);
       exclusive_sum_u32_to<I>(c, tile_keep.p, tile_off.p, ntile + 1);
       exclusive_sum_u32_to<I>(c, tile_heads.p, tile_hoff.p, ntile + 1);
@@ -888,7 +893,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
         if (m2) alloc_lists(m2);
       }
       if (!round0 || m2)
-        hipLaunchKernelGGL(active_place_kernel<I>, dim3((unsigned)ntile), dim3(256), 0, c->stream, keep.p, m, tile_keep.p, tile_off.p,
+        hipLaunchKernelGGL(active_place_kernel<I>, gdim((unsigned)ntile), gdim(256), 0, c->stream, keep.p, m, tile_keep.p, tile_off.p,
                            round0 ? (const I *)nullptr : aslot.p, round0 ? out.sa.p : valo.p, round0 ? out.grp.p : newhead.p, out.finbit,
                            aslot2.p, act_i.p, act_grp.p);
       PFP_HIP(hipGetLastError());
@@ -949,16 +954,19 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       uint32_t ng = 0;
       static const uint32_t seg_min_avg = []() { const char *e = getenv("PFP_SEG_MINAVG"); return e ? (uint32_t)atoi(e) : 24u; }();
       static const bool use_small = getenv("PFP_NO_SMALLSEG") == nullptr;
-      if (use_segsort && use_small) small = seg_starts(m) <= kSmallSeg;      // families of a handful of members: placed directly
+      small = use_segsort && use_small && m / ngrp <= kSmallSeg / 4;      // families of a handful of members: placed directly
       if (!small && use_segsort && m >= (1u << 20) && m < 0xFFFFFFFFull && m / ngrp >= seg_min_avg) {
         uint32_t maxlen = 0;
         seg_setup(m, ng, maxlen);
         seg = maxlen <= (1u << 15) && m / ng >= seg_min_avg;
       }
+      if (small) seg_bufs();
+      // both key forms are written when the direct placement is tried: should a group prove too long, the
+      // device-wide sort takes over with the 64-bit keys
       { KScope ks(c, "pfp::build_keys_pivot_kernel", m * (4 + 4 + 4 + 12 + 64));
-        hipLaunchKernelGGL(build_keys_pivot_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, out.bytes, m, h, piv_cap, act_i.p,
-                           act_grp.p, out.sa.p, out.finbit, key.p, (seg || small) ? k32.p : (uint32_t *)nullptr, val.p); }
-      if (small) { seg_small_sort(m); seg_round = true; }
+        hipLaunchKernelGGL(build_keys_pivot_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, out.bytes, m, h, piv_cap, act_i.p,
+                           act_grp.p, out.sa.p, out.finbit, key.p, (seg || small) ? k32.p : (uint32_t *)nullptr, val.p, small ? 1 : 0); }
+      if (small && seg_small_sort(m)) seg_round = true;
       else if (seg) { segsort_pairs_u32<I>(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, kPivBits); seg_round = true; }
       else { sort_pairs_db(c, key, keyo, val, valo, m, 0, nb + kPivBits); std::swap(key, keyo); std::swap(val, valo); }
       out.rounds++;
@@ -969,28 +977,34 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       lazy_pending = false;
       if (m * kLazyRatio > N) {      // most lookups would need the search: scatter the settled ranks once
         KScope ks(c, "pfp::write_back_kernel", N * (4 + 4 + 1 + 4));
-        hipLaunchKernelGGL(scatter_settled_kernel<I>, dim3(cdiv(N, TB)), dim3(TB), 0, c->stream, N, out.sa.p, out.grp.p, keep0.p,
+        hipLaunchKernelGGL(scatter_settled_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, out.sa.p, out.grp.p, keep0.p,
                            out.finbit, out.rank.p);
         if (!out.paybits) out.skeys.release();      // with payload the merge still reads the records from skeys
         out.tab.release();
       }
     }
     repair_ranks(m, aslot.p);                 // a doubling round reads rank[] of arbitrary positions
+    if (active_stale) {
+      hipLaunchKernelGGL(active_ranks_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, act_i.p, act_grp.p, out.rank.p);
+      active_stale = false;
+    }
     const RankViewT<I> L = rank_view(out);
     dbl_round = true;
     if constexpr (!kWide) {
       static const bool use_small = getenv("PFP_NO_SMALLSEG") == nullptr;
-      if (use_segsort && use_small && seg_starts(m) <= kSmallSeg) {
+      if (use_segsort && use_small && ngrp && m / ngrp <= kSmallSeg / 4) {
+        seg_bufs();
         { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
-          hipLaunchKernelGGL(build_keys32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
-        seg_small_sort(m);
-        seg_round = true;
+          hipLaunchKernelGGL(build_keys32_kernel, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
+        seg_round = seg_small_sort(m);
+      }
+      if (seg_round) {
       } else if (use_segsort && m >= (1u << 20) && ngrp && m / ngrp >= 24) {
         uint32_t ng = 0, maxlen = 0;
         seg_setup(m, ng, maxlen);
         if (maxlen <= (1u << 15) && m / ng >= 24) {
           { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
-            hipLaunchKernelGGL(build_keys32_kernel, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
+            hipLaunchKernelGGL(build_keys32_kernel, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
           segsort_pairs_u32<I>(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, bits_for(N));
           seg_round = true;
         }
@@ -1000,12 +1014,12 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       if constexpr (kWide) {
         if (!dkey.p || dkey.n < m) { dkey.alloc(c, m); dkeyo.alloc(c, m); }
         { KScope ks(c, "pfp::build_keys_kernel", m * (8 + 8 + 8 + 24));
-          hipLaunchKernelGGL(build_keys_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p, L, nb, dkey.p, val.p); }
+          hipLaunchKernelGGL(build_keys_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p, L, nb, dkey.p, val.p); }
         sort_pairs_db(c, dkey, dkeyo, val, valo, m, 0, keybits);
         std::swap(dkey, dkeyo); std::swap(val, valo);
       } else {
         { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 4 + 12));
-          hipLaunchKernelGGL(build_keys_kernel<I>, dim3(cdiv(m, TB)), dim3(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p, L, nb, key.p, val.p); }
+          hipLaunchKernelGGL(build_keys_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, act_i.p, act_grp.p, L, nb, key.p, val.p); }
         sort_pairs_db(c, key, keyo, val, valo, m, 0, keybits);
         std::swap(key, keyo); std::swap(val, valo);
       }
@@ -1019,26 +1033,26 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
 
 template <class I>
 __global__ void gather_ranks_kernel(RankViewT<I> L, uint64_t count, const uint64_t *__restrict__ pos, I *__restrict__ out) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   bool settled;
   if (a < count) out[a] = rank_at(L, pos[a], settled);
 }
 template <class I>
 void gather_ranks(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, uint64_t count, I *d_out) {
   if (!count) return;
-  hipLaunchKernelGGL(gather_ranks_kernel<I>, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, rank_view(so), count, d_pos, d_out);
+  hipLaunchKernelGGL(gather_ranks_kernel<I>, gdim(cdiv(count, 256)), gdim(256), 0, c->stream, rank_view(so), count, d_pos, d_out);
   PFP_HIP(hipGetLastError());
 }
 template void gather_ranks<uint32_t>(pfp_ctx *, const SuffixOrderT<uint32_t> &, const uint64_t *, uint64_t, uint32_t *);
 template void gather_ranks<uint64_t>(pfp_ctx *, const SuffixOrderT<uint64_t> &, const uint64_t *, uint64_t, uint64_t *);
 
 static KeyCode dict_key_code(pfp_ctx *c, const uint8_t *bytes, uint64_t N) {
-  DBuf<uint32_t> hist(c, 256);
+  DBuf<unsigned long long> hist(c, 256);
   hist.zero();
-  hipLaunchKernelGGL(byte_histogram_kernel, dim3(std::min<uint64_t>(cdiv64(N, 4096), (uint64_t)c->n_cu * 8)), dim3(256), 0,
+  hipLaunchKernelGGL(byte_histogram_kernel, gdim(std::min<uint64_t>(cdiv64(N, 4096), (uint64_t)c->n_cu * 8)), gdim(256), 0,
                      c->stream, bytes, N, hist.p);
-  std::vector<uint32_t> hh(256);
-  PFP_HIP(hipMemcpyAsync(hh.data(), hist.p, 1024, hipMemcpyDeviceToHost, c->stream));
+  std::vector<uint64_t> hh(256);
+  PFP_HIP(hipMemcpyAsync(hh.data(), hist.p, 2048, hipMemcpyDeviceToHost, c->stream));
   sync(c);
   return make_key_code(hh.data());
 }
@@ -1056,12 +1070,12 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   out.paybits = (pay && !no_payload && kc.kbits + 1 <= 48) ? 16 : 0;
   out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
   { KScope ks(c, "pfp::init_keys_packed_kernel", N * (9 + sizeof(I) + (out.paybits ? 9 : 0)));
-    hipLaunchKernelGGL(init_keys_packed_kernel<I>, dim3((unsigned)cdiv64(N, kKeyPos)), dim3(256), 0, c->stream, bytes, N, kc, slen,
+    hipLaunchKernelGGL(init_keys_packed_kernel<I>, gdim((unsigned)cdiv64(N, kKeyPos)), gdim(256), 0, c->stream, bytes, N, kc, slen,
                        pay ? *pay : SlotPayloadSrc{}, out.paybits, key.p, val.p); }
   if (c->debug) {
     DBuf<unsigned long long> bad(c, 1);
     bad.zero();
-    hipLaunchKernelGGL(check_keys_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, kc, key.p, out.keymask, bad.p);
+    hipLaunchKernelGGL(check_keys_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, bytes, N, kc, key.p, out.keymask, bad.p);
     PFP_HIP(hipMemcpyAsync(c->h_scalars, bad.p, 8, hipMemcpyDeviceToHost, c->stream));
     sync(c);
     PFP_REQUIRE(c->h_scalars[0] == 0, PFP_EHIP, "bit-stream keys differ from packed_key_at at " + std::to_string(c->h_scalars[0]) + " positions");
@@ -1081,7 +1095,7 @@ __global__ void sample_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, ui
   __shared__ uint32_t lut[256];
   lut[threadIdx.x] = kp.lut[threadIdx.x];
   __syncthreads();
-  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t k = BID * 256 + threadIdx.x;
   if (k >= ns) return;
   const uint64_t i = (uint64_t)k * stride;
   key[k] = i < N ? packed_key_at(s, i, kp.kbits, lut) : ~0ull;
@@ -1097,7 +1111,8 @@ __global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restr
                                                           unsigned long long *__restrict__ tile_emits) {
   __shared__ KeyStreamLds L;
   __shared__ unsigned long long wsum[2][4];
-  const uint64_t B0 = (uint64_t)blockIdx.x * kKeyPos;
+  if ((uint64_t)BID * kKeyPos >= N) return;      // a workgroup of the padded last grid row
+  const uint64_t B0 = (uint64_t)BID * kKeyPos;
   const uint64_t k = block_stream_key(L, s, N, kp, slen, B0);
   const uint64_t i = B0 + threadIdx.x;
   unsigned long long cnt = 0, emits = 0;
@@ -1114,15 +1129,15 @@ __global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restr
   if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = cnt; wsum[1][threadIdx.x >> 6] = emits; }
   __syncthreads();
   if (threadIdx.x == 0) {       // per-workgroup sums (one atomic per workgroup on one address would serialise 1.6 M of them)
-    tile_below[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
-    tile_emits[blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    tile_below[BID] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+    tile_emits[BID] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
   }
 }
 __global__ __launch_bounds__(256) void sum2_u64_kernel(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b,
                                                        uint64_t n, unsigned long long *__restrict__ out) {
   __shared__ unsigned long long ws[2][4];
   unsigned long long x = 0, y = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) { x += a[i]; y += b[i]; }
+  for (uint64_t i = (uint64_t)BID * 256 + threadIdx.x; i < n; i += (uint64_t)GDIM * 256) { x += a[i]; y += b[i]; }
   for (int o = 32; o > 0; o >>= 1) { x += __shfl_down(x, o, 64); y += __shfl_down(y, o, 64); }
   if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = x; ws[1][threadIdx.x >> 6] = y; }
   __syncthreads();
@@ -1138,7 +1153,7 @@ __global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__re
   __shared__ uint32_t lut[256];
   lut[threadIdx.x] = kp.lut[threadIdx.x];
   __syncthreads();
-  uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t a = (uint64_t)BID * 256 + threadIdx.x;
   if (a >= n) return;
   const I i = idx[a];
   uint64_t k = packed_key_at(s, i, kp.kbits, lut);
@@ -1161,7 +1176,7 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
     const uint64_t stride = N / ns;
     DBuf<uint64_t> sk(c, ns), sko(c, ns);
     DBuf<uint32_t> sv(c, ns), svo(c, ns);
-    hipLaunchKernelGGL(sample_keys_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, c->stream, bytes, N, stride, ns, kc, sk.p, sv.p);
+    hipLaunchKernelGGL(sample_keys_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, bytes, N, stride, ns, kc, sk.p, sv.p);
     sort_pairs_u64_u32(c, sk.p, sko.p, sv.p, svo.p, ns, 0, 64);
     std::vector<uint64_t> hs(ns);
     PFP_HIP(hipMemcpyAsync(hs.data(), sko.p, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1176,9 +1191,9 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   {
     const uint64_t nblk = cdiv64(N, kKeyPos);
     DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
-    hipLaunchKernelGGL(range_flags_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, bytes, N, kc, slen, klo, khi, khi_open,
+    hipLaunchKernelGGL(range_flags_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, kc, slen, klo, khi, khi_open,
                        count ? *count : SlotPayloadSrc{}, flag.p, tb.p, te.p);
-    hipLaunchKernelGGL(sum2_u64_kernel, dim3((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), dim3(256), 0, c->stream, tb.p, te.p, nblk,
+    hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, tb.p, te.p, nblk,
                        below.p);
   }
   const uint64_t n_mine = count_flags(c, flag.p, N);      // the share's size first: its index list is then exactly that long
@@ -1198,7 +1213,7 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
   if (n_mine) {
     KScope ks(c, "pfp::init_keys_packed_kernel", (uint64_t)n_mine * 17);
-    hipLaunchKernelGGL(init_keys_list_kernel<I>, dim3(cdiv(n_mine, 256)), dim3(256), 0, c->stream, bytes, (uint64_t)n_mine, kc,
+    hipLaunchKernelGGL(init_keys_list_kernel<I>, gdim(cdiv(n_mine, 256)), gdim(256), 0, c->stream, bytes, (uint64_t)n_mine, kc,
                        pay ? *pay : SlotPayloadSrc{}, out.paybits, idx.p, key.p, val.p);
   }
   idx.release();
@@ -1217,7 +1232,7 @@ template void sort_dict_suffixes_range<uint64_t>(pfp_ctx *, const uint8_t *, uin
 template <class I>
 __global__ void gather_slots_range_kernel(RankViewT<I> L, uint64_t klo, uint64_t khi, uint64_t slot_base, uint64_t count,
                                           const uint64_t *__restrict__ pos, uint64_t *__restrict__ out) {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= count) return;
   const uint64_t j = pos[a];
   const uint64_t k = packed_key_at(L.bytes, j, L.kbits, L.lut);
@@ -1228,7 +1243,7 @@ __global__ void gather_slots_range_kernel(RankViewT<I> L, uint64_t klo, uint64_t
 template <class I>
 void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, uint64_t count, uint64_t *d_out) {
   if (!count) return;
-  hipLaunchKernelGGL(gather_slots_range_kernel<I>, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, rank_view(so), so.klo, so.khi,
+  hipLaunchKernelGGL(gather_slots_range_kernel<I>, gdim(cdiv(count, 256)), gdim(256), 0, c->stream, rank_view(so), so.klo, so.khi,
                      so.slot_base, count, d_pos, d_out);
   PFP_HIP(hipGetLastError());
 }
@@ -1241,7 +1256,7 @@ void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrde
   SufGeom g{MODE_PLAIN, N, nullptr};
   DBuf<uint64_t> key(c, N);
   DBuf<I> val(c, N);
-  hipLaunchKernelGGL(init_keys_bytes_kernel<I>, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, bytes, N, key.p, val.p);
+  hipLaunchKernelGGL(init_keys_bytes_kernel<I>, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, bytes, N, key.p, val.p);
   doubling<I>(c, g, key, val, 8, out);
 }
 template void sort_byte_suffixes<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, SuffixOrderT<uint32_t> &);
@@ -1255,19 +1270,19 @@ void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder 
   // the symbol width is measured, not taken on trust (max_sym is only an upper bound for the check)
   DBuf<uint32_t> mx(c, 1);
   mx.zero();
-  hipLaunchKernelGGL(max_u32_kernel, dim3((int)std::min<uint64_t>(cdiv64(N, 256), 1024)), dim3(256), 0, c->stream, sym, N, mx.p);
+  hipLaunchKernelGGL(max_u32_kernel, gdim((int)std::min<uint64_t>(cdiv64(N, 256), 1024)), gdim(256), 0, c->stream, sym, N, mx.p);
   const uint32_t real_max = read_scalar(c, mx.p);
   PFP_REQUIRE(real_max <= max_sym, PFP_EFORMAT, "integer string holds a symbol above its alphabet size");
   const int sb = bits_for(real_max);
   static const bool no_runkeys = getenv("PFP_NO_RUNKEYS") != nullptr;
   if (64 - 2 * sb >= 6 && !no_runkeys) {
     DBuf<uint32_t> v(c, N), pm(c, N);
-    hipLaunchKernelGGL(run_marks_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, sym, (uint32_t)N, v.p);
+    hipLaunchKernelGGL(run_marks_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, (uint32_t)N, v.p);
     inclusive_max_u32(c, v.p, pm.p, N);
-    hipLaunchKernelGGL(init_keys_int_run_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, sym, (uint32_t)N, pm.p, sb, key.p,
+    hipLaunchKernelGGL(init_keys_int_run_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, (uint32_t)N, pm.p, sb, key.p,
                        val.p);
   } else {
-    hipLaunchKernelGGL(init_keys_int_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, sym, N, key.p, val.p);
+    hipLaunchKernelGGL(init_keys_int_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, N, key.p, val.p);
   }
   doubling<uint32_t>(c, g, key, val, 2, out);
 }

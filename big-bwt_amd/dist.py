@@ -61,6 +61,31 @@ def all_gather_var(t, group=None):
     return [o[:s] for o, s in zip(outs, sizes)]
 
 
+def all_to_all_var(parts, group=None):
+    """parts[r] goes to rank r (1-D tensors, same dtype/device, any lengths) -> list: what every rank sent here.
+    nccl (RCCL): one all_to_all_single with the split sizes the ranks announce first; gloo (CPU tests, ranks
+    sharing one GPU): every rank's concatenated send buffer is all-gathered and the own pieces are cut out."""
+    import torch.distributed as dist
+    world, me = dist.get_world_size(group), dist.get_rank(group)
+    backend = dist.get_backend(group)
+    dev, dtype = parts[0].device, parts[0].dtype
+    send_sizes = torch.tensor([p.numel() for p in parts], dtype=torch.int64, device=dev)
+    if backend != "nccl":
+        tables = all_gather_var(send_sizes, group)                     # tables[s][r] = elements s sends to r
+        bufs = all_gather_var(torch.cat(parts) if parts else torch.empty(0, dtype=dtype, device=dev), group)
+        out = []
+        for s_ in range(world):
+            off = int(tables[s_][:me].sum())
+            out.append(bufs[s_][off: off + int(tables[s_][me])])
+        return out
+    recv_sizes = torch.empty_like(send_sizes)
+    dist.all_to_all_single(recv_sizes, send_sizes, group=group)
+    rs, ss = [int(x) for x in recv_sizes.tolist()], [int(x) for x in send_sizes.tolist()]
+    recv = torch.empty(sum(rs), dtype=dtype, device=dev)
+    dist.all_to_all_single(recv, torch.cat(parts).contiguous(), output_split_sizes=rs, input_split_sizes=ss, group=group)
+    return list(torch.split(recv, rs))
+
+
 def slice_bounds(n_out, rank, size):
     """output range [lo,hi) of rank `rank`: equal split of the n+1 BWT positions"""
     return (n_out * rank) // size, (n_out * (rank + 1)) // size
@@ -97,9 +122,13 @@ class _Step:
 
 
 # ----------------------------------------------------------------------------- the algorithm
-def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True):
+def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True, dedup="alltoall"):
     """Generator.  `shard`: 1-D uint8 device tensor, this rank's byte range of the text.
-    Yields ('allgather', tensor) and receives the list of all ranks' tensors.
+    Yields ('allgather', tensor) and receives the list of all ranks' tensors, or ('alltoall', [tensor per rank])
+    and receives what every rank sent to this one.
+    dedup: "alltoall" - every distinct word is owned by the rank its hash points at (all-to-all of words, all-to-all
+    of the answers, allgatherv of distinct words only); "allgather" - every rank gathers all local dictionaries and
+    deduplicates the union itself (the simple form, kept for comparison).
     Returns dict(bwt=slice tensor, sa=slice tensor|None, lo, hi, n_total, stats) plus, as the flags ask, the
     rank's pieces of the reference's output files as device byte tensors with their file offsets:
     sa5 / sa5_off (.sa, 5-byte ints, pfbwt.cpp:159-160), ssa / ssa_off, esa / esa_off (.ssa/.esa pairs,
@@ -160,18 +189,58 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
     d_sai = torch.empty(info["phrases"], dtype=torch.int64, device=dev) if want_sai else None
     ctx.dist_export_local(d_dict.data_ptr(), d_occ.data_ptr(), d_last.data_ptr(), d_sai.data_ptr() if want_sai else None)
     del local
-    # --- global dictionary from the union of the local ones
-    dicts = yield ("allgather", d_dict)
-    occs = yield ("allgather", d_occ)
-    union = torch.cat(dicts).contiguous()
-    union_occ = torch.cat(occs).contiguous()
-    word_base = sum(o.numel() for o in occs[:rank])
+    # --- global dictionary
     d_sym = torch.empty(info["phrases"], dtype=torch.int32, device=dev)
-    wslot = torch.zeros(union_occ.numel(), dtype=torch.int64, device=dev)
-    torch.cuda.synchronize(dev)
     parts = size if shard_sa else 1
-    ginfo = step.run(lambda: ctx.dist_global_sort(union.data_ptr(), union.numel(), union_occ.data_ptr(), union_occ.numel(),
-                                                  rank if parts > 1 else 0, parts, wslot.data_ptr()))
+    word_base = 0
+    if dedup == "alltoall":
+        # exchange A: words travel to the owner of their hash class, come back as global ids; only
+        # distinct words are gathered
+        del d_dict, d_occ
+        counts = step.run(lambda: ctx.dist_partition_words(size)) or [(0, 0)] * size
+        sendb = torch.empty(sum(b for _, b in counts) + 1, dtype=torch.uint8, device=dev)
+        sendo = torch.empty(sum(k for k, _ in counts) + 1, dtype=torch.int32, device=dev)
+        if step.err is None:
+            step.run(lambda: ctx.dist_export_partition(sendb.data_ptr(), sendo.data_ptr()))
+        st = yield ("allgather", step.status())
+        step.check(st, "word partition")
+        wsplit, bsplit = [k for k, _ in counts], [b for _, b in counts]
+        recvb = yield ("alltoall", list(torch.split(sendb[: sum(bsplit)], bsplit)))
+        recvo = yield ("alltoall", list(torch.split(sendo[: sum(wsplit)], wsplit)))
+        rb, ro = torch.cat(recvb).contiguous(), torch.cat(recvo).contiguous()
+        pid = torch.empty(ro.numel() + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        own = step.run(lambda: ctx.dist_owner_dedup(rb.data_ptr(), rb.numel(), ro.data_ptr(), ro.numel(), pid.data_ptr())) or (0, 0)
+        ownb = torch.empty(own[1] + 1, dtype=torch.uint8, device=dev)
+        owno = torch.empty(own[0] + 1, dtype=torch.int32, device=dev)
+        if step.err is None:
+            step.run(lambda: ctx.dist_export_owned(ownb.data_ptr(), owno.data_ptr()))
+        owned = yield ("allgather", torch.tensor([own[0], int(step.status()[0])], dtype=torch.int64, device=dev))
+        step.check([t[1:2] for t in owned], "owner dedup")
+        base = sum(int(t[0]) for t in owned[:rank])
+        answers = yield ("alltoall", list(torch.split(pid[: ro.numel()] + base, [t.numel() for t in recvo])))
+        gid_sent = torch.cat(answers).contiguous()          # owner order = the order this rank exported its words in
+        dict_parts = yield ("allgather", ownb[: own[1]].contiguous())
+        occ_parts = yield ("allgather", owno[: own[0]].contiguous())
+        union = torch.cat(dict_parts).contiguous()
+        union_occ = torch.cat(occ_parts).contiguous()
+        wslot = torch.zeros(union_occ.numel(), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        sort_call = lambda part, nparts: ctx.dist_global_sort_distinct(union.data_ptr(), union.numel(), union_occ.data_ptr(), union_occ.numel(),
+                                                                       gid_sent.data_ptr(), part, nparts, wslot.data_ptr())
+        del recvb, recvo, rb, ro, sendb, sendo, dict_parts, occ_parts
+    else:
+        dicts = yield ("allgather", d_dict)
+        occs = yield ("allgather", d_occ)
+        union = torch.cat(dicts).contiguous()
+        union_occ = torch.cat(occs).contiguous()
+        word_base = sum(o.numel() for o in occs[:rank])
+        wslot = torch.zeros(union_occ.numel(), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        sort_call = lambda part, nparts: ctx.dist_global_sort(union.data_ptr(), union.numel(), union_occ.data_ptr(), union_occ.numel(),
+                                                              part, nparts, wslot.data_ptr())
+        del dicts, occs, d_dict, d_occ
+    ginfo = step.run(lambda: sort_call(rank if parts > 1 else 0, parts))
     ok = ginfo is not None
     status = yield ("allgather", torch.tensor([1 if (ok and ginfo["complete"]) else 0, ginfo["emits"] if ok else 0, int(step.status()[0])],
                                               dtype=torch.int64, device=dev))
@@ -181,8 +250,7 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
         parts = 1
         wslot.zero_()
         torch.cuda.synchronize(dev)          # the library works on its own stream, not on torch's
-        ginfo = step.run(lambda: ctx.dist_global_sort(union.data_ptr(), union.numel(), union_occ.data_ptr(), union_occ.numel(), 0, 1,
-                                                      wslot.data_ptr()))
+        ginfo = step.run(lambda: sort_call(0, 1))
         st = yield ("allgather", step.status())
         step.check(st, "replicated dictionary suffix sort")
     emits = [int(s[1]) for s in status]
@@ -196,7 +264,7 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
         step.run(lambda: ctx.dist_global_finish(wslot.data_ptr(), 1, word_base, d_sym.data_ptr()))
     st = yield ("allgather", step.status())
     step.check(st, "word ranking")
-    del union, union_occ, dicts, occs, d_dict, d_occ, wslot, wslots
+    del union, union_occ, wslot, wslots
     # --- the whole parse everywhere
     syms = yield ("allgather", d_sym)
     lasts = yield ("allgather", d_last)
@@ -253,7 +321,7 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
             if key in out:
                 out[key + "_off"] = 10 * sum(int(t[j]) for t in ks[:rank])
     out["stats"] = dict(local=info, glob=ginfo, phrases_total=int(sym_all.numel()), shard_bytes=n_shard, extra_triggers=len(extra),
-                        sa_shares=parts)
+                        sa_shares=parts, dedup=dedup)
     return out
 
 
@@ -267,44 +335,50 @@ def write_outputs(ctx, path, res):
             ctx.pwrite_dev(path + ext, res[key + "_off"], res[key].data_ptr(), res[key].numel())
 
 
-def run(ctx, shard, w=10, p=100, flags=0, halo=DEFAULT_HALO, group=None, shard_sa=True):
+def run(ctx, shard, w=10, p=100, flags=0, halo=DEFAULT_HALO, group=None, shard_sa=True, dedup="alltoall"):
     """Drive `phases` with torch.distributed (backend nccl == RCCL on ROCm; gloo works for CPU tests of the plumbing)."""
     import torch.distributed as dist
     rank, size = dist.get_rank(group), dist.get_world_size(group)
-    gen = phases(ctx, shard, rank, size, w, p, flags, halo, shard_sa)
+    gen = phases(ctx, shard, rank, size, w, p, flags, halo, shard_sa, dedup)
     reply = None
     try:
         while True:
             kind, payload = gen.send(reply)
-            assert kind == "allgather"
-            reply = all_gather_var(payload, group)
-            if payload.is_cuda:
-                torch.cuda.synchronize(payload.device)
+            if kind == "allgather":
+                reply = all_gather_var(payload, group)
+            else:
+                assert kind == "alltoall"
+                reply = all_to_all_var(payload, group)
+            if shard.is_cuda:
+                torch.cuda.synchronize(shard.device)
     except StopIteration as fin:
         return fin.value
 
 
-def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True):
+def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True, dedup="alltoall"):
     """Run R virtual ranks in one process (ctxs[r], shards[r] may all live on one GPU): every
     collective is served by plain concatenation.  Used by the GPU tests to check the distributed
     chain bit for bit against the single-GPU chain."""
     size = len(shards)
-    gens = [phases(ctxs[r], shards[r], r, size, w, p, flags, halo, shard_sa) for r in range(size)]
+    gens = [phases(ctxs[r], shards[r], r, size, w, p, flags, halo, shard_sa, dedup) for r in range(size)]
     replies = [None] * size
     results = [None] * size
     live = set(range(size))
     while live:
-        reqs = {}
+        reqs, kinds = {}, set()
         for r in sorted(live):
             try:
                 kind, payload = gens[r].send(replies[r])
-                assert kind == "allgather"
+                kinds.add(kind)
                 reqs[r] = payload
             except StopIteration as fin:
                 results[r] = fin.value
         live = set(reqs)
         if live:
-            assert len(live) == size, "ranks fell out of step"
-            gathered = [reqs[r] for r in range(size)]
-            replies = [list(gathered) for _ in range(size)]
+            assert len(live) == size and len(kinds) == 1, "ranks fell out of step"
+            if kinds == {"allgather"}:
+                gathered = [reqs[r] for r in range(size)]
+                replies = [list(gathered) for _ in range(size)]
+            else:
+                replies = [[reqs[s_][r] for s_ in range(size)] for r in range(size)]
     return results

@@ -229,10 +229,11 @@ int main(int argc, char **argv) {
     pfp_parse_result_free(&pr);
     free(ilist); free(bwlast); free(bwsai);
   } else {
-    pfp_bwt_result br;
-    printf("==== Parsing, BWT of parsing, final BWT on the GPU. Command: pfp_bigbwt(%s, -w %d -p %llu%s%s%s)\n", input, w,
+    /* the text (an mmap of the input) is streamed to the GPU in chunks, the outputs are streamed from HBM straight
+     * into input.bwt / .sa / .ssa / .esa: no output is held in host memory */
+    printf("==== Parsing, BWT of parsing, final BWT on the GPU. Command: pfp_bigbwt_files(%s, -w %d -p %llu%s%s%s)\n", input, w,
            p, s ? " -s" : "", e ? " -e" : "", S ? " -S" : "");
-    rc = pfp_bigbwt(ctx, text, n, w, p, flags, &br);
+    rc = pfp_bigbwt_files(ctx, text, n, w, p, flags, input, NULL);
     if (rc) goto fail;
     pfp_stats st;
     pfp_get_stats(ctx, &st);
@@ -245,11 +246,7 @@ int main(int argc, char **argv) {
       printf("  GPU ms: scan %.2f phrases %.2f dictSA %.2f parseSA %.2f merge %.2f total %.2f\n", st.ms_scan,
              st.ms_phrases, st.ms_sa_dict, st.ms_sa_parse, st.ms_merge, st.ms_total);
     if (st.n != n) fprintf(stderr, "Invalid char found in input file: no additional chars will be read\n");
-    status |= write_file(input, "bwt", br.bwt, br.bwt_size);
-    if (S) status |= write_file(input, "sa", br.sa, br.sa_bytes);
-    if (s) status |= write_file(input, "ssa", br.ssa, br.ssa_bytes);
-    if (e) status |= write_file(input, "esa", br.esa, br.esa_bytes);
-    pfp_bwt_result_free(&br);
+    fprintf(logf, "Index width: %llu bits\n", (unsigned long long)st.index_bits);      /* the reference's 32- / 64-bit executables (bigbwt:109-151) */
     printf("Elapsed time: %.4f\n", now_s() - start);
   }
   printf("Total construction time: %.4f\n", now_s() - start0);
@@ -263,14 +260,18 @@ int main(int argc, char **argv) {
   if (check) {   /* bigbwt:177-194: whole-text suffix array -> .Bwt, then compare */
     start = now_s();
     printf("==== Computing BWT using the whole-text suffix array. Command: pfp_sacak(%s)\n", input);
+    /* simplebwt below 2^32 - 16 bytes, simplebwt64 (64-bit suffix array entries) above (bigbwt:177-182) */
+    const int wide = n + 1 >= 0xFFFFFFF0ull;
     uint8_t *t0 = malloc(n + 1);
-    uint32_t *SA = malloc((n + 1) * sizeof *SA);
+    uint32_t *SA = wide ? NULL : malloc((n + 1) * sizeof *SA);
+    uint64_t *SA64 = wide ? malloc((n + 1) * sizeof *SA64) : NULL;
     uint8_t *B = malloc(n + 1);
-    if (!t0 || !SA || !B || n + 1 >= 0xFFFFFFF0ull) { fprintf(stderr, "-c: input too large\n"); status = 1; goto done; }
+    if (!t0 || (!SA && !SA64) || !B) { fprintf(stderr, "-c: out of memory\n"); status = 1; goto done; }
     memcpy(t0, text, n); t0[n] = 0;
-    rc = pfp_sacak(ctx, t0, SA, n + 1);
+    rc = wide ? pfp_sacak64(ctx, t0, SA64, n + 1) : pfp_sacak(ctx, t0, SA, n + 1);
     if (rc) goto fail;
-    for (uint64_t i = 0; i <= n; i++) B[i] = SA[i] ? t0[SA[i] - 1] : 0;   /* simplebwt.c:80-93 */
+    for (uint64_t i = 0; i <= n; i++) { const uint64_t v = wide ? SA64[i] : SA[i]; B[i] = v ? t0[v - 1] : 0; }   /* simplebwt.c:80-93 */
+    free(SA64);
     status |= write_file(input, "Bwt", B, n + 1);
     printf("Elapsed time: %.4f\n", now_s() - start);
     char nm[4096];

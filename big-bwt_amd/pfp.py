@@ -29,9 +29,10 @@ ERRORS = {0: "PFP_OK", -1: "PFP_EINVAL", -2: "PFP_ENODEV", -3: "PFP_EHIP", -4: "
 # every symbol include/pfpgpu.h declares
 SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror", "pfp_version", "pfp_ctx_stream",
            "pfp_free", "pfp_debug_check", "pfp_get_mem_stats", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak", "pfp_sacak_int64", "pfp_sacak64", "pfp_gsacak64",
-           "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_dev", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
+           "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_files", "pfp_bigbwt_dev", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
            "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
-           "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_merge", "pfp_dist_release"]
+           "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_partition_words", "pfp_dist_export_partition",
+           "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_release"]
 
 
 class PfpError(RuntimeError):
@@ -317,6 +318,14 @@ class Context:
                                         C.c_int(flags), C.byref(r)))
         return self._bwt_result(r)
 
+    def bigbwt_files(self, text, base, w=10, p=100, flags=0):
+        """host text in, <base>.bwt/.sa/.ssa/.esa out (streamed from HBM); returns the sizes written"""
+        t = _arr(text, np.uint8)
+        sizes = (C.c_uint64 * 4)()
+        self._check(self.lib.pfp_bigbwt_files(self._h, _ptr(t, C.c_uint8), C.c_uint64(len(t)), C.c_int(w), C.c_uint64(p),
+                                              C.c_int(flags), C.c_char_p(os.fsencode(base)), sizes))
+        return dict(bwt=int(sizes[0]), sa=int(sizes[1]), ssa=int(sizes[2]), esa=int(sizes[3]))
+
     # -- bigbwt chain, device-resident (raw device pointers, e.g. torch tensor.data_ptr())
     def bigbwt_dev(self, d_text_ptr, n, d_bwt_ptr, d_sa_ptr=None, w=10, p=100, flags=0):
         used = C.c_uint64()
@@ -375,6 +384,33 @@ class Context:
         self._check(self.lib.pfp_dist_global_sort(self._h, C.c_void_p(d_union), C.c_uint64(union_bytes), C.c_void_p(d_union_occ),
                                                   C.c_uint64(n_union), C.c_uint32(part), C.c_uint32(parts), C.c_void_p(d_wslot_out),
                                                   info))
+        return dict(words=int(info[0]), dict_bytes=int(info[1]), rounds=int(info[2]), complete=bool(info[3]), slots=int(info[4]),
+                    slot_base=int(info[5]), emits=int(info[6]), index_bits=int(info[7]))
+
+    def dist_partition_words(self, parts):
+        """-> [(words, bytes)] this rank sends to every owner (hash-partitioned dedup)"""
+        cnt = (C.c_uint64 * (2 * parts))()
+        self._check(self.lib.pfp_dist_partition_words(self._h, C.c_uint32(parts), cnt))
+        return [(int(cnt[2 * o]), int(cnt[2 * o + 1])) for o in range(parts)]
+
+    def dist_export_partition(self, d_bytes, d_occ):
+        self._check(self.lib.pfp_dist_export_partition(self._h, C.c_void_p(d_bytes), C.c_void_p(d_occ)))
+
+    def dist_owner_dedup(self, d_bytes, nbytes, d_occ, n_words, d_pid_out):
+        out = (C.c_uint64 * 2)()
+        vp = lambda x: C.c_void_p(x) if x else None
+        self._check(self.lib.pfp_dist_owner_dedup(self._h, vp(d_bytes), C.c_uint64(nbytes), vp(d_occ), C.c_uint64(n_words), vp(d_pid_out), out))
+        return int(out[0]), int(out[1])
+
+    def dist_export_owned(self, d_bytes, d_occ):
+        vp = lambda x: C.c_void_p(x) if x else None
+        self._check(self.lib.pfp_dist_export_owned(self._h, vp(d_bytes), vp(d_occ)))
+
+    def dist_global_sort_distinct(self, d_dict, dict_bytes, d_occ, n_words, d_gid_sent, part, parts, d_wslot_out):
+        info = (C.c_uint64 * 8)()
+        self._check(self.lib.pfp_dist_global_sort_distinct(self._h, C.c_void_p(d_dict), C.c_uint64(dict_bytes), C.c_void_p(d_occ),
+                                                           C.c_uint64(n_words), C.c_void_p(d_gid_sent), C.c_uint32(part), C.c_uint32(parts),
+                                                           C.c_void_p(d_wslot_out), info))
         return dict(words=int(info[0]), dict_bytes=int(info[1]), rounds=int(info[2]), complete=bool(info[3]), slots=int(info[4]),
                     slot_base=int(info[5]), emits=int(info[6]), index_bits=int(info[7]))
 

@@ -123,8 +123,10 @@ WORKLOADS = {
                  desc="1024x mutated yeast-shaped FASTA (~12.6 GB; the north star's >= 10 GB repetitive input on one GPU), BWT only"),
     "huge_s": dict(G=12_100_020, C=1024, r=1e-3, nblocks=[], w=10, p=100, flags=2, seed=3,
                    desc="1024x mutated yeast-shaped FASTA (~12.6 GB; the north star's >= 10 GB repetitive input on one GPU), BWT + -s sampled SA"),
-    "wide": dict(G=12_100_020, C=300, r=1e-2, nblocks=[], w=10, p=100, flags=0, seed=3,
-                 desc="300x yeast-shaped FASTA at 1 % SNPs (~3.7 GB): dictionary > 4 GiB, exercises the 64-bit index build"),
+    "wide": dict(G=12_100_020, C=360, r=3e-2, nblocks=[], w=10, p=100, flags=0, seed=3,
+                 desc="360x yeast-shaped FASTA at 3 % SNPs (~4.4 GB; nearly every phrase is new): dictionary > 4 GiB, exercises the 64-bit index build"),
+    "wide31": dict(G=12_100_020, C=200, r=3e-2, nblocks=[], w=10, p=100, flags=0, seed=3,
+                   desc="200x yeast-shaped FASTA at 3 % SNPs (~2.5 GB): dictionary between 2^31 and 2^32 bytes (32-bit indices without a spare bit)"),
     "c4s": dict(G=12_100_020, C=16, r=1e-3, nblocks=[], w=10, p=100, flags=1, seed=3,
                 desc="BASELINE configs[3] parameters (-w 10 -p 100 -S, full SA) on a 16-copy, 0.2 GB stand-in (parity probe, not a reportable number)"),
     "c5s": dict(G=12_100_020, C=16, r=1e-3, nblocks=[], w=12, p=200, flags=2, seed=3,

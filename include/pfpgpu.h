@@ -139,6 +139,13 @@ void pfp_bwt_result_free(pfp_bwt_result *r);
 int pfp_bigbwt(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags,
                pfp_bwt_result *out);
 
+/* File to files: like pfp_bigbwt, but the outputs are streamed from HBM into <base>.bwt and, as the flags ask,
+ * <base>.sa / .ssa / .esa (created or truncated) instead of being returned: what the `bigbwt` driver calls.  `text`
+ * may be an mmap of the input file: it is read once, front to back, in chunks.  out_bytes (may be NULL) = the sizes
+ * written {bwt, sa, ssa, esa}. */
+int pfp_bigbwt_files(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags,
+                     const char *base, uint64_t out_bytes[4]);
+
 /* Device-resident variant: d_text is a device pointer to n bytes; d_bwt must hold n+1 bytes.
  * Optional device outputs (may be NULL unless the flag is set):
  *   d_sa   u64[n+1]  SA value per BWT position (d_sa[0] = n), flags & (SA|SSA|ESA).  With PFP_FLAG_SA every entry is
@@ -252,6 +259,29 @@ int pfp_dist_global_sort(pfp_ctx *ctx, const void *d_union, uint64_t union_bytes
                          uint64_t n_union, uint32_t part, uint32_t parts, void *d_wslot_out, uint64_t out_info[8]);
 int pfp_dist_global_finish(pfp_ctx *ctx, const void *d_wslot_all, uint32_t parts, uint64_t my_word_base,
                            void *d_sym_out);
+/* Hash-partitioned deduplication (the exchange SURVEY.md 8e calls A; the reference's threaded parser shards its
+ * maps by `hash % (3 N)`, pscan.cpp:137-205): every distinct word is owned by the rank its identity hash points
+ * at, so the union of the local dictionaries is deduplicated in `parts` disjoint pieces and only distinct words
+ * are gathered.  Between the calls the caller runs an all-to-all of (words, occ), an all-to-all of the answers
+ * and an allgatherv of the owners' distinct words (dist.py):
+ *   pfp_dist_partition_words      : counts[2*o], counts[2*o+1] = words / bytes (one 0x01 per word included) this
+ *                                   rank sends to owner o
+ *   pfp_dist_export_partition     : the local words (each + 0x01) and their occ, grouped by owner, owner 0 first
+ *   pfp_dist_owner_dedup          : d_bytes/d_occ = what all ranks sent to this owner, back to back in rank order;
+ *                                   d_pid_out[u] = index of received word u among this owner's distinct words;
+ *                                   out = {distinct words, their bytes}
+ *   pfp_dist_export_owned         : the owner's distinct words (each + 0x01) and their summed occ
+ *   pfp_dist_global_sort_distinct : as pfp_dist_global_sort, on the gathered owner pieces (owner 0 first, no
+ *                                   further dedup); d_gid_sent[k] = global id (owner base + pid answer) of the k-th
+ *                                   word this rank exported; pfp_dist_global_finish then needs no my_word_base */
+int pfp_dist_partition_words(pfp_ctx *ctx, uint32_t parts, uint64_t *counts);
+int pfp_dist_export_partition(pfp_ctx *ctx, void *d_bytes, void *d_occ);
+int pfp_dist_owner_dedup(pfp_ctx *ctx, const void *d_bytes, uint64_t nbytes, const void *d_occ, uint64_t n_words,
+                         void *d_pid_out, uint64_t out[2]);
+int pfp_dist_export_owned(pfp_ctx *ctx, void *d_bytes, void *d_occ);
+int pfp_dist_global_sort_distinct(pfp_ctx *ctx, const void *d_dict, uint64_t dict_bytes, const void *d_occ, uint64_t n_words,
+                                  const void *d_gid_sent, uint32_t part, uint32_t parts, void *d_wslot_out,
+                                  uint64_t out_info[8]);
 int pfp_dist_merge(pfp_ctx *ctx, const void *d_sym, uint64_t P, const void *d_last, const void *d_sai, int flags,
                    uint64_t n_total, uint64_t out_lo, uint64_t out_hi, void *d_bwt_slice, void *d_sa_slice);
 void pfp_dist_release(pfp_ctx *ctx);

@@ -163,7 +163,10 @@ def test_distributed_chain_matches_oracle(O, pkg, R, shard_sa, nblock):
             shards = [torch.from_numpy(text[cuts[r]:cuts[r + 1]].copy()).to(dev) for r in range(R)]
             for c in ctxs:
                 c.set_max_phrase(2000)
-            res = d.simulate(ctxs, shards, 10, 100, flags, halo=4096, shard_sa=shard_sa)
+            # the replicated-sort variant also takes the simple union dedup (allgather of whole local dictionaries), the
+            # sharded one the hash-partitioned all-to-all
+            res = d.simulate(ctxs, shards, 10, 100, flags, halo=4096, shard_sa=shard_sa, dedup="alltoall" if shard_sa else "allgather")
+            assert res[0]["stats"]["dedup"] == ("alltoall" if shard_sa else "allgather")
             assert res[0]["stats"]["extra_triggers"] >= (1 if nblock else 0)
             shares = {r["stats"]["sa_shares"] for r in res}
             # debugging switches that turn pivot rounds off make every range fall back to the replicated sort
