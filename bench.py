@@ -108,7 +108,7 @@ def main():
     text = synth.workload_text_torch(dev, wl_name, variant=variant)
     n = text.numel()
     bwt = torch.empty(n + 1 + 16, dtype=torch.uint8, device=dev)
-    sa = torch.empty(n + 1, dtype=torch.int64, device=dev) if (flags and not collection) else None
+    torch.cuda.empty_cache()          # the generator's temporaries go back to the driver
     torch.cuda.synchronize()
 
     ctx = pkg.Context(local_rank)
@@ -116,31 +116,23 @@ def main():
     last = {}
     outbuf = {}          # reference-format outputs in HBM: sa5 / ssa / esa (sized by the first warm-up step)
 
-    def finish_formats(n_used, sizing=False):
-        """what pfbwt writes besides .bwt, from the device-resident BWT / SA values (inside the timed step)"""
-        n_out = n_used + 1
-        if flags & pkg.FLAG_SA:
-            if sizing:
-                outbuf["sa"] = torch.empty(5 * n_used + 16, dtype=torch.uint8, device=dev)
-            ctx.pack5_dev(sa.data_ptr() + 8, n_used, outbuf["sa"].data_ptr())
-            last["sa_bytes"] = 5 * n_used
-        for key, flag, run_end in (("ssa", pkg.FLAG_SSA, False), ("esa", pkg.FLAG_ESA, True)):
-            if not flags & flag:
-                continue
-            if sizing:
-                k = ctx.sample_runs_dev(bwt.data_ptr(), sa.data_ptr(), n_out, 0, -1, -1, run_end)
-                outbuf[key] = torch.empty(10 * k + 16, dtype=torch.uint8, device=dev)
-                outbuf[key + "_cap"] = k
-            k = ctx.sample_runs_dev(bwt.data_ptr(), sa.data_ptr(), n_out, 0, -1, -1, run_end, outbuf[key].data_ptr(), outbuf[key + "_cap"])
-            last[key + "_bytes"] = 10 * k
-
     def step(sizing=False):
+        """one pass of the hot path: device text -> .bwt bytes in `bwt` and, as the flags ask, the .sa / .ssa / .esa bytes in
+        device buffers of the library (SA values never leave the call: pfp_bigbwt_formats_dev)"""
         if collection:
             last["r"] = dist_mod_pfp.run(ctx, text, w, p, flags)
             return n
-        used = ctx.bigbwt_dev(text.data_ptr(), n, bwt.data_ptr(), sa.data_ptr() if flags else None, w, p, flags)
+        for ptr, _ in outbuf.values():
+            ctx.dev_free(ptr)
+        outbuf.clear()
+        if flags:
+            used, outs = ctx.bigbwt_formats_dev(text.data_ptr(), n, bwt.data_ptr(), w, p, flags)
+            outbuf.update(outs)
+            for k, (_, nb) in outs.items():
+                last[k + "_bytes"] = nb
+        else:
+            used = ctx.bigbwt_dev(text.data_ptr(), n, bwt.data_ptr(), None, w, p, 0)
         last["n_used"] = used
-        finish_formats(used, sizing)
         return used
 
     def barrier():
@@ -214,7 +206,7 @@ def main():
                 digests = {"text": sha_dev(text) == gold["text_sha256"], "bwt": sha_dev(bwt[: n + 1]) == gold["bwt_sha256"]}
                 for key in ("sa", "ssa", "esa"):
                     if key in outbuf and key + "_sha256" in gold:
-                        digests[key] = sha_dev(outbuf[key][: last[key + "_bytes"]]) == gold[key + "_sha256"]
+                        digests[key] = hashlib.sha256(ctx.fetch_dev(*outbuf[key]).tobytes()).hexdigest() == gold[key + "_sha256"]
 
         # ---- roofline: per-kernel device time measured live (HIP events on the ctx stream, timed steps)
         rows = []
@@ -329,7 +321,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "name": wl_name, "bytes_per_gpu": n, "w": w, "p": p, "flags": flags,
                        "phrases": st["n_phrases"], "words": st["n_words"], "dict_bytes": st["dict_size"],
-                       "outputs_in_timed_step": ["bwt"] + [k for k in ("sa", "ssa", "esa") if k in outbuf],
+                       "outputs_in_timed_step": ["bwt"] + [k for k in ("sa", "ssa", "esa") if k in outbuf or (collection and ("sa5" if k == "sa" else k) in last.get("r", {}))],
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{world} shards of one collection: halo + allgatherv of dictionaries and parse over RCCL, "
                                         f"suffix array of the global dictionary sharded by key range, every rank emits the BWT "

@@ -73,7 +73,9 @@ template <class I> struct IdxTraits;
 template <> struct IdxTraits<uint32_t> { using DKey = uint64_t; static constexpr uint32_t kNone = 0xFFFFFFFFu; static constexpr uint32_t kTop = 0x80000000u; };
 template <> struct IdxTraits<uint64_t> { using DKey = unsigned __int128; static constexpr uint64_t kNone = ~0ull; static constexpr uint64_t kTop = 1ull << 63; };
 // true when a dictionary of dsize bytes needs (or PFP_FORCE_IDX64 asks for) the wide build
-inline bool use_wide_index(const pfp_ctx *c, uint64_t dsize) { return c->force_wide || dsize >= 0x7FFFFFF0ull; }
+// (the reference goes to its 64-bit build at 2^31 - 4 already, bigbwt:130; unsigned 32-bit positions reach twice as far, and
+// the wide build needs 8 bytes where this one needs 4)
+inline bool use_wide_index(const pfp_ctx *c, uint64_t dsize) { return c->force_wide || dsize >= 0xFFFFFFF0ull; }
 
 template <class I>
 struct SuffixOrderT {

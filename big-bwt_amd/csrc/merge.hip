@@ -649,11 +649,12 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
 // BWT(P) position over all lists): those and the group's two ends are the only places a run can start or end.
 // Groups where no char dominates and that fit the LDS kernels keep the old path (fallback list).
 struct HardGroupInfo { uint64_t g; uint64_t E; uint32_t k; uint32_t minor; };
+struct MinorMember { uint64_t g; uint32_t k, m; };      // member m (of k) of the hard group at head slot g does not carry the majority char
 template <class I>
 __global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, const I *__restrict__ heads, uint64_t nH,
                                                             uint8_t *__restrict__ gmaj, HardGroupInfo *__restrict__ info,
                                                             uint32_t *__restrict__ minor_cnt, uint8_t *__restrict__ fallback,
-                                                            unsigned long long *__restrict__ chars_total) {
+                                                            unsigned long long *__restrict__ chars_total, uint32_t *__restrict__ minor_members) {
   const uint64_t h = (uint64_t)BID * 256 + threadIdx.x;
   unsigned long long mychars = 0;
   if (h < nH) {
@@ -687,13 +688,22 @@ __global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, con
   if (n2 > mnn) { mc = c2; mnn = n2; }
   if (n3 > mnn) { mc = c3; mnn = n3; }
   const uint64_t minor = E - mnn;
-  // fallback: no dominating char and small enough for the LDS kernels; or too many distinct chars / a minority
-  // count that does not fit the 32-bit list
-  const bool fb = many || minor >= 0x7FFFFFFFull || (E <= (uint64_t)kHardLds && minor * 4 > E) || a.dbg_mode != 0;
+  uint32_t mm = 0;                               // members that do not carry the majority char, and the longest of their lists
+  uint64_t mm_max = 0;
+  prev = base;
+  for (uint64_t m = 0; m < k; m++) {
+    const uint64_t nxt = slot_off(a, g + m + 1);
+    if ((uint32_t)fix_char(a.pc[g + m]) != mc) { mm++; mm_max = nxt - prev > mm_max ? nxt - prev : mm_max; }
+    prev = nxt;
+  }
+  // fallback (the kernels that rank every occurrence): no dominating char, a long minority list (its occurrences
+  // would be ranked one after the other), too many distinct chars
+  const bool fb = many || minor * 4 > E || mm_max > 1024 || a.dbg_mode != 0;
   const bool in_slice = !(base + E <= a.out_lo || base >= a.out_hi);
   fallback[h] = (fb && in_slice) ? 1 : 0;
   gmaj[g] = fb ? 0 : (uint8_t)mc;
   minor_cnt[h] = (fb || !in_slice) ? 0u : (uint32_t)minor;
+  minor_members[h] = (fb || !in_slice) ? 0u : mm;
   info[h] = HardGroupInfo{g, E, (uint32_t)k, (uint32_t)(fb ? 0 : minor)};
   if (!fb && in_slice) mychars = E;
   }
@@ -701,70 +711,93 @@ __global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, con
   if ((threadIdx.x & 63) == 0 && mychars) atomicAdd(chars_total, mychars);
 }
 
-// one thread per minority occurrence (flattened over the groups by the prefix sums of minor_cnt)
+// the minority members of all groups, laid end to end (offsets = prefix sums of their count per group)
 template <class I>
-__global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const HardGroupInfo *__restrict__ info, uint64_t nH,
-                                                         const uint64_t *__restrict__ minor_off, uint64_t total,
-                                                         const uint8_t *__restrict__ gmaj) {
-  for (uint64_t q = (uint64_t)BID * 256 + threadIdx.x; q < total; q += (uint64_t)GDIM * 256) {
-    uint64_t lo = 0, hi = nH;               // minor_off[lo] <= q < minor_off[hi]
-    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (minor_off[mid] <= q) lo = mid; else hi = mid; }
-    const HardGroupInfo gi = info[lo];
-    const uint64_t g = gi.g;
-    const uint32_t k = gi.k;
-    const uint32_t maj = gmaj[g];
-    uint64_t ord = q - minor_off[lo];       // ordinal among the group's minority occurrences, in member order
-    // own member and index
-    uint32_t me = 0, j = 0;
-    uint64_t prev = slot_off(a, g);
-    const uint64_t base = prev;
-    for (uint32_t m = 0; m < k; m++) {
-      const uint64_t nxt = slot_off(a, g + m + 1);
-      const uint64_t occ = nxt - prev;
-      prev = nxt;
-      if ((uint32_t)fix_char(a.pc[g + m]) == maj) continue;
-      if (ord < occ) { me = m; j = (uint32_t)ord; break; }
-      ord -= occ;
+__global__ __launch_bounds__(256) void hard_minor_fill_kernel(MergeArgsT<I> a, const HardGroupInfo *__restrict__ info, uint64_t nH,
+                                                              const uint64_t *__restrict__ mm_off, const uint8_t *__restrict__ gmaj,
+                                                              MinorMember *__restrict__ out) {
+  const uint64_t h = (uint64_t)BID * 256 + threadIdx.x;
+  if (h >= nH) return;
+  uint64_t o = mm_off[h];
+  if (mm_off[h + 1] == o) return;
+  const HardGroupInfo gi = info[h];
+  const uint32_t maj = gmaj[gi.g];
+  for (uint32_t m = 0; m < gi.k; m++)
+    if ((uint32_t)fix_char(a.pc[gi.g + m]) != maj) out[o++] = MinorMember{gi.g, gi.k, m};
+}
+// eight lanes per minority member: its occurrences (usually one) are ranked one after the other - own index +
+// lower_bound in every other member's inverted list, the group's members shared among the lanes (every lane fetches
+// the inverted-list start of its members and bisects there) - rank, predecessor and successor combined by shuffles
+template <class I>
+__global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const MinorMember *__restrict__ mem, uint64_t total) {
+  const int l8 = threadIdx.x & 7;
+  const uint64_t rounds = (total + GDIM * 32 - 1) / (GDIM * 32);      // every lane runs the same number of rounds (shuffles inside)
+  for (uint64_t it = 0; it < rounds; it++) {
+    const uint64_t q = (it * GDIM + BID) * 32 + (threadIdx.x >> 3);
+    const bool live = q < total;
+    MinorMember mmv{0, 0, 0};
+    if (live) mmv = mem[q];
+    const uint64_t g = mmv.g;
+    const uint32_t k = mmv.k, me = mmv.m;
+    uint32_t my_occ = 0, my_ist = 0;
+    uint64_t base = 0, sl = 0;
+    uint8_t mych = 0;
+    if (live) {
+      base = slot_off(a, g);
+      my_occ = (uint32_t)(slot_off(a, g + me + 1) - slot_off(a, g + me));
+      my_ist = slot_ist(a, g + me);
+      mych = fix_char(a.pc[g + me]);
+      if (a.want_sa) sl = a.slen[a.sa[g]];
     }
-    const uint32_t my_ist = slot_ist(a, g + me);
-    const uint32_t pos = a.ilist[my_ist + j];
-    // rank among all occurrences of the group; predecessor and successor position over all lists
-    uint64_t r = j;
-    uint32_t pred = 0, succ = 0xFFFFFFFFu;
-    bool has_pred = false, has_succ = false;
-    prev = base;
-    for (uint32_t m = 0; m < k; m++) {
-      const uint64_t nxt = slot_off(a, g + m + 1);
-      const uint32_t occ = (uint32_t)(nxt - prev);
-      prev = nxt;
-      const uint32_t *lst = a.ilist + (m == me ? my_ist : slot_ist(a, g + m));
-      uint32_t lb;
-      if (m == me) lb = j;
-      else {
-        uint32_t l2 = 0, h2 = occ;          // # entries < pos
-        while (l2 < h2) { const uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
-        lb = l2;
-        r += lb;
+    // longest occurrence count among the 8-lane groups of the wave decides the trip count (shuffles inside the loop)
+    uint32_t trips = my_occ;
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) { const uint32_t v = __shfl_xor(trips, o, 64); trips = v > trips ? v : trips; }
+    for (uint32_t j = 0; j < trips; j++) {
+      const bool act = live && j < my_occ;
+      uint64_t r = 0;
+      uint32_t pos = 0, pred = 0, succ = 0xFFFFFFFFu, has_pred = 0, has_succ = 0;
+      if (act) {
+        pos = a.ilist[my_ist + j];
+        for (uint32_t m = (uint32_t)l8; m < k; m += 8) {
+          const uint32_t occ = (uint32_t)(slot_off(a, g + m + 1) - slot_off(a, g + m));
+          const uint32_t *lst = a.ilist + (m == me ? my_ist : slot_ist(a, g + m));
+          uint32_t lb;
+          if (m == me) lb = j;
+          else {
+            uint32_t l2 = 0, h2 = occ;          // # entries < pos
+            while (l2 < h2) { const uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
+            lb = l2;
+          }
+          r += lb;
+          if (a.want_sa) {
+            if (lb > 0) { const uint32_t v = lst[lb - 1]; if (!has_pred || v > pred) { pred = v; has_pred = 1; } }
+            const uint32_t nx = m == me ? lb + 1 : lb;
+            if (nx < occ) { const uint32_t v = lst[nx]; if (!has_succ || v < succ) { succ = v; has_succ = 1; } }
+          }
+        }
       }
-      if (a.want_sa) {
-        if (lb > 0) { const uint32_t v = lst[lb - 1]; if (!has_pred || v > pred) { pred = v; has_pred = true; } }
-        const uint32_t nx = m == me ? lb + 1 : lb;
-        if (nx < occ) { const uint32_t v = lst[nx]; if (!has_succ || v < succ) { succ = v; has_succ = true; } }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        r += __shfl_xor(r, o, 64);
+        const uint32_t op = __shfl_xor(pred, o, 64), ohp = __shfl_xor(has_pred, o, 64);
+        const uint32_t os = __shfl_xor(succ, o, 64), ohs = __shfl_xor(has_succ, o, 64);
+        if (ohp && (!has_pred || op > pred)) { pred = op; has_pred = 1; }
+        if (ohs && (!has_succ || os < succ)) { succ = os; has_succ = 1; }
       }
-    }
-    const uint64_t o = base + r;
-    if (o >= a.out_lo && o < a.out_hi) {
-      a.bwt[o] = fix_char(a.pc[g + me]);
-      if (a.want_sa) {
-        const uint64_t sl = a.slen[a.sa[g]];
-        a.out_sa[o] = a.bwsai[pos] - sl;
-        if (has_pred && o - 1 >= a.out_lo) a.out_sa[o - 1] = a.bwsai[pred] - sl;
-        if (has_succ && o + 1 < a.out_hi) a.out_sa[o + 1] = a.bwsai[succ] - sl;
+      if (!act || l8 != 0) continue;
+      const uint64_t o = base + r;
+      if (o >= a.out_lo && o < a.out_hi) {
+        a.bwt[o] = mych;
+        if (a.want_sa) {
+          a.out_sa[o] = a.bwsai[pos] - sl;
+          if (has_pred && o - 1 >= a.out_lo) a.out_sa[o - 1] = a.bwsai[pred] - sl;
+          if (has_succ && o + 1 < a.out_hi) a.out_sa[o + 1] = a.bwsai[succ] - sl;
+        }
+      } else if (a.want_sa) {      // the occurrence lies just outside this rank's slice: its neighbours may be inside
+        if (has_pred && o >= 1 && o - 1 >= a.out_lo && o - 1 < a.out_hi) a.out_sa[o - 1] = a.bwsai[pred] - sl;
+        if (has_succ && o + 1 >= a.out_lo && o + 1 < a.out_hi) a.out_sa[o + 1] = a.bwsai[succ] - sl;
       }
-    } else if (a.want_sa) {      // the occurrence lies just outside this rank's slice: its neighbours may be inside
-      const uint64_t sl = a.slen[a.sa[g]];
-      if (has_pred && o >= 1 && o - 1 >= a.out_lo && o - 1 < a.out_hi) a.out_sa[o - 1] = a.bwsai[pred] - sl;
-      if (has_succ && o + 1 >= a.out_lo && o + 1 < a.out_hi) a.out_sa[o + 1] = a.bwsai[succ] - sl;
     }
   }
 }
@@ -1127,20 +1160,31 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   DBuf<unsigned long long> mstat(c, 1);
   mstat.zero();
   DBuf<HardGroupInfo> ginfo;
-  DBuf<uint32_t> minor_cnt;
-  DBuf<uint64_t> minor_off;
+  DBuf<uint32_t> minor_cnt, mm_cnt;
+  DBuf<uint64_t> minor_off, mm_off;
+  DBuf<MinorMember> mm_list;
+  uint64_t n_mm = 0;
   DBuf<I> fb_heads;
   const I *hard_list = heads.p;             // what hard_groups_kernel works through
   const uint64_t *hard_list_n = nheads.p;
   uint64_t n_minor = 0, n_fallback = n_heads;
   if (!dense && n_heads) {
     gmaj.alloc(c, N); fallback.alloc(c, n_heads); ginfo.alloc(c, n_heads); minor_cnt.alloc(c, n_heads + 1); minor_off.alloc(c, n_heads + 1);
+    mm_cnt.alloc(c, n_heads + 1); mm_off.alloc(c, n_heads + 1);
     PFP_HIP(hipMemsetAsync(minor_cnt.p + n_heads, 0, 4, c->stream));
+    PFP_HIP(hipMemsetAsync(mm_cnt.p + n_heads, 0, 4, c->stream));
     a.gmaj = gmaj.p;
     { KScope ks(c, "pfp::hard_classify_kernel", n_heads * 40);
       hipLaunchKernelGGL(hard_classify_kernel<I>, gdim(cdiv(n_heads, 256)), gdim(256), 0, c->stream, a, heads.p, n_heads, gmaj.p,
-                         ginfo.p, minor_cnt.p, fallback.p, mstat.p); }
+                         ginfo.p, minor_cnt.p, fallback.p, mstat.p, mm_cnt.p); }
     exclusive_sum_u32_u64(c, minor_cnt.p, minor_off.p, n_heads + 1);
+    exclusive_sum_u32_u64(c, mm_cnt.p, mm_off.p, n_heads + 1);
+    n_mm = read_scalar(c, mm_off.p + n_heads);
+    if (n_mm) {
+      mm_list.alloc(c, n_mm);
+      hipLaunchKernelGGL(hard_minor_fill_kernel<I>, gdim(cdiv(n_heads, 256)), gdim(256), 0, c->stream, a, ginfo.p, n_heads, mm_off.p, gmaj.p,
+                         mm_list.p);
+    }
     n_fallback = count_flags(c, fallback.p, n_heads);
     n_minor = read_scalar(c, minor_off.p + n_heads);
     fb_heads.alloc(c, n_fallback + 1);
@@ -1169,10 +1213,10 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     KScope ks(c, "pfp::unit_edges_kernel", N * (1 + sizeof(I) * 2 + 4));
     hipLaunchKernelGGL(unit_edges_kernel<I>, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, a);
   }
-  if (n_minor) {
+  if (n_mm) {
     KScope ks(c, "pfp::hard_minor_kernel", n_minor * 64);
-    hipLaunchKernelGGL(hard_minor_kernel<I>, gdim((unsigned)std::min<uint64_t>(cdiv64(n_minor, 256), (uint64_t)c->n_cu * 64)), gdim(256), 0,
-                       c->stream, a, ginfo.p, n_heads, minor_off.p, n_minor, gmaj.p);
+    hipLaunchKernelGGL(hard_minor_kernel<I>, gdim((unsigned)std::min<uint64_t>(cdiv64(n_mm, 32), (uint64_t)c->n_cu * 64)), gdim(256), 0,
+                       c->stream, a, mm_list.p, n_mm);
   }
   PFP_HIP(hipGetLastError());
   for (;;) {

@@ -158,6 +158,7 @@ struct Chain {
   DictOrder ord;
   DBuf<uint32_t> occ_lex, word_at_rank, sym;
   ParseBWT pb;
+  DBuf<uint64_t> sa_own;      // SA values when the caller keeps none (host / file / sampled entry points)
 };
 
 // narrowing / widening copy of an index array to the host (the staged gsacak.h entry points fix their SA width)
@@ -207,6 +208,9 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
     if (c->debug) validate_dictionary(c, ch.D, w);
     build_dict_index(c, ch.D, ch.ix);
     if (c->debug) validate_index(c, ch.D, ch.ix);
+    // the text and its phrase ends have done their part: dictionary, parse, last and sai are all there is from here on
+    ch.tx.buf.release();
+    ch.ends.release();
   }
   {
     PhaseTimer t(c, &st.ms_sa_dict);
@@ -235,6 +239,8 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
   st.sa_rounds_dict = ch.ord.rounds(); st.hash_reseeds = ch.D.reseeds; st.index_bits = ch.ord.wide ? 64 : 32;
 }
 
+// d_sa == nullptr with SA flags: the SA values live in a buffer of the chain (ch.sa_own), allocated when the suffix
+// sorter has given its scratch back - the caller never sees them, only what is sampled / packed from them
 static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, int flags, uint8_t *d_bwt,
                           uint64_t *d_sa, uint64_t *n_used) {
   pfp_stats &st = c->stats;
@@ -250,6 +256,7 @@ static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, 
   {
     PhaseTimer t(c, &st.ms_merge);
     BwtOutputs bo;
+    if (flags && !d_sa) { ch.sa_own.alloc(c, ch.n_used + 1); d_sa = ch.sa_own.p; }
     bo.d_bwt = d_bwt; bo.d_sa = d_sa;
     with_width(ch.ord.wide, [&](auto tag) {
       using I = decltype(tag);
@@ -636,8 +643,35 @@ static void dictionary_from_host(pfp_ctx *c, const uint8_t *s, uint64_t n, Dicti
   build_dict_index(c, D, ix);
 }
 
-template <class OUT>
-static void gsacak_any(pfp_ctx *c, const uint8_t *s, OUT *SA, uint64_t n) {
+// gsacak's optional outputs (gsa/gsacak.h:78-105): LCP[i] = length of the common prefix of the suffixes SA[i-1] and
+// SA[i], where a separator (1) or the final 0 ends the count (gsa/README.md:76-104); DA[i] = index of the string
+// the suffix SA[i] starts in.  One thread per slot compares its two suffixes 8 bytes at a time.
+template <class I, class L>
+__global__ void lcp_da_kernel(const uint8_t *__restrict__ s, uint64_t n, const I *__restrict__ sa, const uint32_t *__restrict__ pos_word,
+                              L *__restrict__ lcp, L *__restrict__ da) {
+  const uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint64_t b = sa[t];
+  if (da) da[t] = (L)pos_word[b];
+  if (!lcp) return;
+  if (t == 0) { lcp[0] = 0; return; }
+  const uint64_t a = sa[t - 1];
+  uint64_t l = 0;
+  for (;;) {
+    const uint64_t x = ld8u(s + a + l), y = ld8u(s + b + l);
+    const uint64_t end = (x - 0x0202020202020202ull) & ~x & 0x8080808080808080ull;      // bytes < 2 of x (lowest flag exact)
+    const uint64_t diff = x ^ y;
+    if (diff | end) {
+      const int fd = diff ? (__builtin_ctzll(diff) >> 3) : 8, fe = end ? (__builtin_ctzll(end) >> 3) : 8;
+      l += fd < fe ? fd : fe;
+      break;
+    }
+    l += 8;
+  }
+  lcp[t] = (L)l;
+}
+template <class OUT, class L>
+static void gsacak_any(pfp_ctx *c, const uint8_t *s, OUT *SA, uint64_t n, L *LCP = nullptr, L *DA = nullptr) {
   PFP_REQUIRE(sizeof(OUT) == 8 || n < 0xFFFFFFF0ull, PFP_ELIMIT, "collection of 4 GiB or more needs the 64-bit entry point (gsacak.h -DM64)");
   Dictionary D; DictIndex ix;
   dictionary_from_host(c, s, n, D, ix);
@@ -646,6 +680,15 @@ static void gsacak_any(pfp_ctx *c, const uint8_t *s, OUT *SA, uint64_t n) {
     SuffixOrderT<I> so;
     sort_dict_suffixes<I>(c, D.bytes.p, n, ix.slen.p, so);
     fetch_converted<I, OUT>(c, so.sa.p, n, SA);
+    if (LCP || DA) {
+      DBuf<L> dl(c, LCP ? n : 1), dd(c, DA ? n : 1);
+      hipLaunchKernelGGL((lcp_da_kernel<I, L>), gdim(cdiv(n, TB)), gdim(TB), 0, c->stream, D.bytes.p, n, so.sa.p, ix.pos_word.p,
+                         LCP ? dl.p : (L *)nullptr, DA ? dd.p : (L *)nullptr);
+      PFP_HIP(hipGetLastError());
+      if (LCP) d2h(c, LCP, dl.p, n);
+      if (DA) d2h(c, DA, dd.p, n);
+      sync(c);
+    }
   });
 }
 extern "C" {
@@ -653,7 +696,7 @@ int pfp_gsacak(pfp_ctx *c, const uint8_t *s, uint32_t *SA, uint64_t n) {
   if (!c || !s || !SA) return PFP_EINVAL;   // gsacak.c:2503
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
-  gsacak_any<uint32_t>(c, s, SA, n);
+  gsacak_any<uint32_t, int32_t>(c, s, SA, n);
   return PFP_OK;
   PFP_CATCH(c)
 }
@@ -661,7 +704,23 @@ int pfp_gsacak64(pfp_ctx *c, const uint8_t *s, uint64_t *SA, uint64_t n) {
   if (!c || !s || !SA) return PFP_EINVAL;
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
-  gsacak_any<uint64_t>(c, s, SA, n);
+  gsacak_any<uint64_t, int64_t>(c, s, SA, n);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+int pfp_gsacak_lcp_da(pfp_ctx *c, const uint8_t *s, uint32_t *SA, int32_t *LCP, int32_t *DA, uint64_t n) {
+  if (!c || !s || !SA) return PFP_EINVAL;   // gsacak.c:2503; LCP and DA are optional like there
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  gsacak_any<uint32_t, int32_t>(c, s, SA, n, LCP, DA);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+int pfp_gsacak_lcp_da64(pfp_ctx *c, const uint8_t *s, uint64_t *SA, int64_t *LCP, int64_t *DA, uint64_t n) {
+  if (!c || !s || !SA) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  gsacak_any<uint64_t, int64_t>(c, s, SA, n, LCP, DA);
   return PFP_OK;
   PFP_CATCH(c)
 }
@@ -838,13 +897,55 @@ int pfp_bigbwt(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, i
   Chain ch;
   ch.tx.stage(c, text, false, n, w);
   DBuf<uint8_t> d_bwt(c, n + 1 + 16);
-  DBuf<uint64_t> d_sa;
-  if (flags) d_sa.alloc(c, n + 1);
   uint64_t used = 0;
-  run_chain_dev(c, ch, n, w, p, flags, d_bwt.p, flags ? d_sa.p : nullptr, &used);
-  fetch_outputs(c, d_bwt.p, d_sa.p, used + 1, flags, out);
+  run_chain_dev(c, ch, n, w, p, flags, d_bwt.p, nullptr, &used);
+  fetch_outputs(c, d_bwt.p, ch.sa_own.p, used + 1, flags, out);
   return PFP_OK;
   PFP_CATCH(c)
+}
+
+// Device-resident chain whose SA-derived outputs are the reference's files, not SA values: .sa (PFP_FLAG_SA, 5-byte
+// ints), .ssa / .esa (10-byte pairs) as device buffers of the library (pfp_dev_free).  The SA values themselves stay
+// inside (allocated after the suffix sorter has returned its scratch): the 8 bytes per text byte a d_sa array takes
+// are what keeps a 12.6 GB input with -s from fitting one GPU next to the sorter.
+int pfp_bigbwt_formats_dev(pfp_ctx *c, const void *d_text, uint64_t n, int w, uint64_t p, int flags, void *d_bwt,
+                           void *d_out[3], uint64_t out_bytes[3], uint64_t *n_used) {
+  if (!c || (!d_text && n) || !d_bwt || !d_out || !out_bytes) return PFP_EINVAL;
+  for (int k = 0; k < 3; k++) { d_out[k] = nullptr; out_bytes[k] = 0; }
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  check_args(w, p, flags);
+  PFP_REQUIRE(((uintptr_t)d_bwt & 15) == 0, PFP_EINVAL, "d_bwt must be 16-byte aligned");
+  Chain ch;
+  ch.tx.stage(c, d_text, true, n, w);
+  uint64_t used = 0;
+  run_chain_dev(c, ch, n, w, p, flags, (uint8_t *)d_bwt, nullptr, &used);
+  if (n_used) *n_used = used;
+  emit_outputs(c, (const uint8_t *)d_bwt, ch.sa_own.p, used + 1, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
+    if (name[0] == 'b') return;
+    const int k = name[1] == 'a' ? 0 : (name[0] == 's' ? 1 : 2);
+    void *q = nullptr;
+    PFP_HIP(hipMalloc(&q, bytes ? bytes : 1));
+    PFP_HIP(hipMemcpyAsync(q, d, bytes, hipMemcpyDeviceToDevice, c->stream));
+    d_out[k] = q; out_bytes[k] = bytes;
+  });
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+int pfp_memcpy_d2h(pfp_ctx *c, void *host_dst, const void *d_src, uint64_t nbytes) {
+  if (!c || ((!host_dst || !d_src) && nbytes)) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  stream_d2h(c, (const uint8_t *)d_src, nbytes, [&](const uint8_t *pin, uint64_t off, uint64_t len) { par_memcpy((uint8_t *)host_dst + off, pin, len); });
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+void pfp_dev_free(pfp_ctx *c, void *d_ptr) {
+  if (!c || !d_ptr) return;
+  (void)hipSetDevice(c->device);
+  (void)hipFree(d_ptr);
 }
 
 // file to files: the host text (an mmap of the input works) is streamed in, the outputs are streamed from HBM
@@ -858,12 +959,10 @@ int pfp_bigbwt_files(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_
   Chain ch;
   ch.tx.stage(c, text, false, n, w);
   DBuf<uint8_t> d_bwt(c, n + 1 + 16);
-  DBuf<uint64_t> d_sa;
-  if (flags) d_sa.alloc(c, n + 1);
   uint64_t used = 0;
-  run_chain_dev(c, ch, n, w, p, flags, d_bwt.p, flags ? d_sa.p : nullptr, &used);
+  run_chain_dev(c, ch, n, w, p, flags, d_bwt.p, nullptr, &used);
   uint64_t sizes[4] = {0, 0, 0, 0};
-  emit_outputs(c, d_bwt.p, d_sa.p, used + 1, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
+  emit_outputs(c, d_bwt.p, ch.sa_own.p, used + 1, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
     write_dev_file(c, std::string(base) + "." + name, 0, d, bytes, true);
     sizes[name[0] == 'b' ? 0 : (name[1] == 'a' ? 1 : (name[0] == 's' ? 2 : 3))] = bytes;
   });

@@ -645,7 +645,7 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
                                   const I *__restrict__ val, const I *__restrict__ newhead,
                                   const uint8_t *__restrict__ hd, I finbit, const K *__restrict__ prevkey,
                                   int prevshift, const I *__restrict__ prevgrp, const uint8_t *__restrict__ veto,
-                                  const uint8_t *__restrict__ lazy_bytes, I *__restrict__ sa,
+                                  const uint32_t *__restrict__ wstart_bits, I *__restrict__ sa,
                                   I *__restrict__ rank, I *__restrict__ grp, uint8_t *__restrict__ keep) {
   uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= m) return;
@@ -668,7 +668,9 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
   // (compute_lexrank); every other settled rank is filled in by repair_ranks_kernel if a doubling
   // round follows after all.  One byte read replaces the scattered 4-byte store.
   bool wr = k ? old != newhead[a] : true;
-  if (lazy_bytes) wr = !k && (i == 0 || lazy_bytes[i - 1] == kEndOfWord);
+  // (a whole word is a singleton group: only a suffix alone in its group can be one; which positions start a word is
+  // read from a bitmap of N bits - it stays cache resident where the dictionary bytes would not)
+  if (wstart_bits) wr = !k && single && ((wstart_bits[i >> 5] >> (i & 31)) & 1u);
   if (wr) rank[i] = newhead[a] | (k ? (I)0 : finbit);
   keep[a] = k ? 1 : 0;
 }
@@ -676,6 +678,18 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
 // ranks that pivot rounds left unwritten: every slot re-ordered after the first round that is not in
 // the active list any more holds a settled suffix
 // lazy ranks: the unresolved suffixes get theirs (= their group's head slot) from the active list
+// bit i set: position i starts a word (i == 0 or the byte before it is a terminator)
+__global__ __launch_bounds__(256) void word_start_bits_kernel(const uint8_t *__restrict__ s, uint64_t N, uint32_t *__restrict__ bits) {
+  const uint64_t wi = (uint64_t)BID * 256 + threadIdx.x;      // 32 positions per thread
+  const uint64_t p0 = wi * 32;
+  if (p0 >= N) return;
+  uint32_t m = 0;
+  for (int k = 0; k < 32; k++) {
+    const uint64_t i = p0 + k;
+    if (i < N && (i == 0 || s[i - 1] == kEndOfWord)) m |= 1u << k;
+  }
+  bits[wi] = m;
+}
 template <class I>
 __global__ void active_ranks_kernel(uint64_t m, const I *__restrict__ act_i, const I *__restrict__ act_grp, I *__restrict__ rank) {
   uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
@@ -776,6 +790,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   static const bool lazy_pivot_ranks = getenv("PFP_EAGER_PIVOT_RANKS") == nullptr;
   bool ranks_stale = false;     // pivot rounds skipped rank[] of settled suffixes that are not whole words
   bool active_stale = false;    // ... and the first round / pivot rounds skipped rank[] of the suffixes that stay unresolved
+  DBuf<uint32_t> wstart_bits;   // pivot rounds: which positions start a word (their ranks order the dictionary)
   // lazy ranks are possible when pivot rounds (which never read rank[]) can follow the first round
   const bool lazy_active = lazy && lazy_pivot_ranks && out.finbit && g.mode == MODE_DICT && kPivotCap >= 16 && (uint64_t)nb + kPivBits <= 64;
   auto repair_ranks = [&](uint64_t m_active, const I *aslot_list) {
@@ -815,6 +830,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   DBuf<I> tile_off, tile_hoff;
   uint32_t piv_cap = kPivotCap;  // bytes compared per member in the next pivot round
   bool long_cap_tried = false;
+  bool small_failed = false;     // a direct-placement attempt met a group longer than its window
   for (;;) {
     DBuf<I> tile_last, tile_scan;      // first round of dictionary mode: last head per 256 slots, and its running maximum
     if (first && lazy) {
@@ -858,7 +874,11 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       const bool have_prev = out.rounds > 0;
       KScope ks(c, "pfp::write_back_kernel", m * (13 + 4 + 13));
       const uint8_t *vetop = pivot_round ? veto.p : (const uint8_t *)nullptr;
-      const uint8_t *lazyb = (pivot_round && lazy_pivot_ranks) ? out.bytes : (const uint8_t *)nullptr;
+      if (pivot_round && lazy_pivot_ranks && !wstart_bits.p) {
+        wstart_bits.alloc(c, cdiv64(NP, 32));
+        hipLaunchKernelGGL(word_start_bits_kernel, gdim(cdiv(cdiv64(NP, 32), TB)), gdim(TB), 0, c->stream, out.bytes, NP, wstart_bits.p);
+      }
+      const uint32_t *lazyb = (pivot_round && lazy_pivot_ranks) ? wstart_bits.p : (const uint32_t *)nullptr;
       const I *prevgrp = (have_prev && seg_round) ? act_grp.p : (const I *)nullptr;
       if (dbl_round && kWide && !seg_round)
         hipLaunchKernelGGL((write_back_kernel<I, K>), gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p, hd.p,
@@ -954,12 +974,16 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       uint32_t ng = 0;
       static const uint32_t seg_min_avg = []() { const char *e = getenv("PFP_SEG_MINAVG"); return e ? (uint32_t)atoi(e) : 24u; }();
       static const bool use_small = getenv("PFP_NO_SMALLSEG") == nullptr;
-      small = use_segsort && use_small && m / ngrp <= kSmallSeg / 4;      // families of a handful of members: placed directly
-      if (!small && use_segsort && m >= (1u << 20) && m < 0xFFFFFFFFull && m / ngrp >= seg_min_avg) {
-        uint32_t maxlen = 0;
-        seg_setup(m, ng, maxlen);
-        seg = maxlen <= (1u << 15) && m / ng >= seg_min_avg;
-      }
+      // families of a handful of members: placed directly (after a group proved too long, only once the average is tiny)
+      small = use_segsort && use_small && m / ngrp <= kSmallSeg / 4 && (!small_failed || m / ngrp <= 3);
+      auto try_seg = [&]() {
+        if (use_segsort && m >= (1u << 20) && m < 0xFFFFFFFFull && m / ngrp >= seg_min_avg) {
+          uint32_t maxlen = 0;
+          seg_setup(m, ng, maxlen);
+          seg = maxlen <= (1u << 15) && m / ng >= seg_min_avg;
+        }
+      };
+      if (!small) try_seg();
       if (small) seg_bufs();
       // both key forms are written when the direct placement is tried: should a group prove too long, the
       // device-wide sort takes over with the 64-bit keys
@@ -967,6 +991,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
         hipLaunchKernelGGL(build_keys_pivot_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, out.bytes, m, h, piv_cap, act_i.p,
                            act_grp.p, out.sa.p, out.finbit, key.p, (seg || small) ? k32.p : (uint32_t *)nullptr, val.p, small ? 1 : 0); }
       if (small && seg_small_sort(m)) seg_round = true;
+      else if (small && (small_failed = true, try_seg(), false)) {}
       else if (seg) { segsort_pairs_u32<I>(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, kPivBits); seg_round = true; }
       else { sort_pairs_db(c, key, keyo, val, valo, m, 0, nb + kPivBits); std::swap(key, keyo); std::swap(val, valo); }
       out.rounds++;
@@ -992,11 +1017,12 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     dbl_round = true;
     if constexpr (!kWide) {
       static const bool use_small = getenv("PFP_NO_SMALLSEG") == nullptr;
-      if (use_segsort && use_small && ngrp && m / ngrp <= kSmallSeg / 4) {
+      if (use_segsort && use_small && ngrp && m / ngrp <= kSmallSeg / 4 && (!small_failed || m / ngrp <= 3)) {
         seg_bufs();
         { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
           hipLaunchKernelGGL(build_keys32_kernel, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
         seg_round = seg_small_sort(m);
+        if (!seg_round) small_failed = true;
       }
       if (seg_round) {
       } else if (use_segsort && m >= (1u << 20) && ngrp && m / ngrp >= 24) {

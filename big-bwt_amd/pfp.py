@@ -28,8 +28,8 @@ ERRORS = {0: "PFP_OK", -1: "PFP_EINVAL", -2: "PFP_ENODEV", -3: "PFP_EHIP", -4: "
 
 # every symbol include/pfpgpu.h declares
 SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror", "pfp_version", "pfp_ctx_stream",
-           "pfp_free", "pfp_debug_check", "pfp_get_mem_stats", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak", "pfp_sacak_int64", "pfp_sacak64", "pfp_gsacak64",
-           "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_files", "pfp_bigbwt_dev", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
+           "pfp_free", "pfp_debug_check", "pfp_get_mem_stats", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak", "pfp_sacak_int64", "pfp_sacak64", "pfp_gsacak64", "pfp_gsacak_lcp_da", "pfp_gsacak_lcp_da64",
+           "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_files", "pfp_bigbwt_dev", "pfp_bigbwt_formats_dev", "pfp_dev_free", "pfp_memcpy_d2h", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
            "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
            "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_partition_words", "pfp_dist_export_partition",
            "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_release"]
@@ -103,6 +103,7 @@ def load_library():
         lib.pfp_set_max_phrase.restype = None
         lib.pfp_set_kernel_trace.restype = None
         lib.pfp_dist_release.restype = None
+        lib.pfp_dev_free.restype = None
         lib.pfp_parse_result_free.restype = None
         lib.pfp_bwt_result_free.restype = None
         _lib = lib
@@ -278,6 +279,15 @@ class Context:
         self._check(self.lib.pfp_gsacak64(self._h, _ptr(s, C.c_uint8), _ptr(sa, C.c_uint64), C.c_uint64(len(s))))
         return sa
 
+    def gsacak_lcp_da(self, s, wide=False):
+        """gsacak(s, SA, LCP, DA, n) with all three outputs (gsa/gsacak.h:96-105)"""
+        s = _arr(s, np.uint8)
+        it, ut, fn = (np.int64, np.uint64, self.lib.pfp_gsacak_lcp_da64) if wide else (np.int32, np.uint32, self.lib.pfp_gsacak_lcp_da)
+        sa = np.zeros(len(s), dtype=ut); lcp = np.zeros(len(s), dtype=it); da = np.zeros(len(s), dtype=it)
+        self._check(fn(self._h, _ptr(s, C.c_uint8), sa.ctypes.data_as(C.c_void_p), lcp.ctypes.data_as(C.c_void_p),
+                       da.ctypes.data_as(C.c_void_p), C.c_uint64(len(s))))
+        return sa, lcp, da
+
     # -- stage 2: bwtparse.c main
     def bwtparse(self, parse, last, occ, sai=None):
         parse = _arr(parse, np.uint32); last = _arr(last, np.uint8); occ = _arr(occ, np.uint32)
@@ -333,6 +343,25 @@ class Context:
                                             C.c_int(flags), C.c_void_p(d_bwt_ptr),
                                             C.c_void_p(d_sa_ptr) if d_sa_ptr else None, C.byref(used)))
         return used.value
+
+    def bigbwt_formats_dev(self, d_text_ptr, n, d_bwt_ptr, w=10, p=100, flags=0):
+        """device text in, .bwt into d_bwt, .sa/.ssa/.esa as library-owned device buffers: -> (n_used, {name: (ptr, bytes)});
+        release every ptr with dev_free"""
+        used = C.c_uint64()
+        outs = (C.c_void_p * 3)()
+        sizes = (C.c_uint64 * 3)()
+        self._check(self.lib.pfp_bigbwt_formats_dev(self._h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_int(w), C.c_uint64(p), C.c_int(flags),
+                                                    C.c_void_p(d_bwt_ptr), outs, sizes, C.byref(used)))
+        return used.value, {k: (outs[i], int(sizes[i])) for i, k in enumerate(("sa", "ssa", "esa")) if outs[i]}
+
+    def fetch_dev(self, d_ptr, nbytes):
+        """device bytes (a buffer the library handed out) -> numpy uint8 array"""
+        out = np.empty(int(nbytes), dtype=np.uint8)
+        self._check(self.lib.pfp_memcpy_d2h(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(d_ptr), C.c_uint64(nbytes)))
+        return out
+
+    def dev_free(self, d_ptr):
+        self.lib.pfp_dev_free(self._h, C.c_void_p(d_ptr))
 
     def pack5_dev(self, d_vals_ptr, count, d_out5_ptr):
         """count u64 device values -> 5-byte LE ints in device memory (utils.c:112-129)"""

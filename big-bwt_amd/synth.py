@@ -76,8 +76,12 @@ def collection_torch(dev, G, C, r, seed, nblocks=(), variant=0, first_copy=0, he
     import torch
     assert G % 60 == 0
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    idx = torch.arange(G, dtype=torch.int64, device=dev)
-    base = lut[mix64_torch(idx + _s64(seed * K0)) & 3]
+    CH = 1 << 28          # positions per piece (the int64 temporaries of a piece stay at a few GB)
+    base = torch.empty(G, dtype=torch.uint8, device=dev)
+    for s0 in range(0, G, CH):
+        i = torch.arange(s0, min(G, s0 + CH), dtype=torch.int64, device=dev)
+        base[s0:s0 + i.numel()] = lut[mix64_torch(i + _s64(seed * K0)) & 3]
+    del i
     for st, ln in nblocks:
         base[st:st + ln] = ord("N")
     thr = int(r * (1 << 53))
@@ -87,10 +91,14 @@ def collection_torch(dev, G, C, r, seed, nblocks=(), variant=0, first_copy=0, he
         seq = base
         if r > 0:
             k = _s64((((seed * K1 + c + 1 + variant * 4096) & _M64) * K2) & _M64)
-            h = mix64_torch(idx + k)
-            mut = (((h >> 11) & ((1 << 53) - 1)) < thr) & (base != ord("N"))
-            seq = torch.where(mut, lut[(h >> 3) & 3], base)
-            del h, mut
+            seq = torch.empty_like(base)
+            for s0 in range(0, G, CH):
+                i = torch.arange(s0, min(G, s0 + CH), dtype=torch.int64, device=dev)
+                b = base[s0:s0 + i.numel()]
+                h = mix64_torch(i + k)
+                mut = (((h >> 11) & ((1 << 53) - 1)) < thr) & (b != ord("N"))
+                seq[s0:s0 + i.numel()] = torch.where(mut, lut[(h >> 3) & 3], b)
+            del h, mut, i, b
         parts.append(torch.tensor(list(header(c + (variant * C if header_base is None else header_base))), dtype=torch.uint8, device=dev))
         parts.append(torch.cat([seq.view(-1, 60), nl], dim=1).reshape(-1))
     out = torch.cat(parts).contiguous()
@@ -123,8 +131,8 @@ WORKLOADS = {
                  desc="1024x mutated yeast-shaped FASTA (~12.6 GB; the north star's >= 10 GB repetitive input on one GPU), BWT only"),
     "huge_s": dict(G=12_100_020, C=1024, r=1e-3, nblocks=[], w=10, p=100, flags=2, seed=3,
                    desc="1024x mutated yeast-shaped FASTA (~12.6 GB; the north star's >= 10 GB repetitive input on one GPU), BWT + -s sampled SA"),
-    "wide": dict(G=12_100_020, C=360, r=3e-2, nblocks=[], w=10, p=100, flags=0, seed=3,
-                 desc="360x yeast-shaped FASTA at 3 % SNPs (~4.4 GB; nearly every phrase is new): dictionary > 4 GiB, exercises the 64-bit index build"),
+    "wide": dict(G=4_260_000_000, C=1, r=0.0, nblocks=[], w=10, p=100, flags=0, seed=3,
+                 desc="one 4.26 G-base random genome as FASTA (~4.33 GB, non-repetitive): dictionary > 4 GiB, exercises the 64-bit index build"),
     "wide31": dict(G=12_100_020, C=200, r=3e-2, nblocks=[], w=10, p=100, flags=0, seed=3,
                    desc="200x yeast-shaped FASTA at 3 % SNPs (~2.5 GB): dictionary between 2^31 and 2^32 bytes (32-bit indices without a spare bit)"),
     "c4s": dict(G=12_100_020, C=16, r=1e-3, nblocks=[], w=10, p=100, flags=1, seed=3,

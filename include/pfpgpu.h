@@ -102,6 +102,12 @@ int pfp_gsacak(pfp_ctx *ctx, const uint8_t *s, uint32_t *SA, uint64_t n);
  * bigbwt selects for parses / dictionaries / texts beyond the 32-bit limits (bigbwt:109-151, 177-194): 64-bit SA
  * entries, n up to 2^40.  Inside the library the index width follows the input size in every entry point
  * (32-bit positions below 4 GiB, 64-bit above; PFP_FORCE_IDX64=1 in the environment forces the wide build). */
+/* gsacak with its optional outputs (gsa/gsacak.h:96-105; either may be NULL): LCP[i] = common prefix of the
+ * suffixes SA[i-1], SA[i] with separators and the final 0 ending the count, LCP[0] = 0; DA[i] = index of the
+ * string suffix SA[i] starts in (gsa/README.md:76-104).  The reference's pfbwt passes DA = NULL and uses LCP only
+ * for its "same suffix as the entry before" test (pfbwt.cpp:204-209), which pfp_merge answers from rank equality. */
+int pfp_gsacak_lcp_da(pfp_ctx *ctx, const uint8_t *s, uint32_t *SA, int32_t *LCP, int32_t *DA, uint64_t n);
+int pfp_gsacak_lcp_da64(pfp_ctx *ctx, const uint8_t *s, uint64_t *SA, int64_t *LCP, int64_t *DA, uint64_t n);
 int pfp_sacak_int64(pfp_ctx *ctx, const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k);
 int pfp_sacak64(pfp_ctx *ctx, const uint8_t *s, uint64_t *SA, uint64_t n);
 int pfp_gsacak64(pfp_ctx *ctx, const uint8_t *s, uint64_t *SA, uint64_t n);
@@ -176,6 +182,17 @@ int pfp_pwrite_dev(pfp_ctx *ctx, const char *path, uint64_t file_offset, const v
 int pfp_sample_runs_dev(pfp_ctx *ctx, const void *d_bwt, const void *d_sa, uint64_t count, uint64_t pos_base,
                         int left_byte, int right_byte, int run_end, void *d_out10, uint64_t cap_pairs,
                         uint64_t *n_pairs);
+
+/* Device-resident chain that hands back the reference's SA-derived FILES instead of SA values: d_out[0] = .sa
+ * bytes (PFP_FLAG_SA), d_out[1] = .ssa, d_out[2] = .esa - device buffers allocated by the library, released with
+ * pfp_dev_free; out_bytes their sizes; entries for flags not set stay NULL / 0.  The SA values live inside the call
+ * only (8 bytes per text byte, allocated after the suffix sorter has returned its scratch), so a >= 10 GB input
+ * with -s fits one GPU.  d_bwt as in pfp_bigbwt_dev. */
+int pfp_bigbwt_formats_dev(pfp_ctx *ctx, const void *d_text, uint64_t n, int w, uint64_t p, int flags, void *d_bwt,
+                           void *d_out[3], uint64_t out_bytes[3], uint64_t *n_used);
+void pfp_dev_free(pfp_ctx *ctx, void *d_ptr);
+/* device -> host copy through the context's pinned staging buffers (for buffers the library handed out) */
+int pfp_memcpy_d2h(pfp_ctx *ctx, void *host_dst, const void *d_src, uint64_t nbytes);
 
 /* per-call statistics of the most recent pfp_bigbwt / pfp_bigbwt_dev / pfp_parse on this ctx */
 typedef struct {

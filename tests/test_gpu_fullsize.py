@@ -38,6 +38,20 @@ def run_dev(pkg, ctx, text, w, p, flags):
     return out
 
 
+def run_formats(pkg, ctx, text, w, p, flags):
+    """the same through pfp_bigbwt_formats_dev (SA values stay inside the call, the files come back as device buffers)"""
+    import torch
+    n = text.numel()
+    bwt = torch.empty(n + 17, dtype=torch.uint8, device=text.device)
+    used, outs = ctx.bigbwt_formats_dev(text.data_ptr(), n, bwt.data_ptr(), w, p, flags)
+    assert used == n
+    res = {"bwt": sha_dev(bwt[: n + 1])}
+    for key, (ptr, nbytes) in outs.items():
+        res[key] = hashlib.sha256(ctx.fetch_dev(ptr, nbytes).tobytes()).hexdigest()
+        ctx.dev_free(ptr)
+    return res
+
+
 def check(got, g):
     for key in ("bwt", "sa", "ssa", "esa"):
         if key + "_sha256" in g:
@@ -65,6 +79,10 @@ def test_benchmark_workloads_match_reference_digests(pkg, ctx, synth, golden_ful
     text = synth.workload_text_torch(torch.device("cuda", 0), name)
     assert text.numel() == g["n"] and sha_dev(text) == g["text_sha256"]          # torch evaluator == numpy evaluator
     check(run_dev(pkg, ctx, text, g["w"], g["p"], g["flags"]), g)
+    if g["flags"]:
+        got = run_formats(pkg, ctx, text, g["w"], g["p"], g["flags"])
+        assert set(got) == {"bwt"} | {k for k, bit in (("sa", 1), ("ssa", 2), ("esa", 4)) if g["flags"] & bit}
+        check(got, g)
 
 
 def test_pack_and_sample_exports_on_slices(O, pkg, ctx):

@@ -128,6 +128,15 @@ def test_suffix_sorters_match_oracle(O, wctx):
     assert np.array_equal(ctx.gsacak64(d), sa.astype(np.uint64))
     assert np.array_equal(ctx.sacak64(t), O.sacak(t).astype(np.uint64))
     assert np.array_equal(ctx.sacak_int64(s), O.sacak_int(s).astype(np.uint64))
+    # gsacak's optional LCP and DA outputs (gsa/gsacak.h:96-105, gsa/README.md:76-104)
+    osa, olcp = O.gsacak(d, want_lcp=True)
+    word_of = np.concatenate([[0], np.cumsum(d == 1)[:-1]])          # index of the string every position lies in
+    for wide in (False, True):
+        gsa, glcp, gda = ctx.gsacak_lcp_da(d, wide)
+        assert np.array_equal(gsa.astype(np.uint32), osa) and np.array_equal(glcp.astype(np.int32), olcp)
+        assert np.array_equal(gda.astype(np.int64), word_of[osa])
+    esa, elcp, eda = ctx.gsacak_lcp_da(ex)
+    assert elcp.tolist() == O.gsacak(ex, want_lcp=True)[1].tolist()
 
 
 def test_error_behaviour(pkg, ctx, O):

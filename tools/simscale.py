@@ -1,38 +1,62 @@
-"""virtual-rank profile of the distributed chain on ONE GPU: R contexts, phases timed per rank (compute only, no wire)"""
-import sys, os, time, torch, importlib
+"""virtual-rank profile of the distributed chain on ONE GPU: R contexts, one rank's compute phases timed (no wire).
+
+    python tools/simscale.py R [workload] [dedup]
+
+Rank r holds variant r of the workload (bench.py's weak-scaling collection); dist.simulate serves the collectives by
+concatenation, so the sum of the timed library calls of one rank is that rank's compute per step; R = 1 is the
+same chain on one shard."""
+import importlib
+import os
+import sys
+import time
+
+import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as entry, bench
+import __graft_entry__ as entry  # noqa: E402
+
 pkg = entry.load_package()
 D = importlib.import_module("bigbwt_amd.dist")
+synth = importlib.import_module("bigbwt_amd.synth")
 dev = torch.device('cuda', 0)
-R = int(sys.argv[1]); name = sys.argv[2] if len(sys.argv) > 2 else 'c2'
-wl = bench.WORKLOADS[name]
-texts = [bench.make_text(dev, wl, 2, variant=r) for r in range(R)]
+R = int(sys.argv[1]); name = sys.argv[2] if len(sys.argv) > 2 else 'c3'
+dedup = sys.argv[3] if len(sys.argv) > 3 else 'alltoall'
+wl = synth.WORKLOADS[name]
+texts = [synth.workload_text_torch(dev, name, variant=r) for r in range(R)]
+torch.cuda.empty_cache()
 ctxs = [pkg.Context(0) for _ in range(R)]
-# time the methods of rank 0's context
 acc = {}
+
+
 def wrap(obj, meth):
     f = getattr(obj, meth)
+
     def g(*a, **k):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         r = f(*a, **k)
         torch.cuda.synchronize(); acc[meth] = acc.get(meth, 0.0) + (time.perf_counter() - t0) * 1e3
         return r
     setattr(obj, meth, g)
-for m_ in ('dist_propose_triggers', 'dist_local_parse', 'dist_export_local', 'dist_global_sort', 'dist_global_finish', 'dist_merge'):
+
+
+for m_ in ('dist_propose_triggers', 'dist_local_parse', 'dist_export_local', 'dist_partition_words', 'dist_export_partition',
+           'dist_owner_dedup', 'dist_export_owned', 'dist_global_sort', 'dist_global_sort_distinct', 'dist_global_finish', 'dist_merge',
+           'pack5_dev', 'sample_runs_dev'):
     wrap(ctxs[R - 1], m_)
 for it in range(2):
     acc.clear()
-    if it == 1: ctxs[R - 1].set_kernel_trace(True)
+    if it == 1:
+        ctxs[R - 1].set_kernel_trace(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    res = D.simulate(ctxs, texts, wl['w'], wl['p'], 0)
+    res = D.simulate(ctxs, texts, wl['w'], wl['p'], wl['flags'], dedup=dedup)
     torch.cuda.synchronize(); el = (time.perf_counter() - t0) * 1e3
-print('R=%d workload=%s total wall (all ranks sequential) %.1f ms' % (R, name, el))
-print('last rank phases ms:', {k: round(v, 2) for k, v in acc.items()}, 'sum %.1f' % sum(acc.values()))
-print('stats', res[R - 1]['stats'])
-
+print('R=%d workload=%s dedup=%s flags=%d total wall (all ranks one after the other) %.1f ms' % (R, name, dedup, wl['flags'], el))
+print('last rank compute ms:', {k: round(v, 2) for k, v in acc.items()}, 'sum %.1f' % sum(acc.values()))
+st = res[R - 1]['stats']
+print('stats', {k: st[k] for k in ('phrases_total', 'shard_bytes', 'sa_shares', 'dedup')}, st['glob'])
 kt = ctxs[R - 1].kernel_trace()
 rows = sorted(kt, key=lambda r: -r['total_ms'])
-for r in rows[:14]: print('   %-48s %8.2f ms %5d launches' % (r['name'], r['total_ms'], r['launches']))
+for r in rows[:12]:
+    print('   %-48s %8.2f ms %5d launches' % (r['name'], r['total_ms'], r['launches']))
 print('   traced total %.1f ms' % sum(r['total_ms'] for r in rows))
