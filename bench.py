@@ -329,7 +329,7 @@ def main():
                                        f"{world} independent texts (one per GPU), no collective")},
             "roofline": roofline,
             "roofline_passes": passes,
-            "kernels": rows[:14],
+            "kernels": rows[:24],
             "scan_pass_k1": scan_row,
             "cpu_baseline": cpu,
             "host_buffer_boundary": host_boundary,

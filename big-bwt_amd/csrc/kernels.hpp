@@ -175,7 +175,23 @@ struct BwtOutputs {
   uint64_t *d_sa = nullptr;    // [n+1] device, caller-provided when flags != 0
   uint64_t hard_groups = 0, hard_chars = 0, hard_big_groups = 0, hard_max_chars = 0, hard_max_members = 0;
   uint64_t hard_minor_groups = 0, hard_minor_chars = 0;   // groups handled by majority fill; occurrences ranked for them
+  // -s / -e without -S (sparse SA): the run boundaries of the emitted BWT slice - bit r of bmap = position r starts or ends
+  // a run, bpre[k] = boundaries before bit 64 k, n_bound of them in all.  With d_sa == nullptr the SA values live in
+  // sa_c[rank of the position among the boundaries] (16 bytes per run instead of 8 per text byte); with d_sa given they
+  // are stored there, at boundary positions only.
+  DBuf<uint64_t> bmap, bpre, sa_c;
+  uint64_t n_bound = 0;
 };
+// where the SA value of BWT position i (relative to the slice the arrays describe) is found
+struct SaView {
+  const uint64_t *dense = nullptr;                       // dense[i], or
+  const uint64_t *bmap = nullptr, *bpre = nullptr, *sa_c = nullptr;      // sa_c[rank of i among the set bits of bmap]
+};
+inline SaView sa_view(const BwtOutputs &o) {
+  SaView v;
+  if (o.sa_c.p) { v.bmap = o.bmap.p; v.bpre = o.bpre.p; v.sa_c = o.sa_c.p; } else v.dense = o.d_sa;
+  return v;
+}
 // emits BWT positions [out_lo,out_hi) into out.d_bwt[0..) / out.d_sa[0..) (default: everything)
 template <class I>
 void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const SuffixOrderT<I> &so, const ParseBWT &pb,
@@ -186,7 +202,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
 void pack5_dev(pfp_ctx *c, const uint64_t *vals, uint64_t cnt, uint8_t *out5);
 void unpack5_dev(pfp_ctx *c, const uint8_t *in5, uint64_t cnt, uint64_t *vals);
 // pairs (pos,sa) packed as 10 bytes each; returns pair count; out buffer allocated inside
-uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const uint64_t *sa, uint64_t n_out, bool run_end,
+uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const SaView &sa, uint64_t n_out, bool run_end,
                          DBuf<uint8_t> &out10);
 // the same in two steps over a slice of the BWT (multi-GPU): count the boundaries, then place the pairs.
 // left / right = the BWT byte just before / after the slice, -1 at the ends of the whole BWT.
@@ -195,7 +211,7 @@ struct RunSampler {
   uint64_t ntile = 0, pairs = 0;
   DBuf<uint32_t> tile_cnt; DBuf<uint64_t> tile_off;
   RunSampler(pfp_ctx *c, const uint8_t *bwt, uint64_t cnt, int left, int right, bool run_end);   // counts (one sync)
-  void place(const uint64_t *sa, uint64_t pos_base, uint8_t *out10);                               // sa[i] belongs to bwt[i]
+  void place(const SaView &sa, uint64_t pos_base, uint8_t *out10);                                 // SA value i belongs to bwt[i]
 };
 
 

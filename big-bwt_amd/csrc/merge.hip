@@ -369,7 +369,32 @@ struct MergeArgsT {
   const uint64_t *tbase; const uint32_t *loc;    // output offset of slot t = tbase[t >> 11] + loc[t] (slot_off)
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
   uint8_t *bwt; uint64_t *out_sa;
+  // what a launch writes: BWT chars (bit 0), SA values (bit 1).  Dense SA does both at once; sparse SA needs the finished
+  // BWT to know where values are looked at, so its kernels run twice.
+  int pass;
+  // sparse SA: bit (x - out_lo) of bmap is set where position x starts or ends a run of the BWT (the two ends of the
+  // slice always count); bpre[k] = boundaries before bit 64 k.  SA values go to sa_c[rank of x among the boundaries]
+  // (the caller keeps no SA array), or to out_sa[x] - only where the bit is set.
+  const uint64_t *bmap, *bpre;
+  uint64_t *sa_c;
 };
+enum : int { PASS_BWT = 1, PASS_SA = 2 };
+template <class I>
+__device__ __forceinline__ void sa_put(const MergeArgsT<I> &a, uint64_t x, uint64_t v) {
+  if (x < a.out_lo || x >= a.out_hi) return;
+  if (!a.bmap) { a.out_sa[x] = v; return; }
+  const uint64_t r = x - a.out_lo, wv = a.bmap[r >> 6];
+  if (!((wv >> (r & 63)) & 1ull)) return;
+  if (a.sa_c) a.sa_c[a.bpre[r >> 6] + (uint64_t)__popcll(wv & ((1ull << (r & 63)) - 1ull))] = v;
+  else a.out_sa[x] = v;
+}
+template <class I>
+__device__ __forceinline__ bool sa_wanted(const MergeArgsT<I> &a, uint64_t x) {      // would sa_put(x) store anything?
+  if (x < a.out_lo || x >= a.out_hi) return false;
+  if (!a.bmap) return true;
+  const uint64_t r = x - a.out_lo;
+  return (a.bmap[r >> 6] >> (r & 63)) & 1ull;
+}
 // Exclusive prefix of the per-slot counts, kept as a 64-bit base per 2048 slots (= one expand workgroup) and a
 // 32-bit offset inside the tile: 4 bytes per slot to write and read instead of 8, and the N-long scan
 // becomes one streaming tile kernel plus a scan over N/2048 sums.
@@ -414,7 +439,7 @@ __device__ __forceinline__ void expand_stage(const MergeArgsT<I> &a, ExpandLds &
     const uint64_t t = t0 + s;
     uint8_t ch = a.pc[t];
     uint8_t cls = ch == 0 ? CLS_NONE : (ch == kEndOfWord ? CLS_FULL : CLS_FILL);
-    if (cls == CLS_FILL) {
+    if (cls == CLS_FILL && a.pass != PASS_SA) {      // (the SA-only round of the sparse mode looks at whole words only)
       const I g = a.grp[t];
       if (a.hard[g]) {
         cls = CLS_HARD;
@@ -478,10 +503,10 @@ __device__ __forceinline__ void expand_sa_1(const MergeArgsT<I> &a, const Expand
   while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (L.loff[mid] <= x) lo = mid; else hi = mid; }
   const uint8_t cl = L.lcls[lo];
   if (cl != CLS_FULL && (cl != CLS_FILL || a.want_sa == SA_SPARSE)) return;
+  if (!sa_wanted(a, base + x)) return;
   const I i = a.sa[t0 + lo];
   const uint64_t pos = a.ilist[slot_ist(a, t0 + lo) + (uint32_t)(x - L.loff[lo])];
-  a.out_sa[base + x] = (cl == CLS_FULL && a.pos_base + base + x == 0) ? a.n_out_global - 1
-                                                                      : a.bwsai[pos] - (uint64_t)a.slen[i];
+  sa_put(a, base + x, (cl == CLS_FULL && a.pos_base + base + x == 0) ? a.n_out_global - 1 : a.bwsai[pos] - (uint64_t)a.slen[i]);
 }
 
 // Sparse SA mode (-s / -e without -S): SA values are only looked at where a run of the BWT starts or ends.
@@ -506,8 +531,10 @@ __global__ __launch_bounds__(256) void expand_kernel(MergeArgsT<I> a, uint32_t *
   // a block whose slots emit more than the quota (a word with hundreds of thousands of
   // occurrences) finishes only its first quota here; expand_heavy_kernel shares the rest
   const uint64_t mine = Ltot <= kExpandQuota ? Ltot : kExpandQuota;
-  if (Ltot > kExpandQuota && threadIdx.x == 0) { uint32_t i = atomicAdd(nheavy, 1u); if (i < heavy_cap) heavy[i] = BID; }
-  for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < mine; x0 += 256 * 16) expand_16(a, L, t0, ns, base, x0, Ltot);
+  if (Ltot > kExpandQuota && threadIdx.x == 0 && (a.pass & PASS_BWT)) { uint32_t i = atomicAdd(nheavy, 1u); if (i < heavy_cap) heavy[i] = BID; }
+  if (a.pass & PASS_BWT)
+    for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < mine; x0 += 256 * 16) expand_16(a, L, t0, ns, base, x0, Ltot);
+  if (!(a.pass & PASS_SA)) return;
   if (SPARSE) {
     for (int s = threadIdx.x; s < ns; s += 256)
       if (L.lcls[s] == CLS_FULL) fulls[atomicAdd(&nfull, 1u)] = (uint32_t)s;
@@ -533,9 +560,10 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgsT<I> a, cons
     __syncthreads();
     expand_stage(a, L, t0, ns, base);
     const uint64_t Ltot = L.loff[ns];
-    for (uint64_t x0 = kExpandQuota + ((uint64_t)BID * 256 + threadIdx.x) * 16; x0 < Ltot; x0 += (uint64_t)GDIM * 256 * 16)
-      expand_16(a, L, t0, ns, base, x0, Ltot);
-    if (a.want_sa)      // sparse mode: expand_sa_1 writes for full-word slots only (other classes come from unit_edges_kernel)
+    if (a.pass & PASS_BWT)
+      for (uint64_t x0 = kExpandQuota + ((uint64_t)BID * 256 + threadIdx.x) * 16; x0 < Ltot; x0 += (uint64_t)GDIM * 256 * 16)
+        expand_16(a, L, t0, ns, base, x0, Ltot);
+    if (a.want_sa && (a.pass & PASS_SA))      // sparse mode: expand_sa_1 writes for full-word slots only (other classes come from unit_edges_kernel)
       for (uint64_t x = kExpandQuota + (uint64_t)BID * 256 + threadIdx.x; x < Ltot; x += (uint64_t)GDIM * 256)
         expand_sa_1(a, L, t0, ns, base, x);
   }
@@ -546,17 +574,9 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgsT<I> a, cons
 // the unit's first position - when the unit before ends in a different char - and end only at its last position.
 // The first position belongs to the smallest BWT(P) position over the members' inverted lists, the last one to the
 // largest (wfirst / wlast per word): O(members) per unit instead of merging the lists (pfbwt.cpp:605-676 walks a
-// heap through all of them).  One lane per slot: chars of the neighbouring units by ballot, "needed" flags spread
-// over a unit's lanes, segmented min / max by shuffles; a unit that crosses the wave is finished serially by
-// its first (last) lane.
-template <class I>
-__device__ __forceinline__ uint32_t unit_char_of_slot(const MergeArgsT<I> &a, uint64_t t) {      // 0x100: unknown
-  const uint32_t c = a.pc[t];
-  if (c == 0) return 0x200u;                       // emits nothing
-  if (c == kEndOfWord) return 0x100u;
-  if (a.hard[a.grp[t]]) return 0x100u;
-  return fix_char((uint8_t)c);
-}
+// heap through all of them).  One lane per slot: whether the two positions can be sampled from the boundary bitmap of
+// the finished BWT, "needed" flags spread over a unit's lanes, segmented min / max by shuffles; a unit that crosses the
+// wave is finished serially by its first (last) lane.
 template <class I>
 __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
   const uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
@@ -564,35 +584,24 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
   const uint64_t wbase = t - lane;
   const bool in = t < a.N;
   const uint32_t ch = in ? a.pc[t] : 0u;
-  const bool emit = ch != 0, full = ch == kEndOfWord;
+  const bool unit = ch != 0 && ch != kEndOfWord;        // lanes that belong to a fill / hard unit (whole words: expand_kernel)
   uint64_t g = t;
-  bool hd = false;
-  if (emit && !full) { g = a.grp[t]; hd = a.hard[g] != 0; }
-  const bool unit = emit && !full;                 // lanes that belong to a fill / hard unit
-  const uint32_t cu = (!emit) ? 0x200u : ((full || hd) ? 0x100u : (uint32_t)fix_char((uint8_t)ch));
-  const unsigned long long em = __ballot(emit);
+  if (unit) g = a.grp[t];
+  const unsigned long long um = __ballot(unit);
   // same unit as the next slot?
   const uint64_t g_next = __shfl_down(g, 1, 64);
-  const bool emit_next = (em >> ((lane + 1) & 63)) & 1ull;
+  const bool unit_next = (um >> ((lane + 1) & 63)) & 1ull;
   bool cont;                                       // the unit goes on in slot t + 1
-  if (lane < 63) cont = unit && emit_next && g_next == g;
+  if (lane < 63) cont = unit && unit_next && g_next == g;
   else cont = unit && t + 1 < a.N && a.pc[t + 1] != 0 && a.pc[t + 1] != kEndOfWord && a.grp[t + 1] == (I)g;
   const bool head = unit && g == t;
   const bool last = unit && !cont;
-  // char of the emitting slot before / after (by lane; outside the wave: bounded walk)
-  const unsigned long long below = em & ((1ull << lane) - 1ull), above = lane < 63 ? em & ~((2ull << lane) - 1ull) : 0ull;
-  const int pl = below ? 63 - __clzll((long long)below) : lane, nl = above ? __ffsll((long long)above) - 1 : lane;
-  uint32_t prevc = __shfl(cu, pl, 64), nextc = __shfl(cu, nl, 64);
-  if (head && !below) {
-    prevc = 0x100u;
-    for (uint64_t tt = t, steps = 0; tt > 0 && steps < 64; steps++) { tt--; const uint32_t c = unit_char_of_slot(a, tt); if (c != 0x200u) { prevc = c; break; } }
-  }
-  if (last && !above) {
-    nextc = 0x100u;
-    for (uint64_t tt = t + 1, steps = 0; tt < a.N && steps < 64; tt++, steps++) { const uint32_t c = unit_char_of_slot(a, tt); if (c != 0x200u) { nextc = c; break; } }
-  }
-  const bool need_first = head && (hd || prevc != cu || prevc == 0x100u);
-  const bool need_last = last && (hd || nextc != cu || nextc == 0x100u);
+  // is the unit's first / last position one the sampled files can look at?
+  uint64_t o_first = 0, o_last = 0;
+  if (head) o_first = slot_off(a, t);
+  if (last) o_last = slot_off(a, t + 1) - 1;
+  const bool need_first = head && sa_wanted(a, o_first);
+  const bool need_last = last && sa_wanted(a, o_last);
   // spread the two flags over the lanes of the unit that lie in this wave
   const bool head_here = unit && g >= wbase;
   const int hl = head_here ? (int)(g - wbase) : lane;
@@ -627,17 +636,62 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
   if (need_first) {
     if (cont63 && g63 == g)
       for (uint64_t m = wbase + 64; m < a.N && a.grp[m] == (I)g; m++) { const uint32_t f = a.wfirst[a.pos_word[a.sa[m]]]; mn = f < mn ? f : mn; }
-    const uint64_t o = slot_off(a, t);
-    if (o >= a.out_lo && o < a.out_hi) a.out_sa[o] = a.bwsai[mn] - (uint64_t)a.slen[myi];
+    sa_put(a, o_first, a.bwsai[mn] - (uint64_t)a.slen[myi]);
   }
   if (need_last) {
     if (g < wbase)
       for (uint64_t m = wbase; m-- > g;) { const uint32_t l = a.wlast[a.pos_word[a.sa[m]]]; mx = l > mx ? l : mx; }
-    const uint64_t o = slot_off(a, t + 1) - 1;
-    if (o >= a.out_lo && o < a.out_hi) a.out_sa[o] = a.bwsai[mx] - (uint64_t)a.slen[myi];
+    sa_put(a, o_last, a.bwsai[mx] - (uint64_t)a.slen[myi]);
   }
 }
 
+// Boundaries of the runs of the BWT slice [out_lo, out_hi): bit r of the map = position out_lo + r starts a run
+// (differs from the byte before) or ends one (differs from the byte after); the slice's own first and last position
+// always count - their neighbours belong to another rank.
+constexpr int kRunTile = 4096;
+__device__ __forceinline__ void run_mask16(const uint8_t *__restrict__ bwt, uint64_t base, uint64_t cnt, int left, int right,
+                                           int run_end, uint32_t m[4]) {
+  m[0] = m[1] = m[2] = m[3] = 0;
+  if (base >= cnt) return;
+  if (base + 17 <= cnt && base >= 1) {          // interior: both neighbours of all 16 positions are inside the slice
+    const uint4 x = ld16u(bwt + base);
+    const uint4 y = run_end ? ld16u(bwt + base + 1) : ld16u(bwt + base - 1);
+    m[0] = nonzero_bytes(x.x ^ y.x); m[1] = nonzero_bytes(x.y ^ y.y); m[2] = nonzero_bytes(x.z ^ y.z); m[3] = nonzero_bytes(x.w ^ y.w);
+    return;
+  }
+  for (int k = 0; k < 16; k++) {
+    const uint64_t i = base + k;
+    if (i >= cnt) break;
+    const int b = bwt[i];
+    int nb;
+    if (run_end) nb = i + 1 < cnt ? (int)bwt[i + 1] : right;
+    else nb = i ? (int)bwt[i - 1] : left;
+    if (nb < 0 || nb != b) m[k >> 2] |= 1u << (8 * (k & 3));
+  }
+}
+__device__ __forceinline__ uint32_t pack_byte_flags(uint32_t m) {      // flags at bits 0, 8, 16, 24 -> bits 0..3
+  return (m & 1u) | ((m >> 7) & 2u) | ((m >> 14) & 4u) | ((m >> 21) & 8u);
+}
+// one lane per 16 positions (one 16-byte load and its two shifted neighbours), four lanes make one word of the map
+__global__ __launch_bounds__(256) void run_bitmap_kernel(const uint8_t *__restrict__ bwt, uint64_t cnt, uint64_t *__restrict__ bmap,
+                                                         uint32_t *__restrict__ wcnt) {
+  const uint64_t ch = (uint64_t)BID * 256 + threadIdx.x;
+  const uint64_t base = ch * 16;
+  uint32_t ms[4], me[4];
+  run_mask16(bwt, base, cnt, -1, -1, 0, ms);
+  run_mask16(bwt, base, cnt, -1, -1, 1, me);
+  uint32_t bits = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) bits |= pack_byte_flags(ms[q] | me[q]) << (4 * q);
+  uint64_t v = (uint64_t)bits << (16 * (threadIdx.x & 3));
+  v |= __shfl_xor(v, 1, 64);
+  v |= __shfl_xor(v, 2, 64);
+  if ((threadIdx.x & 3) == 0 && base < cnt) { bmap[ch >> 2] = v; wcnt[ch >> 2] = (uint32_t)__popcll(v); }
+}
+__global__ void count_unset_kernel(const uint64_t *__restrict__ v, uint64_t n, unsigned long long *__restrict__ total) {
+  const uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (i < n && v[i] == ~0ull) atomicAdd(total, 1ull);
+}
 // Hard groups, BWT-only and sparse-SA modes: majority fill + minority placement.  The members of a group of equal
 // suffixes whose preceding chars disagree are, in a collection of similar sequences, one or a few words with most of
 // the occurrences and one char (the base phrase and the variants that differ elsewhere) plus a handful of
@@ -650,6 +704,9 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
 // Groups where no char dominates and that fit the LDS kernels keep the old path (fallback list).
 struct HardGroupInfo { uint64_t g; uint64_t E; uint32_t k; uint32_t minor; };
 struct MinorMember { uint64_t g; uint32_t k, m; };      // member m (of k) of the hard group at head slot g does not carry the majority char
+// sparse SA: what the second pass needs of a placed minority occurrence - its output position, its BWT(P) position
+// and those of its neighbours in the merged order (flags bit 0 / 1: there is a predecessor / successor), suffix length
+struct MinorRec { uint64_t o; uint32_t pos, pred, succ, flags, sl, pad; };
 template <class I>
 __global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, const I *__restrict__ heads, uint64_t nH,
                                                             uint8_t *__restrict__ gmaj, HardGroupInfo *__restrict__ info,
@@ -729,7 +786,8 @@ __global__ __launch_bounds__(256) void hard_minor_fill_kernel(MergeArgsT<I> a, c
 // lower_bound in every other member's inverted list, the group's members shared among the lanes (every lane fetches
 // the inverted-list start of its members and bisects there) - rank, predecessor and successor combined by shuffles
 template <class I>
-__global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const MinorMember *__restrict__ mem, uint64_t total) {
+__global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const MinorMember *__restrict__ mem, uint64_t total,
+                                                         MinorRec *__restrict__ recs, unsigned long long *__restrict__ nrecs) {
   const int l8 = threadIdx.x & 7;
   const uint64_t rounds = (total + GDIM * 32 - 1) / (GDIM * 32);      // every lane runs the same number of rounds (shuffles inside)
   for (uint64_t it = 0; it < rounds; it++) {
@@ -787,19 +845,21 @@ __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const 
       }
       if (!act || l8 != 0) continue;
       const uint64_t o = base + r;
-      if (o >= a.out_lo && o < a.out_hi) {
-        a.bwt[o] = mych;
-        if (a.want_sa) {
-          a.out_sa[o] = a.bwsai[pos] - sl;
-          if (has_pred && o - 1 >= a.out_lo) a.out_sa[o - 1] = a.bwsai[pred] - sl;
-          if (has_succ && o + 1 < a.out_hi) a.out_sa[o + 1] = a.bwsai[succ] - sl;
-        }
-      } else if (a.want_sa) {      // the occurrence lies just outside this rank's slice: its neighbours may be inside
-        if (has_pred && o >= 1 && o - 1 >= a.out_lo && o - 1 < a.out_hi) a.out_sa[o - 1] = a.bwsai[pred] - sl;
-        if (has_succ && o + 1 >= a.out_lo && o + 1 < a.out_hi) a.out_sa[o + 1] = a.bwsai[succ] - sl;
-      }
+      if (o >= a.out_lo && o < a.out_hi) a.bwt[o] = mych;
+      if (a.want_sa)       // (also when the occurrence lies just outside this rank's slice: its neighbours may be inside)
+        recs[atomicAdd(nrecs, 1ull)] = MinorRec{o, pos, pred, succ, has_pred | (has_succ << 1), (uint32_t)sl, 0u};
     }
   }
+}
+
+template <class I>
+__global__ void hard_minor_sa_kernel(MergeArgsT<I> a, const MinorRec *__restrict__ recs, uint64_t n) {
+  const uint64_t q = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const MinorRec r = recs[q];
+  sa_put(a, r.o, a.bwsai[r.pos] - (uint64_t)r.sl);
+  if ((r.flags & 1u) && r.o >= 1) sa_put(a, r.o - 1, a.bwsai[r.pred] - (uint64_t)r.sl);
+  if (r.flags & 2u) sa_put(a, r.o + 1, a.bwsai[r.succ] - (uint64_t)r.sl);
 }
 
 // Hard groups.  hard[] is 1 exactly at the head slot of every hard group; the heads are compacted
@@ -937,8 +997,8 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgsT<I> a, const
         }
         const uint64_t o = L.gbase[gi] + r;
         if (o >= a.out_lo && o < a.out_hi) {
-          a.bwt[o] = L.lmch[q];
-          if (a.want_sa) a.out_sa[o] = a.bwsai[pos] - (uint64_t)L.lmsl[q];
+          if (a.pass & PASS_BWT) a.bwt[o] = L.lmch[q];
+          if (a.want_sa && (a.pass & PASS_SA)) sa_put(a, o, a.bwsai[pos] - (uint64_t)L.lmsl[q]);
         }
       }
       wave_lds_sync();
@@ -995,8 +1055,8 @@ __global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgsT<I> a, const B
       uint32_t lo = 0, hi = k;
       while (hi - lo > 1) { const uint32_t mdl = (lo + hi) >> 1; if (slot_off(a, g + mdl) - base <= e) lo = mdl; else hi = mdl; }
       const uint64_t t = g + lo;
-      a.bwt[o] = fix_char(a.pc[t]);
-      if (a.want_sa) a.out_sa[o] = a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]];
+      if (a.pass & PASS_BWT) a.bwt[o] = fix_char(a.pc[t]);
+      if (a.want_sa && (a.pass & PASS_SA)) sa_put(a, o, a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]]);
     }
     wave_lds_sync();
   }
@@ -1027,8 +1087,8 @@ __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgsT<I> a, const Bi
       r += l2;
     }
     if (base + r >= a.out_lo && base + r < a.out_hi) {
-      a.bwt[base + r] = fix_char(a.pc[t]);
-      if (a.want_sa) a.out_sa[base + r] = a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]];
+      if (a.pass & PASS_BWT) a.bwt[base + r] = fix_char(a.pc[t]);
+      if (a.want_sa && (a.pass & PASS_SA)) sa_put(a, base + r, a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]]);
     }
   }
 }
@@ -1081,7 +1141,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   // SA values: none, all (-S), or only where the sampled files can look (-s / -e): run boundaries of the BWT
   const int sa_mode = !flags ? SA_NONE : ((flags & PFP_FLAG_SA) ? SA_DENSE : SA_SPARSE);
   static const bool dense_always = getenv("PFP_DENSE_SA") != nullptr;      // tests: -s / -e through the dense path
-  const int samode = (sa_mode == SA_SPARSE && dense_always) ? SA_DENSE : sa_mode;
+  const int samode = (sa_mode == SA_SPARSE && dense_always && out.d_sa) ? SA_DENSE : sa_mode;
   const bool dense = samode == SA_DENSE;
   DBuf<uint32_t> wfirst, wlast;
   if (samode == SA_SPARSE) { wfirst.alloc(c, d); wlast.alloc(c, d); }
@@ -1182,6 +1242,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     n_mm = read_scalar(c, mm_off.p + n_heads);
     if (n_mm) {
       mm_list.alloc(c, n_mm);
+      KScope ks(c, "pfp::hard_minor_fill_kernel", n_heads * 40 + n_mm * 16);
       hipLaunchKernelGGL(hard_minor_fill_kernel<I>, gdim(cdiv(n_heads, 256)), gdim(256), 0, c->stream, a, ginfo.p, n_heads, mm_off.p, gmaj.p,
                          mm_list.p);
     }
@@ -1198,25 +1259,32 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     }
     hard_list = fb_heads.p; hard_list_n = nheads.p + 1;
   }
-  {
-    const uint32_t nblk = (uint32_t)cdiv64(N, kSlots);
-    DBuf<uint32_t> heavy(c, nblk), nheavy(c, 1);
-    nheavy.zero();
-    { KScope ks(c, "pfp::expand_kernel", N * 14 + n_out * (dense ? 17 : 1));
-    if (samode == SA_SPARSE) hipLaunchKernelGGL((expand_kernel<I, 1>), gdim(nblk), gdim(256), 0, c->stream, a, heavy.p, nheavy.p, nblk);
-    else hipLaunchKernelGGL((expand_kernel<I, 0>), gdim(nblk), gdim(256), 0, c->stream, a, heavy.p, nheavy.p, nblk); }
-    const uint32_t nh = read_scalar(c, nheavy.p);
+  const bool sparse = samode == SA_SPARSE;
+  // what one launch writes: chars and SA values together (dense), or chars first and - once the finished BWT says where
+  // the sampled files can look - SA values in a second round of the same kernels (sparse)
+  a.pass = sparse ? PASS_BWT : (PASS_BWT | PASS_SA);
+  const uint32_t nblk = (uint32_t)cdiv64(N, kSlots);
+  DBuf<uint32_t> heavy(c, nblk), nheavy(c, 1);
+  nheavy.zero();
+  uint32_t nh = 0;
+  auto run_expand = [&]() {
+    { KScope ks(c, "pfp::expand_kernel", a.pass == PASS_SA ? N * 5 + pb.P * 28 : N * 14 + n_out * (dense ? 17 : 1));
+      if (sparse) hipLaunchKernelGGL((expand_kernel<I, 1>), gdim(nblk), gdim(256), 0, c->stream, a, heavy.p, nheavy.p, nblk);
+      else hipLaunchKernelGGL((expand_kernel<I, 0>), gdim(nblk), gdim(256), 0, c->stream, a, heavy.p, nheavy.p, nblk); }
+    if (a.pass & PASS_BWT) nh = read_scalar(c, nheavy.p);
     KScope ks2(c, "pfp::expand_heavy_kernel", 0);   // bytes are accounted in expand_kernel's n_out term
     if (nh) hipLaunchKernelGGL(expand_heavy_kernel<I>, gdim(c->n_cu * 4), gdim(256), 0, c->stream, a, heavy.p, nh);
-  }
-  if (samode == SA_SPARSE) {
-    KScope ks(c, "pfp::unit_edges_kernel", N * (1 + sizeof(I) * 2 + 4));
-    hipLaunchKernelGGL(unit_edges_kernel<I>, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, a);
-  }
+    PFP_HIP(hipGetLastError());
+  };
+  run_expand();
+  DBuf<MinorRec> recs;
+  DBuf<unsigned long long> nrecs(c, 1);
+  nrecs.zero();
   if (n_mm) {
+    if (sparse) recs.alloc(c, n_minor + 1);
     KScope ks(c, "pfp::hard_minor_kernel", n_minor * 64);
     hipLaunchKernelGGL(hard_minor_kernel<I>, gdim((unsigned)std::min<uint64_t>(cdiv64(n_mm, 32), (uint64_t)c->n_cu * 64)), gdim(256), 0,
-                       c->stream, a, mm_list.p, n_mm);
+                       c->stream, a, mm_list.p, n_mm, recs.p, nrecs.p);
   }
   PFP_HIP(hipGetLastError());
   for (;;) {
@@ -1235,17 +1303,14 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   out.hard_chars = c->h_scalars[0];
   out.hard_groups = c->h_scalars[1];
   out.hard_minor_groups = n_heads - n_fallback; out.hard_minor_chars = n_minor;
-  out.hard_chars += read_scalar(c, (const uint64_t *)mstat.p);      // all chars of hard groups, whichever path wrote them
-  out.hard_groups += n_heads - n_fallback;
   out.hard_big_groups = c->h_scalars[2]; out.hard_max_chars = 0; out.hard_max_members = c->h_scalars[4];
   const uint32_t nmid = (uint32_t)std::min<uint64_t>(c->h_scalars[3], mid_cap);
   PFP_REQUIRE(c->h_scalars[3] <= mid_cap, PFP_EHIP, "more sorted-path hard groups than the output can hold");
   const uint32_t nbig = (uint32_t)c->h_scalars[2];
-  if (nmid) {
-    KScope ks(c, "pfp::hard_sort_kernel", (uint64_t)nmid * (kHardSortMin + 1) * (samode ? 21 : 5));      // lower bound: ilist entry + char (+ SA) per occurrence
-    hipLaunchKernelGGL(hard_sort_kernel<I>, gdim(c->n_cu * 4), gdim(256), 0, c->stream, a, mid.p, nmid);
-    PFP_HIP(hipGetLastError());
-  }
+  out.hard_chars += read_scalar(c, (const uint64_t *)mstat.p);      // all chars of hard groups, whichever path wrote them
+  out.hard_groups += n_heads - n_fallback;
+  DBuf<uint64_t> estart;
+  uint64_t big_total = 0;
   if (nbig) {
     // occurrences of the queued groups, laid end to end
     std::vector<BigGroup> hb(nbig);
@@ -1253,14 +1318,78 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     sync(c);
     std::vector<uint64_t> es(nbig + 1, 0);
     for (uint32_t q = 0; q < nbig; q++) es[q + 1] = es[q] + hb[q].E;
-    DBuf<uint64_t> estart(c, nbig + 1);
+    estart.alloc(c, nbig + 1);
     PFP_HIP(hipMemcpyAsync(estart.p, es.data(), (nbig + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    const uint64_t total = es[nbig];
-    const int nb = (int)std::min<uint64_t>(cdiv64(total, 256), (uint64_t)c->n_cu * 32);
-    hipLaunchKernelGGL(hard_big_kernel<I>, gdim(nb), gdim(256), 0, c->stream, a, big.p, nbig, estart.p, total);
+    sync(c);      // es is a local
+    big_total = es[nbig];
+  }
+  auto run_queued = [&]() {
+    if (nmid) {
+      KScope ks(c, "pfp::hard_sort_kernel", (uint64_t)nmid * (kHardSortMin + 1) * (samode ? 21 : 5));      // lower bound: ilist entry + char (+ SA) per occurrence
+      hipLaunchKernelGGL(hard_sort_kernel<I>, gdim(c->n_cu * 4), gdim(256), 0, c->stream, a, mid.p, nmid);
+      PFP_HIP(hipGetLastError());
+    }
+    if (nbig) {
+      const int nb = (int)std::min<uint64_t>(cdiv64(big_total, 256), (uint64_t)c->n_cu * 32);
+      KScope ks(c, "pfp::hard_big_kernel", big_total * (samode ? 21 : 5));
+      hipLaunchKernelGGL(hard_big_kernel<I>, gdim(nb), gdim(256), 0, c->stream, a, big.p, nbig, estart.p, big_total);
+      PFP_HIP(hipGetLastError());
+    }
+  };
+  run_queued();
+  if (!sparse) { sync(c); return; }
+
+  // ---- sparse SA, second round: where can the sampled files look?
+  const uint64_t cnt_slice = a.out_hi > a.out_lo ? a.out_hi - a.out_lo : 0;
+  const uint64_t nw = cdiv64(cnt_slice, 64);
+  out.bmap.alloc(c, nw + 1); out.bpre.alloc(c, nw + 1);
+  {
+    DBuf<uint32_t> wcnt(c, nw + 1);
+    PFP_HIP(hipMemsetAsync(wcnt.p + nw, 0, 4, c->stream));
+    PFP_HIP(hipMemsetAsync(out.bmap.p + nw, 0, 8, c->stream));
+    if (nw) {
+      KScope ks(c, "pfp::run_bitmap_kernel", cnt_slice + nw * 12);
+      hipLaunchKernelGGL(run_bitmap_kernel, gdim(cdiv(cdiv64(cnt_slice, 16), 256)), gdim(256), 0, c->stream, out.d_bwt, cnt_slice,
+                         out.bmap.p, wcnt.p);
+    }
+    exclusive_sum_u32_u64(c, wcnt.p, out.bpre.p, nw + 1);
+    out.n_bound = read_scalar(c, out.bpre.p + nw);
+  }
+  a.bmap = out.bmap.p; a.bpre = out.bpre.p;
+  if (!out.d_sa) {      // the caller keeps no SA array: values go to their rank among the boundaries
+    out.sa_c.alloc(c, out.n_bound + 1);
+    if (c->debug) PFP_HIP(hipMemsetAsync(out.sa_c.p, 0xFF, (out.n_bound + 1) * 8, c->stream));
+    a.sa_c = out.sa_c.p;
+  }
+  a.pass = PASS_SA;
+  run_expand();
+  { KScope ks(c, "pfp::unit_edges_kernel", N * (1 + sizeof(I) * 2 + 4));
+    hipLaunchKernelGGL(unit_edges_kernel<I>, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, a); }
+  if (n_mm) {
+    const uint64_t nr = read_scalar(c, (const uint64_t *)nrecs.p);
+    PFP_REQUIRE(nr <= n_minor, PFP_EHIP, "minority placement recorded more occurrences than were counted");
+    if (nr) hipLaunchKernelGGL(hard_minor_sa_kernel<I>, gdim(cdiv(nr, 256)), gdim(256), 0, c->stream, a, recs.p, nr);
+  }
+  if (n_fallback) {      // the groups the LDS kernels ranked: the same ranks again, SA values this time (queues as they stand)
+    DBuf<unsigned long long> scratch(c, 5);
+    scratch.zero();
+    KScope ks(c, "pfp::hard_groups_kernel", N * 5);
+    hipLaunchKernelGGL(hard_groups_kernel<I>, gdim(c->n_cu * 8), gdim(256), 0, c->stream, a, hard_list, hard_list_n, scratch.p, big.p,
+                       0u, mid.p, 0u);
     PFP_HIP(hipGetLastError());
+    run_queued();
     sync(c);
   }
+  PFP_HIP(hipGetLastError());
+  if (c->debug && a.sa_c) {      // every boundary of the BWT must have received its value
+    DBuf<unsigned long long> unset(c, 1);
+    unset.zero();
+    if (out.n_bound)
+      hipLaunchKernelGGL(count_unset_kernel, gdim(cdiv(out.n_bound, 256)), gdim(256), 0, c->stream, out.sa_c.p, out.n_bound, unset.p);
+    const uint64_t u = read_scalar(c, (const uint64_t *)unset.p);
+    PFP_REQUIRE(u == 0, PFP_EHIP, "sparse SA: " + std::to_string(u) + " run boundaries of the BWT received no SA value");
+  }
+  sync(c);
 }
 template void merge_bwt<uint32_t>(pfp_ctx *, const Dictionary &, const DictIndex &, const SuffixOrderT<uint32_t> &, const ParseBWT &,
                                   const uint32_t *, int, int, uint64_t, BwtOutputs &, uint64_t, uint64_t, uint64_t, uint64_t);
@@ -1315,27 +1444,6 @@ void unpack5_dev(pfp_ctx *c, const uint8_t *in5, uint64_t cnt, uint64_t *vals) {
 // positions, tile offsets scanned, then every thread places its pairs <position, SA value> as 10 bytes.
 // left / right: the BWT byte just outside the slice, or -1 at the ends of the whole BWT (then the
 // edge position is a boundary by definition).
-constexpr int kRunTile = 4096;
-__device__ __forceinline__ void run_mask16(const uint8_t *__restrict__ bwt, uint64_t base, uint64_t cnt, int left, int right,
-                                           int run_end, uint32_t m[4]) {
-  m[0] = m[1] = m[2] = m[3] = 0;
-  if (base >= cnt) return;
-  if (base + 17 <= cnt && base >= 1) {          // interior: both neighbours of all 16 positions are inside the slice
-    const uint4 x = ld16u(bwt + base);
-    const uint4 y = run_end ? ld16u(bwt + base + 1) : ld16u(bwt + base - 1);
-    m[0] = nonzero_bytes(x.x ^ y.x); m[1] = nonzero_bytes(x.y ^ y.y); m[2] = nonzero_bytes(x.z ^ y.z); m[3] = nonzero_bytes(x.w ^ y.w);
-    return;
-  }
-  for (int k = 0; k < 16; k++) {
-    const uint64_t i = base + k;
-    if (i >= cnt) break;
-    const int b = bwt[i];
-    int nb;
-    if (run_end) nb = i + 1 < cnt ? (int)bwt[i + 1] : right;
-    else nb = i ? (int)bwt[i - 1] : left;
-    if (nb < 0 || nb != b) m[k >> 2] |= 1u << (8 * (k & 3));
-  }
-}
 __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restrict__ bwt, uint64_t cnt, int left, int right,
                                                         int run_end, uint32_t *__restrict__ tile_cnt) {
   __shared__ uint32_t ws[4];
@@ -1350,7 +1458,7 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
   if (threadIdx.x == 0) tile_cnt[BID] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
-__global__ __launch_bounds__(256) void run_place_kernel(const uint8_t *__restrict__ bwt, const uint64_t *__restrict__ sa,
+__global__ __launch_bounds__(256) void run_place_kernel(const uint8_t *__restrict__ bwt, SaView sa,
                                                         uint64_t cnt, uint64_t pos_base, int left, int right, int run_end,
                                                         const uint64_t *__restrict__ tile_off, uint8_t *__restrict__ out10) {
   __shared__ uint32_t ws[4];
@@ -1370,7 +1478,10 @@ __global__ __launch_bounds__(256) void run_place_kernel(const uint8_t *__restric
 #pragma unroll
   for (int k = 0; k < 16; k++)
     if ((m[k >> 2] >> (8 * (k & 3))) & 1u) {
-      const uint64_t x = pos_base + base + k, v = sa[base + k];
+      const uint64_t x = pos_base + base + k, r = base + k;
+      uint64_t v;
+      if (sa.dense) v = sa.dense[r];
+      else { const uint64_t wv = sa.bmap[r >> 6]; v = sa.sa_c[sa.bpre[r >> 6] + (uint64_t)__popcll(wv & ((1ull << (r & 63)) - 1ull))]; }
       uint8_t *dst = out10 + 10 * o;
       reinterpret_cast<U64u *>(dst)->v = (x & 0xFFFFFFFFFFull) | (v << 40);       // 5 bytes of x, 3 low bytes of v
       reinterpret_cast<U16u *>(dst + 8)->v = (uint16_t)(v >> 24);                  // bytes 3, 4 of v
@@ -1393,7 +1504,7 @@ RunSampler::RunSampler(pfp_ctx *c_, const uint8_t *bwt_, uint64_t cnt_, int left
   PFP_HIP(hipGetLastError());
   pairs = read_scalar(c, tile_off.p + ntile);
 }
-void RunSampler::place(const uint64_t *sa, uint64_t pos_base, uint8_t *out10) {
+void RunSampler::place(const SaView &sa, uint64_t pos_base, uint8_t *out10) {
   if (!ntile || !pairs) return;
   KScope ks(c, "pfp::run_place_kernel", cnt + pairs * 18);
   hipLaunchKernelGGL(run_place_kernel, gdim((unsigned)ntile), gdim(256), 0, c->stream, bwt, sa, cnt, pos_base, left, right,
@@ -1401,7 +1512,7 @@ void RunSampler::place(const uint64_t *sa, uint64_t pos_base, uint8_t *out10) {
   PFP_HIP(hipGetLastError());
 }
 
-uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const uint64_t *sa, uint64_t n_out, bool run_end,
+uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const SaView &sa, uint64_t n_out, bool run_end,
                          DBuf<uint8_t> &out10) {
   RunSampler rs(c, bwt, n_out, -1, -1, run_end);
   out10.alloc(c, rs.pairs * 10 + 16);

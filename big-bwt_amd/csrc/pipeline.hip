@@ -158,7 +158,8 @@ struct Chain {
   DictOrder ord;
   DBuf<uint32_t> occ_lex, word_at_rank, sym;
   ParseBWT pb;
-  DBuf<uint64_t> sa_own;      // SA values when the caller keeps none (host / file / sampled entry points)
+  DBuf<uint64_t> sa_own;      // every SA value (-S) when the caller keeps none (host / file entry points)
+  BwtOutputs out;             // outputs of the merge; -s / -e with no caller array: SA values at the run boundaries only (out.sa_c)
 };
 
 // narrowing / widening copy of an index array to the host (the staged gsacak.h entry points fix their SA width)
@@ -239,8 +240,9 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
   st.sa_rounds_dict = ch.ord.rounds(); st.hash_reseeds = ch.D.reseeds; st.index_bits = ch.ord.wide ? 64 : 32;
 }
 
-// d_sa == nullptr with SA flags: the SA values live in a buffer of the chain (ch.sa_own), allocated when the suffix
-// sorter has given its scratch back - the caller never sees them, only what is sampled / packed from them
+// d_sa == nullptr with SA flags: the SA values live in buffers of the chain, allocated when the suffix sorter has
+// given its scratch back - all of them for -S (ch.sa_own), those at the run boundaries of the BWT for -s / -e
+// (ch.out.sa_c); the caller never sees them, only what is sampled / packed from them
 static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, int flags, uint8_t *d_bwt,
                           uint64_t *d_sa, uint64_t *n_used) {
   pfp_stats &st = c->stats;
@@ -255,8 +257,9 @@ static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, 
   }
   {
     PhaseTimer t(c, &st.ms_merge);
-    BwtOutputs bo;
-    if (flags && !d_sa) { ch.sa_own.alloc(c, ch.n_used + 1); d_sa = ch.sa_own.p; }
+    BwtOutputs &bo = ch.out;
+    static const bool dense_always = getenv("PFP_DENSE_SA") != nullptr;      // tests: -s / -e through the dense path
+    if (flags && !d_sa && ((flags & PFP_FLAG_SA) || dense_always)) { ch.sa_own.alloc(c, ch.n_used + 1); d_sa = ch.sa_own.p; }
     bo.d_bwt = d_bwt; bo.d_sa = d_sa;
     with_width(ch.ord.wide, [&](auto tag) {
       using I = decltype(tag);
@@ -293,12 +296,13 @@ static uint8_t *fetch_bytes(pfp_ctx *c, const uint8_t *d_src, uint64_t nbytes) {
 // the reference's output files from the device results of a finished chain, produced one after the other into
 // `sink(name, device pointer, bytes)` (host buffers of a pfp_bwt_result, or files)
 template <class Sink>
-static void emit_outputs(pfp_ctx *c, const uint8_t *d_bwt, const uint64_t *d_sa, uint64_t n_out, int flags, Sink &&sink) {
+static void emit_outputs(pfp_ctx *c, const uint8_t *d_bwt, const SaView &d_sa, uint64_t n_out, int flags, Sink &&sink) {
   sink("bwt", d_bwt, n_out);
   if (flags & PFP_FLAG_SA) {                       // .sa: n entries, SA[0]=n omitted (pfbwt.cpp:158-162)
     uint64_t cnt = n_out - 1;
     DBuf<uint8_t> packed(c, cnt * 5 + 16);
-    pack5_dev(c, d_sa + 1, cnt, packed.p);
+    PFP_REQUIRE(d_sa.dense, PFP_EINVAL, "full SA output without the SA values");
+    pack5_dev(c, d_sa.dense + 1, cnt, packed.p);
     sink("sa", packed.p, cnt * 5);
     sync(c);
   }
@@ -316,7 +320,7 @@ static void emit_outputs(pfp_ctx *c, const uint8_t *d_bwt, const uint64_t *d_sa,
   }
   sync(c);
 }
-static void fetch_outputs(pfp_ctx *c, const uint8_t *d_bwt, const uint64_t *d_sa, uint64_t n_out, int flags,
+static void fetch_outputs(pfp_ctx *c, const uint8_t *d_bwt, const SaView &d_sa, uint64_t n_out, int flags,
                           pfp_bwt_result *out) {
   emit_outputs(c, d_bwt, d_sa, n_out, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
     uint8_t *h = fetch_bytes(c, d, bytes);
@@ -439,6 +443,11 @@ int pfp_debug_check(pfp_ctx *c) {
   if (c->pool.corrupt.empty()) return PFP_OK;
   c->err = c->pool.corrupt;
   return PFP_EHIP;
+}
+void pfp_pool_trim(pfp_ctx *c) {      // give the cached device blocks back to the driver (several contexts sharing one GPU)
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  c->pool.trim();
 }
 int pfp_get_mem_stats(const pfp_ctx *c, uint64_t out[4]) {
   if (!c || !out) return PFP_EINVAL;
@@ -818,15 +827,15 @@ int pfp_merge(pfp_ctx *c, const uint8_t *dict, uint64_t dict_size, const uint32_
   }
   DBuf<uint8_t> d_bwt(c, expect + 16);
   DBuf<uint64_t> d_sa;
-  if (flags) d_sa.alloc(c, expect + 1);
+  if (flags & PFP_FLAG_SA) d_sa.alloc(c, expect + 1);      // -s / -e: the merge keeps the values at the run boundaries (bo.sa_c)
   BwtOutputs bo;
-  bo.d_bwt = d_bwt.p; bo.d_sa = flags ? d_sa.p : nullptr;
+  bo.d_bwt = d_bwt.p; bo.d_sa = d_sa.p;
   with_width(ord.wide, [&](auto tag) {
     using I = decltype(tag);
     merge_bwt<I>(c, D, ix, ord.get<I>(), pb, occ_lex.p, w, flags, expect, bo);
   });
   c->stats.hard_groups = bo.hard_groups; c->stats.hard_chars = bo.hard_chars;
-  fetch_outputs(c, d_bwt.p, d_sa.p, expect, flags, out);
+  fetch_outputs(c, d_bwt.p, sa_view(bo), expect, flags, out);
   return PFP_OK;
   PFP_CATCH(c)
 }
@@ -855,7 +864,9 @@ int pfp_sample_runs_dev(pfp_ctx *c, const void *d_bwt, const void *d_sa, uint64_
   if (!d_out10) return PFP_OK;                  // count only
   PFP_REQUIRE(rs.pairs <= cap_pairs, PFP_ELIMIT, "output buffer holds " + std::to_string(cap_pairs) + " pairs, the slice has " +
                                                      std::to_string(rs.pairs) + " run boundaries");
-  rs.place((const uint64_t *)d_sa, pos_base, (uint8_t *)d_out10);
+  SaView sv;
+  sv.dense = (const uint64_t *)d_sa;
+  rs.place(sv, pos_base, (uint8_t *)d_out10);
   sync(c);
   return PFP_OK;
   PFP_CATCH(c)
@@ -899,7 +910,7 @@ int pfp_bigbwt(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, i
   DBuf<uint8_t> d_bwt(c, n + 1 + 16);
   uint64_t used = 0;
   run_chain_dev(c, ch, n, w, p, flags, d_bwt.p, nullptr, &used);
-  fetch_outputs(c, d_bwt.p, ch.sa_own.p, used + 1, flags, out);
+  fetch_outputs(c, d_bwt.p, sa_view(ch.out), used + 1, flags, out);
   return PFP_OK;
   PFP_CATCH(c)
 }
@@ -921,7 +932,7 @@ int pfp_bigbwt_formats_dev(pfp_ctx *c, const void *d_text, uint64_t n, int w, ui
   uint64_t used = 0;
   run_chain_dev(c, ch, n, w, p, flags, (uint8_t *)d_bwt, nullptr, &used);
   if (n_used) *n_used = used;
-  emit_outputs(c, (const uint8_t *)d_bwt, ch.sa_own.p, used + 1, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
+  emit_outputs(c, (const uint8_t *)d_bwt, sa_view(ch.out), used + 1, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
     if (name[0] == 'b') return;
     const int k = name[1] == 'a' ? 0 : (name[0] == 's' ? 1 : 2);
     void *q = nullptr;
@@ -962,7 +973,7 @@ int pfp_bigbwt_files(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_
   uint64_t used = 0;
   run_chain_dev(c, ch, n, w, p, flags, d_bwt.p, nullptr, &used);
   uint64_t sizes[4] = {0, 0, 0, 0};
-  emit_outputs(c, d_bwt.p, ch.sa_own.p, used + 1, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
+  emit_outputs(c, d_bwt.p, sa_view(ch.out), used + 1, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
     write_dev_file(c, std::string(base) + "." + name, 0, d, bytes, true);
     sizes[name[0] == 'b' ? 0 : (name[1] == 'a' ? 1 : (name[0] == 's' ? 2 : 3))] = bytes;
   });
@@ -1023,14 +1034,25 @@ __global__ void dist_sym_kernel(uint64_t P, const uint32_t *__restrict__ lpid, u
   if (k < P) sym[k] = lexrank[gid_of_union[word_base + lpid[k]]] + 1;
 }
 // hash class of every local word: owner = (hash >> 20) % parts; per-owner word and byte counts
-__global__ void word_owner_kernel(uint32_t d, const uint64_t *__restrict__ hash, const uint32_t *__restrict__ wlen, uint32_t parts,
-                                  uint32_t *__restrict__ owner, uint32_t *__restrict__ ids, unsigned long long *__restrict__ counts) {
+// (counts are summed per workgroup in LDS first: one atomic per workgroup and owner, not one per word - with few
+// owners every word would hit the same two addresses)
+__global__ __launch_bounds__(256) void word_owner_kernel(uint32_t d, const uint64_t *__restrict__ hash, const uint32_t *__restrict__ wlen,
+                                                         uint32_t parts, uint32_t *__restrict__ owner, uint32_t *__restrict__ ids,
+                                                         unsigned long long *__restrict__ counts) {
+  __shared__ unsigned long long lc[2 * 64];
+  const uint32_t np = parts < 64 ? parts : 64;      // owners beyond 64 (not a single-node case) go straight to global memory
+  for (uint32_t q = threadIdx.x; q < 2 * np; q += 256) lc[q] = 0;
+  __syncthreads();
   uint32_t j = BID * blockDim.x + threadIdx.x;
-  if (j >= d) return;
-  const uint32_t o = (uint32_t)((hash[j] >> 20) % parts);
-  owner[j] = o; ids[j] = j;
-  atomicAdd(&counts[2 * o], 1ull);
-  atomicAdd(&counts[2 * o + 1], (unsigned long long)wlen[j] + 1);
+  if (j < d) {
+    const uint32_t o = (uint32_t)((hash[j] >> 20) % parts);
+    owner[j] = o; ids[j] = j;
+    unsigned long long *dst = o < np ? lc : counts;
+    atomicAdd(&dst[2 * o], 1ull);
+    atomicAdd(&dst[2 * o + 1], (unsigned long long)wlen[j] + 1);
+  }
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < 2 * np; q += 256) if (lc[q]) atomicAdd(&counts[q], lc[q]);
 }
 __global__ void gather_u32_kernel(uint32_t n, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) {
   uint32_t i = BID * blockDim.x + threadIdx.x;

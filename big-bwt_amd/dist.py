@@ -355,7 +355,7 @@ def run(ctx, shard, w=10, p=100, flags=0, halo=DEFAULT_HALO, group=None, shard_s
         return fin.value
 
 
-def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True, dedup="alltoall"):
+def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True, dedup="alltoall", trim=False):
     """Run R virtual ranks in one process (ctxs[r], shards[r] may all live on one GPU): every
     collective is served by plain concatenation.  Used by the GPU tests to check the distributed
     chain bit for bit against the single-GPU chain."""
@@ -373,6 +373,8 @@ def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=Tru
                 reqs[r] = payload
             except StopIteration as fin:
                 results[r] = fin.value
+            if trim:          # many virtual ranks on one card: a rank's cached device blocks must not starve the next one
+                ctxs[r].pool_trim()
         live = set(reqs)
         if live:
             assert len(live) == size and len(kinds) == 1, "ranks fell out of step"

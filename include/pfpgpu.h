@@ -55,6 +55,8 @@ void pfp_free(void *host_ptr);     /* frees host buffers returned by this librar
  * allocation of its own with canary bands on both sides and a poison-filled body; bands are verified when a
  * block is released.  pfp_debug_check returns PFP_EHIP (message in pfp_last_error) once a band was damaged. */
 int pfp_debug_check(pfp_ctx *ctx);
+/* returns the context's cached (currently unused) device blocks to the driver */
+void pfp_pool_trim(pfp_ctx *ctx);
 /* out = {bytes held from the driver, peak bytes in use, bytes in use now, blocks handed out in debug mode} */
 int pfp_get_mem_stats(const pfp_ctx *ctx, uint64_t out[4]);
 

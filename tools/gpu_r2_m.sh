@@ -1,0 +1,18 @@
+#!/bin/bash
+mkdir -p gpurun_out
+S=gpurun_out/r2m_summary.txt
+run() { local name=$1 to=$2; shift 2
+  echo "=== $name" | tee -a $S
+  timeout -k 10 $to "$@" > gpurun_out/$name.log 2>&1
+  local rc=$?
+  echo "rc=$rc" | tee -a $S
+  tail -4 gpurun_out/$name.log | cut -c1-400 | tee -a $S
+  if [ $rc -ge 124 ]; then echo "killed/timeout: stopping" | tee -a $S; exit $rc; fi
+}
+rm -f $S
+run r2m_tests 1000 python -m pytest tests -m gpu -q -x
+run r2m_bench_c3 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline
+run r2m_bench_huge_s 600 python bench.py --steps 2 --warmup 1 --workload huge_s --no-cpu-baseline
+for R in 1 2 4; do
+  run r2m_sim_$R 400 python tools/simscale.py $R c3
+done

@@ -49,7 +49,7 @@ for it in range(2):
     if it == 1:
         ctxs[R - 1].set_kernel_trace(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    res = D.simulate(ctxs, texts, wl['w'], wl['p'], wl['flags'], dedup=dedup)
+    res = D.simulate(ctxs, texts, wl['w'], wl['p'], wl['flags'], dedup=dedup, trim=R > 2)
     torch.cuda.synchronize(); el = (time.perf_counter() - t0) * 1e3
 print('R=%d workload=%s dedup=%s flags=%d total wall (all ranks one after the other) %.1f ms' % (R, name, dedup, wl['flags'], el))
 print('last rank compute ms:', {k: round(v, 2) for k, v in acc.items()}, 'sum %.1f' % sum(acc.values()))
