@@ -348,14 +348,17 @@ __global__ void gather_idx_kernel(uint64_t n, const I *__restrict__ idx, const I
   uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
 }
+// per word: start of its inverted list, number of occurrences, smallest / largest BWT(P) position - one 16-byte record,
+// one memory sector for everything a hard-group or unit-edge kernel wants to know about a member's word
+struct alignas(16) WordRec { uint32_t ist, occ, first, last; };
 __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank, const uint32_t *__restrict__ istart_lex,
                                const uint32_t *__restrict__ wocc, const uint32_t *__restrict__ ilist,
-                               uint32_t *__restrict__ wistart, uint32_t *__restrict__ wfirst, uint32_t *__restrict__ wlast) {
+                               uint32_t *__restrict__ wistart, WordRec *__restrict__ wrec) {
   uint32_t j = BID * blockDim.x + threadIdx.x;
   if (j >= d) return;
   const uint32_t st = istart_lex[lexrank[j]] + 1;   // +1: ilist[0] is the EOS symbol (pfbwt.cpp:389)
   wistart[j] = st;
-  if (wfirst) { wfirst[j] = ilist[st]; wlast[j] = ilist[st + wocc[j] - 1]; }      // smallest / largest BWT(P) position of the word
+  if (wrec) { const uint32_t oc = wocc[j]; wrec[j] = WordRec{st, oc, ilist[st], ilist[st + oc - 1]}; }
 }
 
 template <class I>
@@ -364,7 +367,8 @@ struct MergeArgsT {
   uint64_t pos_base, n_out_global;   // global BWT position of local position 0; global n+1 (== n_out unless the slots are one rank's range)
   uint64_t out_lo, out_hi;   // this call emits BWT positions [out_lo,out_hi) only (multi-GPU slices); bwt/out_sa are indexed by global position
   const I *sa, *grp;
-  const uint32_t *slen, *ist, *pos_word, *wistart, *wfirst, *wlast;
+  const uint32_t *slen, *ist, *pos_word, *wistart;
+  const WordRec *wrec;
   const uint8_t *pc, *hard, *gmaj;     // gmaj[g]: majority char of hard group g when the minority path places the rest (else 0)
   const uint64_t *tbase; const uint32_t *loc;    // output offset of slot t = tbase[t >> 11] + loc[t] (slot_off)
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgsT<I> a, cons
 // suffix): its output range is one fill char c (unknown for hard groups), so a run of the BWT can start only at
 // the unit's first position - when the unit before ends in a different char - and end only at its last position.
 // The first position belongs to the smallest BWT(P) position over the members' inverted lists, the last one to the
-// largest (wfirst / wlast per word): O(members) per unit instead of merging the lists (pfbwt.cpp:605-676 walks a
+// largest (WordRec::first / last per word): O(members) per unit instead of merging the lists (pfbwt.cpp:605-676 walks a
 // heap through all of them).  One lane per slot: whether the two positions can be sampled from the boundary bitmap of
 // the finished BWT, "needed" flags spread over a unit's lanes, segmented min / max by shuffles; a unit that crosses the
 // wave is finished serially by its first (last) lane.
@@ -614,9 +618,9 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
   I myi = 0;
   if (unit && (nf || nlz)) {
     myi = a.sa[t];
-    const uint32_t wd = a.pos_word[myi];
-    if (nf) mn = a.wfirst[wd];
-    if (nlz) mx = a.wlast[wd];
+    const WordRec wr = a.wrec[a.pos_word[myi]];
+    if (nf) mn = wr.first;
+    if (nlz) mx = wr.last;
   }
   // segmented reductions: min towards the first lane of the unit, max towards its last lane
 #pragma unroll
@@ -635,12 +639,12 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
   const bool cont63 = __shfl((int)cont, 63, 64) != 0;
   if (need_first) {
     if (cont63 && g63 == g)
-      for (uint64_t m = wbase + 64; m < a.N && a.grp[m] == (I)g; m++) { const uint32_t f = a.wfirst[a.pos_word[a.sa[m]]]; mn = f < mn ? f : mn; }
+      for (uint64_t m = wbase + 64; m < a.N && a.grp[m] == (I)g; m++) { const uint32_t f = a.wrec[a.pos_word[a.sa[m]]].first; mn = f < mn ? f : mn; }
     sa_put(a, o_first, a.bwsai[mn] - (uint64_t)a.slen[myi]);
   }
   if (need_last) {
     if (g < wbase)
-      for (uint64_t m = wbase; m-- > g;) { const uint32_t l = a.wlast[a.pos_word[a.sa[m]]]; mx = l > mx ? l : mx; }
+      for (uint64_t m = wbase; m-- > g;) { const uint32_t l = a.wrec[a.pos_word[a.sa[m]]].last; mx = l > mx ? l : mx; }
     sa_put(a, o_last, a.bwsai[mx] - (uint64_t)a.slen[myi]);
   }
 }
@@ -802,10 +806,11 @@ __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const 
     uint8_t mych = 0;
     if (live) {
       base = slot_off(a, g);
-      my_occ = (uint32_t)(slot_off(a, g + me + 1) - slot_off(a, g + me));
-      my_ist = slot_ist(a, g + me);
+      const I myi = a.sa[g + me];
+      const WordRec wr = a.wrec[a.pos_word[myi]];
+      my_occ = wr.occ; my_ist = wr.ist;
       mych = fix_char(a.pc[g + me]);
-      if (a.want_sa) sl = a.slen[a.sa[g]];
+      if (a.want_sa) sl = a.slen[myi];       // (equal suffixes: the same for every member)
     }
     // longest occurrence count among the 8-lane groups of the wave decides the trip count (shuffles inside the loop)
     uint32_t trips = my_occ;
@@ -818,21 +823,31 @@ __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const 
       if (act) {
         pos = a.ilist[my_ist + j];
         for (uint32_t m = (uint32_t)l8; m < k; m += 8) {
-          const uint32_t occ = (uint32_t)(slot_off(a, g + m + 1) - slot_off(a, g + m));
-          const uint32_t *lst = a.ilist + (m == me ? my_ist : slot_ist(a, g + m));
-          uint32_t lb;
-          if (m == me) lb = j;
-          else {
-            uint32_t l2 = 0, h2 = occ;          // # entries < pos
-            while (l2 < h2) { const uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
-            lb = l2;
+          uint32_t lb, pv = 0, sv = 0;
+          bool hp = false, hs = false;
+          if (m == me) {
+            lb = j;
+            if (a.want_sa) {
+              if (j > 0) { pv = a.ilist[my_ist + j - 1]; hp = true; }
+              if (j + 1 < my_occ) { sv = a.ilist[my_ist + j + 1]; hs = true; }
+            }
+          } else {
+            // the member's word record answers for a list that lies wholly on one side of pos (a variant that
+            // occurs once: always); only a list that straddles pos is bisected
+            const WordRec wr = a.wrec[a.pos_word[a.sa[g + m]]];
+            if (pos < wr.first) { lb = 0; sv = wr.first; hs = true; }
+            else if (pos > wr.last) { lb = wr.occ; pv = wr.last; hp = true; }
+            else {
+              const uint32_t *lst = a.ilist + wr.ist;
+              uint32_t l2 = 1, h2 = wr.occ - 1;          // # entries < pos: lst[0] < pos < lst[occ - 1]
+              while (l2 < h2) { const uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
+              lb = l2;
+              if (a.want_sa) { pv = lst[lb - 1]; hp = true; sv = lst[lb]; hs = true; }
+            }
           }
           r += lb;
-          if (a.want_sa) {
-            if (lb > 0) { const uint32_t v = lst[lb - 1]; if (!has_pred || v > pred) { pred = v; has_pred = 1; } }
-            const uint32_t nx = m == me ? lb + 1 : lb;
-            if (nx < occ) { const uint32_t v = lst[nx]; if (!has_succ || v < succ) { succ = v; has_succ = 1; } }
-          }
+          if (hp && (!has_pred || pv > pred)) { pred = pv; has_pred = 1; }
+          if (hs && (!has_succ || sv < succ)) { succ = sv; has_succ = 1; }
         }
       }
 #pragma unroll
@@ -898,20 +913,22 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgsT<I> a, const
                                                           const uint64_t *__restrict__ nheads_p,
                                                           unsigned long long *__restrict__ stats,
                                                           BigGroup *__restrict__ big, uint32_t big_cap,
-                                                          BigGroup *__restrict__ mid, uint32_t mid_cap) {
+                                                          BigGroup *__restrict__ mid, uint32_t mid_cap, int gpb) {
   __shared__ HardLds S[4];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   HardLds &L = S[wv];
   const uint64_t nH = *nheads_p;
-  const uint64_t nbatch = (nH + 63) / 64;
+  // gpb groups per wave and batch: 64 when there are groups enough to keep every wave of the chip busy, fewer
+  // otherwise - a batch is one long chain of dependent phases, so the chip wants many of them in flight
+  const uint64_t nbatch = (nH + gpb - 1) / gpb;
   unsigned long long my_chars = 0, my_groups = 0;
   for (uint64_t b = BID * 4 + wv; b < nbatch; b += GDIM * 4) {
     // ---- A: one group per lane
-    const uint64_t hidx = b * 64 + lane;
+    const uint64_t hidx = b * gpb + lane;
     uint64_t g = 0, base = 0;
     uint32_t k = 0, E = 0;
     bool live = false;
-    if (hidx < nH) {
+    if (lane < gpb && hidx < nH) {
       g = heads[hidx];
       uint32_t kk = 0;
       while (g + kk < a.N && a.grp[g + kk] == (I)g && a.pc[g + kk] != 0) kk++;
@@ -1067,7 +1084,9 @@ __global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgsT<I> a, const B
 template <class I>
 __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgsT<I> a, const BigGroup *__restrict__ big, uint32_t nbig,
                                                        const uint64_t *__restrict__ estart, uint64_t total) {
-  for (uint64_t ge = (uint64_t)BID * 256 + threadIdx.x; ge < total; ge += (uint64_t)GDIM * 256) {
+  const uint64_t e0 = estart[0];              // (the queue's offsets are absolute: this launch may start in its middle)
+  for (uint64_t gi = (uint64_t)BID * 256 + threadIdx.x; gi < total; gi += (uint64_t)GDIM * 256) {
+    const uint64_t ge = e0 + gi;
     uint32_t lo = 0, hi = nbig;               // estart[lo] <= ge < estart[hi]
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (estart[mid] <= ge) lo = mid; else hi = mid; }
     const uint64_t g = big[lo].g, e = ge - estart[lo];
@@ -1091,6 +1110,44 @@ __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgsT<I> a, const Bi
       if (a.want_sa && (a.pass & PASS_SA)) sa_put(a, base + r, a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]]);
     }
   }
+}
+
+// Large hard groups, the usual way: the occurrences of a chunk of queued groups become keys (group, BWT(P) position)
+// with the member's slot as value, one device-wide radix sort merges every group's lists at once (the reference pops a
+// heap, pfbwt.cpp:537-556), and position i of a group's sorted range is its i-th output.  Ranking every occurrence
+// against every member's list (hard_big_kernel) is E k log(E / k) dependent loads; on 1024 copies of a genome with
+// repeats - k words of ~1000 occurrences each - that was the longest kernel of the chain.
+template <class I>
+__global__ __launch_bounds__(256) void big_keys_kernel(MergeArgsT<I> a, const BigGroup *__restrict__ big, uint32_t q0, uint32_t q1,
+                                                       const uint64_t *__restrict__ estart, uint64_t cnt,
+                                                       uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
+  const uint64_t i = (uint64_t)BID * 256 + threadIdx.x;
+  if (i >= cnt) return;
+  const uint64_t ge = estart[q0] + i;
+  uint32_t lo = q0, hi = q1;                // estart[lo] <= ge < estart[hi]
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (estart[mid] <= ge) lo = mid; else hi = mid; }
+  const uint64_t g = big[lo].g, e = ge - estart[lo];
+  const uint32_t k = big[lo].k;
+  const uint64_t base = slot_off(a, g);
+  uint32_t ml = 0, mh = k;                  // member holding occurrence e
+  while (mh - ml > 1) { const uint32_t mid = (ml + mh) >> 1; if (slot_off(a, g + mid) - base <= e) ml = mid; else mh = mid; }
+  const uint64_t t = g + ml;
+  const uint32_t j = (uint32_t)(e - (slot_off(a, t) - base));
+  keys[i] = ((uint64_t)(lo - q0) << 32) | a.ilist[slot_ist(a, t) + j];
+  vals[i] = t;
+}
+template <class I>
+__global__ __launch_bounds__(256) void big_place_kernel(MergeArgsT<I> a, const BigGroup *__restrict__ big, uint32_t q0,
+                                                        const uint64_t *__restrict__ estart, uint64_t cnt,
+                                                        const uint64_t *__restrict__ keys, const uint64_t *__restrict__ vals) {
+  const uint64_t i = (uint64_t)BID * 256 + threadIdx.x;
+  if (i >= cnt) return;
+  const uint64_t key = keys[i], t = vals[i];
+  const uint32_t lo = q0 + (uint32_t)(key >> 32), pos = (uint32_t)key;
+  const uint64_t o = slot_off(a, big[lo].g) + (estart[q0] + i - estart[lo]);
+  if (o < a.out_lo || o >= a.out_hi) return;
+  if (a.pass & PASS_BWT) a.bwt[o] = fix_char(a.pc[t]);
+  if (a.want_sa && (a.pass & PASS_SA) && sa_wanted(a, o)) sa_put(a, o, a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]]);
 }
 
 // loc[t] = sum of cnt over the slots of t's tile before t; tsum[tile] = the tile's total.  256 threads x 8 slots.
@@ -1143,10 +1200,10 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   static const bool dense_always = getenv("PFP_DENSE_SA") != nullptr;      // tests: -s / -e through the dense path
   const int samode = (sa_mode == SA_SPARSE && dense_always && out.d_sa) ? SA_DENSE : sa_mode;
   const bool dense = samode == SA_DENSE;
-  DBuf<uint32_t> wfirst, wlast;
-  if (samode == SA_SPARSE) { wfirst.alloc(c, d); wlast.alloc(c, d); }
+  DBuf<WordRec> wrec;
+  if (samode != SA_DENSE) wrec.alloc(c, d);      // the minority path of the hard groups and (sparse SA) the unit edges
   hipLaunchKernelGGL(wistart_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, D.wocc.p, pb.ilist.p,
-                     wistart.p, wfirst.p, wlast.p);
+                     wistart.p, wrec.p);
   DBuf<uint16_t> pp16;
   DBuf<uint64_t> pp64;
   DBuf<uint32_t> cnt(c, N + 8), ist;
@@ -1197,7 +1254,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   a.pos_base = pos_base; a.n_out_global = n_out_global ? n_out_global : n_out;
   { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
   a.sa = so.sa.p; a.slen = ix.slen.p; a.grp = so.grp.p; a.ist = dense ? ist.p : nullptr;
-  a.pos_word = ix.pos_word.p; a.wistart = wistart.p; a.wfirst = wfirst.p; a.wlast = wlast.p;
+  a.pos_word = ix.pos_word.p; a.wistart = wistart.p; a.wrec = wrec.p;
   a.pc = pc.p; a.hard = hard.p; a.tbase = tbase.p; a.loc = loc.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p;
   // the caller's buffers hold positions [out_lo, out_hi): rebase so that kernels index by global position
@@ -1287,11 +1344,13 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
                        c->stream, a, mm_list.p, n_mm, recs.p, nrecs.p);
   }
   PFP_HIP(hipGetLastError());
+  int gpb = 64;      // groups per wave batch: down to 8 while that still leaves every wave of the launch a batch
+  while (gpb > 8 && n_fallback / gpb < (uint64_t)c->n_cu * 32) gpb >>= 1;
   for (;;) {
     if (!n_fallback) { PFP_HIP(hipMemsetAsync(hstats.p, 0, 40, c->stream)); }
     else { KScope ks(c, "pfp::hard_groups_kernel", N * 5);
       hipLaunchKernelGGL(hard_groups_kernel<I>, gdim(c->n_cu * 8), gdim(256), 0, c->stream, a, hard_list, hard_list_n, hstats.p, big.p,
-                         big_cap, mid.p, mid_cap); }
+                         big_cap, mid.p, mid_cap, gpb); }
     PFP_HIP(hipGetLastError());
     PFP_HIP(hipMemcpyAsync(c->h_scalars, hstats.p, 40, hipMemcpyDeviceToHost, c->stream));
     sync(c);
@@ -1310,18 +1369,19 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   out.hard_chars += read_scalar(c, (const uint64_t *)mstat.p);      // all chars of hard groups, whichever path wrote them
   out.hard_groups += n_heads - n_fallback;
   DBuf<uint64_t> estart;
-  uint64_t big_total = 0;
+  std::vector<uint64_t> es(nbig + 1, 0);
+  // (read per call: the tests switch them inside one process)
+  const uint64_t big_budget = [] { const char *e = getenv("PFP_BIG_BUDGET"); return e ? strtoull(e, nullptr, 10) : (1ull << 27); }();
+  const bool big_by_rank = getenv("PFP_BIG_BY_RANK") != nullptr;      // the occurrence-by-occurrence kernel for every queued group
   if (nbig) {
     // occurrences of the queued groups, laid end to end
     std::vector<BigGroup> hb(nbig);
     PFP_HIP(hipMemcpyAsync(hb.data(), big.p, nbig * sizeof(BigGroup), hipMemcpyDeviceToHost, c->stream));
     sync(c);
-    std::vector<uint64_t> es(nbig + 1, 0);
     for (uint32_t q = 0; q < nbig; q++) es[q + 1] = es[q] + hb[q].E;
     estart.alloc(c, nbig + 1);
     PFP_HIP(hipMemcpyAsync(estart.p, es.data(), (nbig + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    sync(c);      // es is a local
-    big_total = es[nbig];
+    sync(c);
   }
   auto run_queued = [&]() {
     if (nmid) {
@@ -1329,11 +1389,26 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
       hipLaunchKernelGGL(hard_sort_kernel<I>, gdim(c->n_cu * 4), gdim(256), 0, c->stream, a, mid.p, nmid);
       PFP_HIP(hipGetLastError());
     }
-    if (nbig) {
-      const int nb = (int)std::min<uint64_t>(cdiv64(big_total, 256), (uint64_t)c->n_cu * 32);
-      KScope ks(c, "pfp::hard_big_kernel", big_total * (samode ? 21 : 5));
-      hipLaunchKernelGGL(hard_big_kernel<I>, gdim(nb), gdim(256), 0, c->stream, a, big.p, nbig, estart.p, big_total);
+    // queued groups in chunks of at most big_budget occurrences: keys, one sort, placement (a single group beyond the
+    // budget is ranked occurrence by occurrence - its sort scratch is not worth the memory)
+    for (uint32_t q0 = 0; q0 < nbig;) {
+      uint32_t q1 = q0 + 1;
+      while (q1 < nbig && es[q1 + 1] - es[q0] <= big_budget) q1++;
+      const uint64_t cnt = es[q1] - es[q0];
+      if (cnt > big_budget || big_by_rank) {
+        const int nb = (int)std::min<uint64_t>(cdiv64(cnt, 256), (uint64_t)c->n_cu * 32);
+        KScope ks(c, "pfp::hard_big_kernel", cnt * (samode ? 21 : 5));
+        hipLaunchKernelGGL(hard_big_kernel<I>, gdim(nb), gdim(256), 0, c->stream, a, big.p + q0, q1 - q0, estart.p + q0, cnt);
+      } else {
+        DBuf<uint64_t> bk(c, cnt), bka(c, cnt), bv(c, cnt), bva(c, cnt);
+        { KScope ks(c, "pfp::big_keys_kernel", cnt * 28);
+          hipLaunchKernelGGL(big_keys_kernel<I>, gdim(cdiv(cnt, 256)), gdim(256), 0, c->stream, a, big.p, q0, q1, estart.p, cnt, bk.p, bv.p); }
+        sort_pairs_db<uint64_t, uint64_t>(c, bk, bka, bv, bva, cnt, 0, 32 + bits_for(q1 - q0));
+        { KScope ks(c, "pfp::big_place_kernel", cnt * (samode ? 34 : 18));
+          hipLaunchKernelGGL(big_place_kernel<I>, gdim(cdiv(cnt, 256)), gdim(256), 0, c->stream, a, big.p, q0, estart.p, cnt, bk.p, bv.p); }
+      }
       PFP_HIP(hipGetLastError());
+      q0 = q1;
     }
   };
   run_queued();
@@ -1375,7 +1450,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     scratch.zero();
     KScope ks(c, "pfp::hard_groups_kernel", N * 5);
     hipLaunchKernelGGL(hard_groups_kernel<I>, gdim(c->n_cu * 8), gdim(256), 0, c->stream, a, hard_list, hard_list_n, scratch.p, big.p,
-                       0u, mid.p, 0u);
+                       0u, mid.p, 0u, gpb);
     PFP_HIP(hipGetLastError());
     run_queued();
     sync(c);

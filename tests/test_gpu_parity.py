@@ -187,6 +187,32 @@ def test_mid_size_against_oracle(O, pkg, wctx):
     assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
 
 
+@pytest.mark.parametrize("env", [{}, {"PFP_BIG_BUDGET": "6000"}, {"PFP_BIG_BY_RANK": "1"}])
+def test_large_hard_groups_without_a_dominating_char(O, pkg, wctx, monkeypatch, env):
+    """1200 copies of a short random sequence, a few of them mutated, small window: suffixes of 5+ characters are shared
+    by several words with ~1200 occurrences each and different preceding chars - hard groups of thousands of
+    occurrences where no char dominates.  They are merged by one device-wide sort per chunk of groups (chunked by
+    PFP_BIG_BUDGET occurrences; a group beyond the budget, or PFP_BIG_BY_RANK, takes the per-occurrence ranking kernel)."""
+    rng = np.random.default_rng(5)
+    base = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=1500)]
+    copies = np.tile(base, (1200, 1))
+    for c_ in rng.integers(0, 1200, size=40):
+        copies[c_, rng.integers(0, 1500)] = ord("N")
+    text = copies.reshape(-1).copy()
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    for flags, oflags in ((0, 0), (pkg.FLAG_SA, O.FLAG_SA), (pkg.FLAG_SSA | pkg.FLAG_ESA, O.FLAG_SSA | O.FLAG_ESA)):
+        got = wctx.bigbwt(text, 4, 11, flags)
+        assert wctx.stats()["hard_big_groups"] > 0
+        want = O.bigbwt(text, 4, 11, oflags)
+        assert np.array_equal(got["bwt"], want["bwt"])
+        if flags & pkg.FLAG_SA:
+            assert np.array_equal(pkg.unpack5(got["sa"]), want["sa"])
+        if flags & pkg.FLAG_SSA:
+            assert np.array_equal(pkg.unpack5(got["ssa"]).reshape(-1, 2), want["ssa"])
+            assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
+
+
 def _check_bwt_sa_properties(text, bwt, sa_vals, rng):
     n = len(text)
     assert len(bwt) == n + 1
