@@ -236,6 +236,22 @@ __global__ void pprec_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t
 // per SA(D) slot: count and preceding char (0 = emits nothing), 8 slots per thread; with SA output
 // also the start of the word's inverted list
 template <class I> struct alignas(16) Idx8 { I v[8]; };
+// whole-word slots (preceding char = EndOfWord) of the block's 2048 slots -> tile_full[block]; smallest such slot -> first_full
+__device__ __forceinline__ void tile_full_count(const uint32_t p8[8], int nk, uint64_t t0, uint32_t *__restrict__ tile_full,
+                                                unsigned long long *__restrict__ first_full) {
+  __shared__ uint32_t ws[4];
+  uint32_t cfull = 0;
+  int firstk = -1;
+#pragma unroll
+  for (int k = 7; k >= 0; k--) if (k < nk && p8[k] == kEndOfWord) { cfull++; firstk = k; }
+  const unsigned long long anyf = __ballot(cfull != 0);
+  for (int o = 32; o > 0; o >>= 1) cfull += __shfl_down(cfull, o, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cfull;
+  // the first lane of the first wave that holds one reports it (slots ascend with the thread index)
+  if (anyf && (int)(threadIdx.x & 63) == __ffsll((long long)anyf) - 1) atomicMin(first_full, (unsigned long long)(t0 + firstk));
+  __syncthreads();
+  if (threadIdx.x == 0) tile_full[BID] = ws[0] + ws[1] + ws[2] + ws[3];
+}
 template <class REC, class I>
 __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const I *__restrict__ sa,
                                                           const REC *__restrict__ pp,
@@ -243,12 +259,13 @@ __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const I *_
                                                           const uint32_t *__restrict__ wocc,
                                                           const uint32_t *__restrict__ wistart,
                                                           uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc,
-                                                          uint32_t *__restrict__ ist) {
+                                                          uint32_t *__restrict__ ist, uint32_t *__restrict__ tile_full,
+                                                          unsigned long long *__restrict__ first_full) {
+  if ((uint64_t)BID * 2048 >= N) return;      // a workgroup of the padded last grid row
   uint64_t t0 = ((uint64_t)BID * 256 + threadIdx.x) * 8;
-  if (t0 >= N) return;
   I idx[8];
   uint32_t c8[8], p8[8], w8[8];
-  const int nk = (N - t0) >= 8 ? 8 : (int)(N - t0);
+  const int nk = t0 >= N ? 0 : ((N - t0) >= 8 ? 8 : (int)(N - t0));
   if (nk == 8) {
     const Idx8<I> v8 = *reinterpret_cast<const Idx8<I> *>(sa + t0);
 #pragma unroll
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const I *_
   }
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    const uint64_t v = (uint64_t)pp[idx[k]];
+    const uint64_t v = k < nk ? (uint64_t)pp[idx[k]] : 0ull;
     p8[k] = (uint32_t)v & 0xffu; c8[k] = ((uint32_t)v >> 8) & 0xffu; w8[k] = (uint32_t)(v >> 32);
   }
 #pragma unroll
@@ -276,6 +293,7 @@ __global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const I *_
     for (int k = 0; k < 8; k++)
       if (k < nk) ist[t0 + k] = p8[k] ? wistart[sizeof(REC) == 2 ? pos_word[idx[k]] : w8[k]] : 0u;
   }
+  tile_full_count(p8, nk, t0, tile_full, first_full);
 }
 
 // The same per-slot outputs when the records travelled in the top 16 bits of the first-round keys
@@ -288,11 +306,12 @@ __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const I *
                                                            const uint32_t *__restrict__ pos_word,
                                                            const uint32_t *__restrict__ slen,
                                                            const uint32_t *__restrict__ wocc, uint32_t d, int w,
-                                                           uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc) {
+                                                           uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc,
+                                                           uint32_t *__restrict__ tile_full, unsigned long long *__restrict__ first_full) {
+  if ((uint64_t)BID * 2048 >= N) return;      // a workgroup of the padded last grid row
   uint64_t t0 = ((uint64_t)BID * 256 + threadIdx.x) * 8;
-  if (t0 >= N) return;
   uint32_t c8[8], p8[8];
-  const int nk = (N - t0) >= 8 ? 8 : (int)(N - t0);
+  const int nk = t0 >= N ? 0 : ((N - t0) >= 8 ? 8 : (int)(N - t0));
   uint64_t rf = 0;
   if (refined) rf = nk == 8 ? *reinterpret_cast<const uint64_t *>(refined + t0) : ~0ull;      // tail: take the slow path
 #pragma unroll
@@ -322,6 +341,15 @@ __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const I *
   } else {
     for (int k = 0; k < nk; k++) { cnt[t0 + k] = c8[k]; pc[t0 + k] = (uint8_t)p8[k]; }
   }
+  tile_full_count(p8, nk, t0, tile_full, first_full);
+}
+// whole words are singleton groups and stand in SA(D) in the words' lexicographic order: the q-th whole-word slot
+// belongs to the word of rank q.  Rank of the first whole-word slot held (0 unless the slots are one rank's range).
+template <class I>
+__global__ void full_base0_kernel(const unsigned long long *__restrict__ first_full, const I *__restrict__ sa,
+                                  const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ lexrank, uint32_t *__restrict__ out) {
+  const unsigned long long f = *first_full;
+  *out = f == ~0ull ? 0u : lexrank[pos_word[sa[f]]];
 }
 
 // a group is "hard" when its members disagree on the preceding char (pfbwt.cpp:524-536), or, with
@@ -348,17 +376,17 @@ __global__ void gather_idx_kernel(uint64_t n, const I *__restrict__ idx, const I
   uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
 }
-// per word: start of its inverted list, number of occurrences, smallest / largest BWT(P) position - one 16-byte record,
+// per word: start of its inverted list, number of occurrences, smallest / largest BWT(P) position, end - one 32-byte record,
 // one memory sector for everything a hard-group or unit-edge kernel wants to know about a member's word
-struct alignas(16) WordRec { uint32_t ist, occ, first, last; };
+struct alignas(32) WordRec { uint32_t ist, occ, first, last; uint64_t wend, pad; };      // wend: position of the word's terminator
 __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank, const uint32_t *__restrict__ istart_lex,
                                const uint32_t *__restrict__ wocc, const uint32_t *__restrict__ ilist,
-                               uint32_t *__restrict__ wistart, WordRec *__restrict__ wrec) {
+                               const uint64_t *__restrict__ wend, uint32_t *__restrict__ wistart, WordRec *__restrict__ wrec) {
   uint32_t j = BID * blockDim.x + threadIdx.x;
   if (j >= d) return;
   const uint32_t st = istart_lex[lexrank[j]] + 1;   // +1: ilist[0] is the EOS symbol (pfbwt.cpp:389)
   wistart[j] = st;
-  if (wrec) { const uint32_t oc = wocc[j]; wrec[j] = WordRec{st, oc, ilist[st], ilist[st + oc - 1]}; }
+  if (wrec) { const uint32_t oc = wocc[j]; wrec[j] = WordRec{st, oc, ilist[st], ilist[st + oc - 1], wend[j], 0}; }
 }
 
 template <class I>
@@ -372,6 +400,9 @@ struct MergeArgsT {
   const uint8_t *pc, *hard, *gmaj;     // gmaj[g]: majority char of hard group g when the minority path places the rest (else 0)
   const uint64_t *tbase; const uint32_t *loc;    // output offset of slot t = tbase[t >> 11] + loc[t] (slot_off)
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
+  // whole-word slots: the q-th one (in slot order) is the word of lexicographic rank q, whose inverted list starts at
+  // istart_lex[q] + 1; fullbase[tile] = whole-word slots before the tile, *fullbase0 = rank of the first one held
+  const uint32_t *istart_lex, *fullbase, *fullbase0;
   uint8_t *bwt; uint64_t *out_sa;
   // what a launch writes: BWT chars (bit 0), SA values (bit 1).  Dense SA does both at once; sparse SA needs the finished
   // BWT to know where values are looked at, so its kernels run twice.
@@ -432,26 +463,53 @@ constexpr int kSlots = 2048;
 constexpr uint64_t kExpandQuota = 1u << 16;   // output bytes one workgroup expands before the rest is shared
 
 struct ExpandLds {
-  uint64_t loff[kSlots + 1];
+  uint32_t loff[kSlots + 1];      // offsets inside the tile fit 32 bits (slot_loc_kernel checks)
+  uint32_t lfist[kSlots];         // whole-word slots: start of the word's inverted list
   uint8_t lpc[kSlots], lcls[kSlots];
+  uint32_t ccnt[kSlots / 64 + 1];
 };
 
+// tile = index of the 2048-slot tile starting at slot t0
 template <class I>
-__device__ __forceinline__ void expand_stage(const MergeArgsT<I> &a, ExpandLds &L, uint64_t t0, int ns, uint64_t base) {
-  for (int s = threadIdx.x; s <= ns; s += 256) L.loff[s] = slot_off(a, t0 + s) - base;
-  for (int s = threadIdx.x; s < ns; s += 256) {
-    const uint64_t t = t0 + s;
-    uint8_t ch = a.pc[t];
-    uint8_t cls = ch == 0 ? CLS_NONE : (ch == kEndOfWord ? CLS_FULL : CLS_FILL);
-    if (cls == CLS_FILL && a.pass != PASS_SA) {      // (the SA-only round of the sparse mode looks at whole words only)
-      const I g = a.grp[t];
-      if (a.hard[g]) {
-        cls = CLS_HARD;
-        ch = a.gmaj ? a.gmaj[g] : 0;      // the group's majority char (minority path) or 0 (every position written later)
+__device__ __forceinline__ void expand_stage(const MergeArgsT<I> &a, ExpandLds &L, uint64_t t0, int ns, uint64_t base, uint64_t tile) {
+  for (int s = threadIdx.x; s <= ns; s += 256) L.loff[s] = (uint32_t)(slot_off(a, t0 + s) - base);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t fullmask = 0;          // bit it: my slot of iteration it is a whole word; its rank inside the 64-slot chunk
+  uint64_t franks = 0;
+#pragma unroll
+  for (int it = 0; it < kSlots / 256; it++) {
+    const int s = it * 256 + threadIdx.x;
+    uint8_t cls = CLS_NONE;
+    if (s < ns) {
+      const uint64_t t = t0 + s;
+      uint8_t ch = a.pc[t];
+      cls = ch == 0 ? CLS_NONE : (ch == kEndOfWord ? CLS_FULL : CLS_FILL);
+      if (cls == CLS_FILL && a.pass != PASS_SA) {      // (the SA-only round of the sparse mode looks at whole words only)
+        const I g = a.grp[t];
+        if (a.hard[g]) {
+          cls = CLS_HARD;
+          ch = a.gmaj ? a.gmaj[g] : 0;      // the group's majority char (minority path) or 0 (every position written later)
+        }
       }
+      L.lpc[s] = ch;
+      L.lcls[s] = cls;
     }
-    L.lpc[s] = ch;
-    L.lcls[s] = cls;
+    const unsigned long long fb = __ballot(cls == CLS_FULL);
+    if (lane == 0) L.ccnt[it * 4 + wv] = (uint32_t)__popcll(fb);
+    if (cls == CLS_FULL) { fullmask |= 1u << it; franks |= (uint64_t)__popcll(fb & ((1ull << lane) - 1ull)) << (8 * it); }
+  }
+  __syncthreads();
+  if (fullmask) {
+    const uint32_t q0 = a.ist ? 0u : a.fullbase[tile] + *a.fullbase0;
+#pragma unroll
+    for (int it = 0; it < kSlots / 256; it++)
+      if ((fullmask >> it) & 1u) {
+        const int s = it * 256 + threadIdx.x;
+        if (a.ist) { L.lfist[s] = a.ist[t0 + s]; continue; }
+        uint32_t before = 0;
+        for (int c2 = 0; c2 < it * 4 + wv; c2++) before += L.ccnt[c2];
+        L.lfist[s] = a.istart_lex[q0 + before + (uint32_t)((franks >> (8 * it)) & 0xffu)] + 1u;   // +1: ilist[0] is the EOS symbol
+      }
   }
   __syncthreads();
 }
@@ -477,7 +535,7 @@ __device__ __forceinline__ void expand_16(const MergeArgsT<I> &a, const ExpandLd
       if (cl == CLS_FILL || cl == CLS_MULTI) {
         ch = fix_char(L.lpc[s]);
       } else if (cl == CLS_FULL) {
-        const uint64_t pos = a.ilist[slot_ist(a, t0 + s) + (uint32_t)(x - L.loff[s])];
+        const uint64_t pos = a.ilist[L.lfist[s] + (uint32_t)(x - L.loff[s])];
         ch = a.bwlast[pos];
       } else {      // CLS_HARD: the group's majority char (its other occurrences are placed by hard_minor_kernel), or 0 and
         ch = L.lpc[s];      // every position of the group is written by the hard-group kernels that run after this one
@@ -509,7 +567,7 @@ __device__ __forceinline__ void expand_sa_1(const MergeArgsT<I> &a, const Expand
   if (cl != CLS_FULL && (cl != CLS_FILL || a.want_sa == SA_SPARSE)) return;
   if (!sa_wanted(a, base + x)) return;
   const I i = a.sa[t0 + lo];
-  const uint64_t pos = a.ilist[slot_ist(a, t0 + lo) + (uint32_t)(x - L.loff[lo])];
+  const uint64_t pos = a.ilist[(cl == CLS_FULL ? L.lfist[lo] : slot_ist(a, t0 + lo)) + (uint32_t)(x - L.loff[lo])];
   sa_put(a, base + x, (cl == CLS_FULL && a.pos_base + base + x == 0) ? a.n_out_global - 1 : a.bwsai[pos] - (uint64_t)a.slen[i]);
 }
 
@@ -523,13 +581,14 @@ template <class I, int SPARSE>
 __global__ __launch_bounds__(256) void expand_kernel(MergeArgsT<I> a, uint32_t *__restrict__ heavy, uint32_t *__restrict__ nheavy,
                                                      uint32_t heavy_cap) {
   __shared__ ExpandLds L;
-  __shared__ uint32_t nfull, fulls[SPARSE ? kSlots : 1];
+  __shared__ uint32_t nfull, fpre[SPARSE ? kSlots + 1 : 1], wsum[4];
+  __shared__ uint16_t fulls[SPARSE ? kSlots : 1];
   const uint64_t t0 = (uint64_t)BID * kSlots;
   if (t0 >= a.N) return;      // a workgroup of the padded last grid row
   const int ns = (a.N - t0) >= (uint64_t)kSlots ? kSlots : (int)(a.N - t0);
   const uint64_t base = slot_off(a, t0);
   if (SPARSE && threadIdx.x == 0) nfull = 0;
-  expand_stage(a, L, t0, ns, base);
+  expand_stage(a, L, t0, ns, base, BID);
   const uint64_t Ltot = L.loff[ns];
   if (base + Ltot <= a.out_lo || base >= a.out_hi) return;
   // a block whose slots emit more than the quota (a word with hundreds of thousands of
@@ -540,14 +599,42 @@ __global__ __launch_bounds__(256) void expand_kernel(MergeArgsT<I> a, uint32_t *
     for (uint64_t x0 = (uint64_t)threadIdx.x * 16; x0 < mine; x0 += 256 * 16) expand_16(a, L, t0, ns, base, x0, Ltot);
   if (!(a.pass & PASS_SA)) return;
   if (SPARSE) {
+    // the whole-word slots of the block and the positions they emit, laid end to end: one lane per position (a loop over
+    // the slots with 256 lanes on each - most words occur a few times - was a chain of ~20 dependent gathers per block)
     for (int s = threadIdx.x; s < ns; s += 256)
-      if (L.lcls[s] == CLS_FULL) fulls[atomicAdd(&nfull, 1u)] = (uint32_t)s;
+      if (L.lcls[s] == CLS_FULL) fulls[atomicAdd(&nfull, 1u)] = (uint16_t)s;
     __syncthreads();
     const uint32_t nf = nfull;
-    for (uint32_t q = 0; q < nf; q++) {
+    if (nf == 0) return;
+    const uint32_t chunk = (nf + 255u) / 256u, q0 = threadIdx.x * chunk, q1 = q0 + chunk < nf ? q0 + chunk : nf;
+    uint32_t own = 0;
+    for (uint32_t q = q0; q < q1; q++) {
       const int sl = (int)fulls[q];
-      const uint64_t e = L.loff[sl + 1] < mine ? L.loff[sl + 1] : mine;
-      for (uint64_t x = L.loff[sl] + threadIdx.x; x < e; x += 256) expand_sa_1(a, L, t0, ns, base, x);
+      const uint64_t b = L.loff[sl], e = L.loff[sl + 1] < mine ? L.loff[sl + 1] : mine;
+      const uint32_t cq = e > b ? (uint32_t)(e - b) : 0u;
+      fpre[q] = cq;
+      own += cq;
+    }
+    uint32_t inc = own;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - own;
+    for (int q = 0; q < wv; q++) run += wsum[q];
+    for (uint32_t q = q0; q < q1; q++) { const uint32_t cq = fpre[q]; fpre[q] = run; run += cq; }
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) fpre[nf] = total;
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < total; idx += 256) {
+      uint32_t lo = 0, hi = nf;                    // fpre[lo] <= idx < fpre[hi]
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (fpre[mid] <= idx) lo = mid; else hi = mid; }
+      const int sl = (int)fulls[lo];
+      const uint64_t x = L.loff[sl] + (idx - fpre[lo]);
+      if (!sa_wanted(a, base + x)) continue;
+      const I i = a.sa[t0 + sl];
+      const uint64_t pos = a.ilist[L.lfist[sl] + (uint32_t)(x - L.loff[sl])];
+      sa_put(a, base + x, a.pos_base + base + x == 0 ? a.n_out_global - 1 : a.bwsai[pos] - (uint64_t)a.slen[i]);
     }
   } else if (a.want_sa) {
     for (uint64_t x = threadIdx.x; x < mine; x += 256) expand_sa_1(a, L, t0, ns, base, x);
@@ -562,7 +649,7 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgsT<I> a, cons
     const int ns = (a.N - t0) >= (uint64_t)kSlots ? kSlots : (int)(a.N - t0);
     const uint64_t base = slot_off(a, t0);
     __syncthreads();
-    expand_stage(a, L, t0, ns, base);
+    expand_stage(a, L, t0, ns, base, heavy[q]);
     const uint64_t Ltot = L.loff[ns];
     if (a.pass & PASS_BWT)
       for (uint64_t x0 = kExpandQuota + ((uint64_t)BID * 256 + threadIdx.x) * 16; x0 < Ltot; x0 += (uint64_t)GDIM * 256 * 16)
@@ -615,12 +702,13 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
   const bool nf = __shfl((int)need_first, hl, 64) != 0 && head_here;
   const bool nlz = __shfl((int)need_last, ll, 64) != 0 && unit && lm != 0;
   uint32_t mn = 0xFFFFFFFFu, mx = 0;
-  I myi = 0;
+  uint64_t mysl = 0;      // length of the (common) suffix: distance to the word's terminator
   if (unit && (nf || nlz)) {
-    myi = a.sa[t];
+    const I myi = a.sa[t];
     const WordRec wr = a.wrec[a.pos_word[myi]];
     if (nf) mn = wr.first;
     if (nlz) mx = wr.last;
+    mysl = wr.wend - (uint64_t)myi;
   }
   // segmented reductions: min towards the first lane of the unit, max towards its last lane
 #pragma unroll
@@ -640,12 +728,12 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
   if (need_first) {
     if (cont63 && g63 == g)
       for (uint64_t m = wbase + 64; m < a.N && a.grp[m] == (I)g; m++) { const uint32_t f = a.wrec[a.pos_word[a.sa[m]]].first; mn = f < mn ? f : mn; }
-    sa_put(a, o_first, a.bwsai[mn] - (uint64_t)a.slen[myi]);
+    sa_put(a, o_first, a.bwsai[mn] - mysl);
   }
   if (need_last) {
     if (g < wbase)
       for (uint64_t m = wbase; m-- > g;) { const uint32_t l = a.wrec[a.pos_word[a.sa[m]]].last; mx = l > mx ? l : mx; }
-    sa_put(a, o_last, a.bwsai[mx] - (uint64_t)a.slen[myi]);
+    sa_put(a, o_last, a.bwsai[mx] - mysl);
   }
 }
 
@@ -810,7 +898,7 @@ __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const 
       const WordRec wr = a.wrec[a.pos_word[myi]];
       my_occ = wr.occ; my_ist = wr.ist;
       mych = fix_char(a.pc[g + me]);
-      if (a.want_sa) sl = a.slen[myi];       // (equal suffixes: the same for every member)
+      sl = wr.wend - (uint64_t)myi;          // (equal suffixes: the same for every member)
     }
     // longest occurrence count among the 8-lane groups of the wave decides the trip count (shuffles inside the loop)
     uint32_t trips = my_occ;
@@ -1203,7 +1291,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   DBuf<WordRec> wrec;
   if (samode != SA_DENSE) wrec.alloc(c, d);      // the minority path of the hard groups and (sparse SA) the unit edges
   hipLaunchKernelGGL(wistart_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, D.wocc.p, pb.ilist.p,
-                     wistart.p, wrec.p);
+                     ix.wend.p, wistart.p, wrec.p);
   DBuf<uint16_t> pp16;
   DBuf<uint64_t> pp64;
   DBuf<uint32_t> cnt(c, N + 8), ist;
@@ -1217,10 +1305,14 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   DBuf<uint64_t> tsum(c, ntile + 1), tbase(c, ntile + 1);
   PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream));
   hard.zero();
+  DBuf<uint32_t> tile_full(c, ntile + 1), fullbase(c, ntile + 1), fullbase0(c, 1);
+  DBuf<unsigned long long> first_full(c, 1);
+  tile_full.zero();
+  PFP_HIP(hipMemsetAsync(first_full.p, 0xFF, 8, c->stream));
   if (from_keys) {
     KScope ks(c, "pfp::slot_gather_kernel", N * (8 + 1 + 5));
     hipLaunchKernelGGL(slot_payload_kernel<I>, gdim(cdiv(cdiv64(N, 8), 256)), gdim(256), 0, c->stream, N, so.sa.p, so.skeys.p,
-                       so.refined.p, D.bytes.p, ix.pos_word.p, ix.slen.p, D.wocc.p, d, w, cnt.p, pc.p);
+                       so.refined.p, D.bytes.p, ix.pos_word.p, ix.slen.p, D.wocc.p, d, w, cnt.p, pc.p, tile_full.p, first_full.p);
   } else {
   { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + (dense ? 8 : 2)));
     if (dense) hipLaunchKernelGGL(pprec_kernel<uint64_t>, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, D.bytes.p, NP, d, w,
@@ -1230,9 +1322,9 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   { KScope ks(c, "pfp::slot_gather_kernel", N * (sizeof(I) + 5 + (dense ? 12 : 2)));
     const dim3 grid = gdim(cdiv(cdiv64(N, 8), 256));
     if (dense) hipLaunchKernelGGL((slot_gather_kernel<uint64_t, I>), grid, gdim(256), 0, c->stream, N, so.sa.p, pp64.p,
-                                  ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, ist.p);
+                                  ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, ist.p, tile_full.p, first_full.p);
     else hipLaunchKernelGGL((slot_gather_kernel<uint16_t, I>), grid, gdim(256), 0, c->stream, N, so.sa.p, pp16.p,
-                            ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, (uint32_t *)nullptr); }
+                            ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, (uint32_t *)nullptr, tile_full.p, first_full.p); }
   }
   pp16.release(); pp64.release();
   ovf.zero();
@@ -1240,6 +1332,8 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   { KScope ks(c, "pfp::slot_loc_kernel", N * 8);
     hipLaunchKernelGGL(slot_loc_kernel, gdim((unsigned)ntile), gdim(256), 0, c->stream, cnt.p, N, loc.p, tsum.p, ovf.p); }
   exclusive_sum_u64(c, tsum.p, tbase.p, ntile + 1);
+  exclusive_sum_u32(c, tile_full.p, fullbase.p, ntile + 1);
+  hipLaunchKernelGGL(full_base0_kernel<I>, dim3(1), dim3(1), 0, c->stream, first_full.p, so.sa.p, ix.pos_word.p, ix.lexrank.p, fullbase0.p);
   { KScope ks(c, "pfp::group_flags_kernel", N * 5);
   hipLaunchKernelGGL(group_flags_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, so.grp.p, pc.p, dense ? 1 : 0, hard.p); }
   PFP_REQUIRE(read_scalar(c, ovf.p) == 0, PFP_ELIMIT, "2048 consecutive suffix-array slots emit 2^32 or more BWT positions");
@@ -1257,6 +1351,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   a.pos_word = ix.pos_word.p; a.wistart = wistart.p; a.wrec = wrec.p;
   a.pc = pc.p; a.hard = hard.p; a.tbase = tbase.p; a.loc = loc.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p;
+  a.istart_lex = istart_lex.p; a.fullbase = fullbase.p; a.fullbase0 = fullbase0.p;
   // the caller's buffers hold positions [out_lo, out_hi): rebase so that kernels index by global position
   a.out_lo = out_lo; a.out_hi = out_hi < n_out ? out_hi : n_out;
   a.bwt = out.d_bwt - out_lo; a.out_sa = out.d_sa ? out.d_sa - out_lo : nullptr;

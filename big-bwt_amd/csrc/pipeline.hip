@@ -935,8 +935,10 @@ int pfp_bigbwt_formats_dev(pfp_ctx *c, const void *d_text, uint64_t n, int w, ui
   emit_outputs(c, (const uint8_t *)d_bwt, sa_view(ch.out), used + 1, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
     if (name[0] == 'b') return;
     const int k = name[1] == 'a' ? 0 : (name[0] == 's' ? 1 : 2);
-    void *q = nullptr;
-    PFP_HIP(hipMalloc(&q, bytes ? bytes : 1));
+    // a block of the context's pool (handed back by pfp_dev_free): steady-state calls do not reach the driver
+    hipError_t e = hipSuccess;
+    void *q = c->pool.get(bytes ? bytes : 1, &e, __FILE__, __LINE__);
+    if (!q) throw Error(PFP_ENOMEM, std::string("device allocation of an output buffer failed: ") + hipGetErrorString(e));
     PFP_HIP(hipMemcpyAsync(q, d, bytes, hipMemcpyDeviceToDevice, c->stream));
     d_out[k] = q; out_bytes[k] = bytes;
   });
@@ -956,7 +958,9 @@ int pfp_memcpy_d2h(pfp_ctx *c, void *host_dst, const void *d_src, uint64_t nbyte
 void pfp_dev_free(pfp_ctx *c, void *d_ptr) {
   if (!c || !d_ptr) return;
   (void)hipSetDevice(c->device);
-  (void)hipFree(d_ptr);
+  for (const auto &b : c->pool.all)
+    if (b.p == d_ptr) { c->pool.put(d_ptr); return; }      // (later work of the context is ordered behind the caller's reads only if
+  (void)hipFree(d_ptr);                                    //  those were on the context's stream or have completed: pfpgpu.h)
 }
 
 // file to files: the host text (an mmap of the input works) is streamed in, the outputs are streamed from HBM

@@ -188,8 +188,11 @@ int pfp_sample_runs_dev(pfp_ctx *ctx, const void *d_bwt, const void *d_sa, uint6
 /* Device-resident chain that hands back the reference's SA-derived FILES instead of SA values: d_out[0] = .sa
  * bytes (PFP_FLAG_SA), d_out[1] = .ssa, d_out[2] = .esa - device buffers allocated by the library, released with
  * pfp_dev_free; out_bytes their sizes; entries for flags not set stay NULL / 0.  The SA values live inside the call
- * only (8 bytes per text byte, allocated after the suffix sorter has returned its scratch), so a >= 10 GB input
- * with -s fits one GPU.  d_bwt as in pfp_bigbwt_dev. */
+ * only (-S: 8 bytes per text byte, allocated after the suffix sorter has returned its scratch; -s / -e: 8 bytes per
+ * run boundary of the BWT), so a >= 10 GB input with -s fits one GPU.  d_bwt as in pfp_bigbwt_dev.  The buffers are
+ * blocks of the context's memory pool: pfp_dev_free hands them back for reuse by later calls on the context, so the
+ * caller must have finished reading them (or have read them on the context's stream) before it frees them; they are
+ * released with the context at the latest. */
 int pfp_bigbwt_formats_dev(pfp_ctx *ctx, const void *d_text, uint64_t n, int w, uint64_t p, int flags, void *d_bwt,
                            void *d_out[3], uint64_t out_bytes[3], uint64_t *n_used);
 void pfp_dev_free(pfp_ctx *ctx, void *d_ptr);
