@@ -722,19 +722,44 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
     const int uu = __shfl_up((int)unit, o, 64);
     if (lane >= o && unit && uu && ug == g) mx = umx > mx ? umx : mx;
   }
-  // (shuffles above must be executed by every lane: the two serial extensions below are lane-local)
+  // At most one unit leaves the wave through lane 63 (its head is here and wants the minimum over ALL its members) and at
+  // most one enters through lane 0 (its last member is here and wants the maximum): the members outside the wave are
+  // fetched by all 64 lanes together, 64 at a time (one lane walking them was a chain of 3 dependent gathers per member,
+  // hundreds of members long for the word families of a 1000-copy collection).
   const uint64_t g63 = __shfl(g, 63, 64);
   const bool cont63 = __shfl((int)cont, 63, 64) != 0;
-  if (need_first) {
-    if (cont63 && g63 == g)
-      for (uint64_t m = wbase + 64; m < a.N && a.grp[m] == (I)g; m++) { const uint32_t f = a.wrec[a.pos_word[a.sa[m]]].first; mn = f < mn ? f : mn; }
-    sa_put(a, o_first, a.bwsai[mn] - mysl);
+  const unsigned long long fwd = __ballot(need_first && cont63 && g63 == g);       // the head lane of the unit that goes on
+  if (fwd) {
+    uint32_t ext = 0xFFFFFFFFu;
+    for (uint64_t m0 = wbase + 64;; m0 += 64) {
+      const uint64_t m = m0 + lane;
+      const bool mine = m < a.N && a.grp[m] == (I)g63;       // (members are contiguous; a slot of the group emits)
+      uint32_t f = 0xFFFFFFFFu;
+      if (mine) f = a.wrec[a.pos_word[a.sa[m]]].first;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(f, o, 64); f = v < f ? v : f; }
+      ext = f < ext ? f : ext;
+      if (__ballot(mine) != ~0ull) break;
+    }
+    if ((fwd >> lane) & 1ull) mn = ext < mn ? ext : mn;
   }
-  if (need_last) {
-    if (g < wbase)
-      for (uint64_t m = wbase; m-- > g;) { const uint32_t l = a.wrec[a.pos_word[a.sa[m]]].last; mx = l > mx ? l : mx; }
-    sa_put(a, o_last, a.bwsai[mx] - mysl);
+  const uint64_t g0 = __shfl(g, 0, 64);
+  const int unit0 = __shfl((int)unit, 0, 64);
+  const unsigned long long bwd = __ballot(need_last && g < wbase);                  // the last lane of the unit that came in
+  if (bwd && unit0) {
+    uint32_t ext = 0;
+    for (uint64_t m0 = g0; m0 < wbase; m0 += 64) {
+      const uint64_t m = m0 + lane;
+      uint32_t l = 0;
+      if (m < wbase) l = a.wrec[a.pos_word[a.sa[m]]].last;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(l, o, 64); l = v > l ? v : l; }
+      ext = l > ext ? l : ext;
+    }
+    if ((bwd >> lane) & 1ull) mx = ext > mx ? ext : mx;
   }
+  if (need_first) sa_put(a, o_first, a.bwsai[mn] - mysl);
+  if (need_last) sa_put(a, o_last, a.bwsai[mx] - mysl);
 }
 
 // Boundaries of the runs of the BWT slice [out_lo, out_hi): bit r of the map = position out_lo + r starts a run
