@@ -181,15 +181,26 @@ struct BwtOutputs {
   // are stored there, at boundary positions only.
   DBuf<uint64_t> bmap, bpre, sa_c;
   uint64_t n_bound = 0;
+  // ... and, when the emitted slice is the whole BWT, where runs start / end (the .ssa / .esa positions) with their
+  // prefix counts: the sampled files are then written from the bitmaps alone, without another pass over the BWT bytes
+  DBuf<uint64_t> smap, spre, emap, epre;
+  uint64_t n_starts = 0, n_ends = 0;
 };
 // where the SA value of BWT position i (relative to the slice the arrays describe) is found
 struct SaView {
   const uint64_t *dense = nullptr;                       // dense[i], or
   const uint64_t *bmap = nullptr, *bpre = nullptr, *sa_c = nullptr;      // sa_c[rank of i among the set bits of bmap]
+  // whole BWT only: run starts / ends as bitmaps with prefix counts (null: find them in the BWT bytes)
+  const uint64_t *smap = nullptr, *spre = nullptr, *emap = nullptr, *epre = nullptr;
+  uint64_t n_starts = 0, n_ends = 0, n_words = 0;
 };
 inline SaView sa_view(const BwtOutputs &o) {
   SaView v;
-  if (o.sa_c.p) { v.bmap = o.bmap.p; v.bpre = o.bpre.p; v.sa_c = o.sa_c.p; } else v.dense = o.d_sa;
+  if (o.sa_c.p) {
+    v.bmap = o.bmap.p; v.bpre = o.bpre.p; v.sa_c = o.sa_c.p;
+    v.smap = o.smap.p; v.spre = o.spre.p; v.emap = o.emap.p; v.epre = o.epre.p;
+    v.n_starts = o.n_starts; v.n_ends = o.n_ends; v.n_words = (o.n_out + 63) / 64;
+  } else v.dense = o.d_sa;
   return v;
 }
 // emits BWT positions [out_lo,out_hi) into out.d_bwt[0..) / out.d_sa[0..) (default: everything)

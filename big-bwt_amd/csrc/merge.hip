@@ -786,24 +786,53 @@ __device__ __forceinline__ void run_mask16(const uint8_t *__restrict__ bwt, uint
     if (nb < 0 || nb != b) m[k >> 2] |= 1u << (8 * (k & 3));
   }
 }
+struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
 __device__ __forceinline__ uint32_t pack_byte_flags(uint32_t m) {      // flags at bits 0, 8, 16, 24 -> bits 0..3
   return (m & 1u) | ((m >> 7) & 2u) | ((m >> 14) & 4u) | ((m >> 21) & 8u);
 }
-// one lane per 16 positions (one 16-byte load and its two shifted neighbours), four lanes make one word of the map
+// one lane per 16 positions (one 16-byte load and its two shifted neighbours), four lanes make one word of the map;
+// smap / emap (optional): the starts and the ends on their own, with their counts per word
 __global__ __launch_bounds__(256) void run_bitmap_kernel(const uint8_t *__restrict__ bwt, uint64_t cnt, uint64_t *__restrict__ bmap,
-                                                         uint32_t *__restrict__ wcnt) {
+                                                         uint32_t *__restrict__ wcnt, uint64_t *__restrict__ smap,
+                                                         uint32_t *__restrict__ scnt, uint64_t *__restrict__ emap,
+                                                         uint32_t *__restrict__ ecnt) {
   const uint64_t ch = (uint64_t)BID * 256 + threadIdx.x;
   const uint64_t base = ch * 16;
   uint32_t ms[4], me[4];
   run_mask16(bwt, base, cnt, -1, -1, 0, ms);
   run_mask16(bwt, base, cnt, -1, -1, 1, me);
-  uint32_t bits = 0;
+  uint32_t bs = 0, be = 0;
 #pragma unroll
-  for (int q = 0; q < 4; q++) bits |= pack_byte_flags(ms[q] | me[q]) << (4 * q);
-  uint64_t v = (uint64_t)bits << (16 * (threadIdx.x & 3));
-  v |= __shfl_xor(v, 1, 64);
-  v |= __shfl_xor(v, 2, 64);
-  if ((threadIdx.x & 3) == 0 && base < cnt) { bmap[ch >> 2] = v; wcnt[ch >> 2] = (uint32_t)__popcll(v); }
+  for (int q = 0; q < 4; q++) { bs |= pack_byte_flags(ms[q]) << (4 * q); be |= pack_byte_flags(me[q]) << (4 * q); }
+  uint64_t vs = (uint64_t)bs << (16 * (threadIdx.x & 3)), ve = (uint64_t)be << (16 * (threadIdx.x & 3));
+  vs |= __shfl_xor(vs, 1, 64); vs |= __shfl_xor(vs, 2, 64);
+  ve |= __shfl_xor(ve, 1, 64); ve |= __shfl_xor(ve, 2, 64);
+  if ((threadIdx.x & 3) == 0 && base < cnt) {
+    const uint64_t w = ch >> 2;
+    bmap[w] = vs | ve; wcnt[w] = (uint32_t)__popcll(vs | ve);
+    if (smap) { smap[w] = vs; scnt[w] = (uint32_t)__popcll(vs); }
+    if (emap) { emap[w] = ve; ecnt[w] = (uint32_t)__popcll(ve); }
+  }
+}
+// .ssa / .esa pairs of the whole BWT from the bitmaps: one thread per word of the start (end) map, the SA value of a
+// set bit from its rank among all boundaries
+__global__ __launch_bounds__(256) void bitmap_place_kernel(const uint64_t *__restrict__ map, const uint64_t *__restrict__ pre,
+                                                           const uint64_t *__restrict__ bmap, const uint64_t *__restrict__ bpre,
+                                                           const uint64_t *__restrict__ sa_c, uint64_t nw, uint8_t *__restrict__ out10) {
+  const uint64_t w = (uint64_t)BID * 256 + threadIdx.x;
+  if (w >= nw) return;
+  uint64_t m = map[w];
+  if (!m) return;
+  const uint64_t all = bmap[w], rb = bpre[w];
+  uint64_t o = pre[w];
+  while (m) {
+    const int b = __builtin_ctzll(m);
+    m &= m - 1;
+    const uint64_t x = w * 64 + b, v = sa_c[rb + (uint64_t)__popcll(all & ((1ull << b) - 1ull))];
+    uint8_t *dst = out10 + 10 * o++;
+    reinterpret_cast<U64u *>(dst)->v = (x & 0xFFFFFFFFFFull) | (v << 40);       // 5 bytes of x, 3 low bytes of v
+    reinterpret_cast<U16u *>(dst + 8)->v = (uint16_t)(v >> 24);                  // bytes 3, 4 of v
+  }
 }
 __global__ void count_unset_kernel(const uint64_t *__restrict__ v, uint64_t n, unsigned long long *__restrict__ total) {
   const uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
@@ -1538,17 +1567,26 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   const uint64_t cnt_slice = a.out_hi > a.out_lo ? a.out_hi - a.out_lo : 0;
   const uint64_t nw = cdiv64(cnt_slice, 64);
   out.bmap.alloc(c, nw + 1); out.bpre.alloc(c, nw + 1);
+  // the emitted slice is the whole BWT and the caller keeps no SA array: the sampled files come from the bitmaps
+  const bool whole = !out.d_sa && a.out_lo == 0 && a.out_hi == n_out && pos_base == 0 && a.n_out_global == n_out;
+  const bool want_s = whole && (flags & PFP_FLAG_SSA), want_e = whole && (flags & PFP_FLAG_ESA);
   {
-    DBuf<uint32_t> wcnt(c, nw + 1);
+    DBuf<uint32_t> wcnt(c, nw + 1), scnt, ecnt;
     PFP_HIP(hipMemsetAsync(wcnt.p + nw, 0, 4, c->stream));
     PFP_HIP(hipMemsetAsync(out.bmap.p + nw, 0, 8, c->stream));
+    if (want_s) { out.smap.alloc(c, nw + 1); out.spre.alloc(c, nw + 1); scnt.alloc(c, nw + 1); PFP_HIP(hipMemsetAsync(scnt.p + nw, 0, 4, c->stream)); }
+    if (want_e) { out.emap.alloc(c, nw + 1); out.epre.alloc(c, nw + 1); ecnt.alloc(c, nw + 1); PFP_HIP(hipMemsetAsync(ecnt.p + nw, 0, 4, c->stream)); }
     if (nw) {
-      KScope ks(c, "pfp::run_bitmap_kernel", cnt_slice + nw * 12);
+      KScope ks(c, "pfp::run_bitmap_kernel", cnt_slice + nw * (12 + (want_s ? 12 : 0) + (want_e ? 12 : 0)));
       hipLaunchKernelGGL(run_bitmap_kernel, gdim(cdiv(cdiv64(cnt_slice, 16), 256)), gdim(256), 0, c->stream, out.d_bwt, cnt_slice,
-                         out.bmap.p, wcnt.p);
+                         out.bmap.p, wcnt.p, out.smap.p, scnt.p, out.emap.p, ecnt.p);
     }
     exclusive_sum_u32_u64(c, wcnt.p, out.bpre.p, nw + 1);
+    if (want_s) exclusive_sum_u32_u64(c, scnt.p, out.spre.p, nw + 1);
+    if (want_e) exclusive_sum_u32_u64(c, ecnt.p, out.epre.p, nw + 1);
     out.n_bound = read_scalar(c, out.bpre.p + nw);
+    if (want_s) out.n_starts = read_scalar(c, out.spre.p + nw);
+    if (want_e) out.n_ends = read_scalar(c, out.epre.p + nw);
   }
   a.bmap = out.bmap.p; a.bpre = out.bpre.p;
   if (!out.d_sa) {      // the caller keeps no SA array: values go to their rank among the boundaries
@@ -1652,7 +1690,6 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
   __syncthreads();
   if (threadIdx.x == 0) tile_cnt[BID] = ws[0] + ws[1] + ws[2] + ws[3];
 }
-struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
 __global__ __launch_bounds__(256) void run_place_kernel(const uint8_t *__restrict__ bwt, SaView sa,
                                                         uint64_t cnt, uint64_t pos_base, int left, int right, int run_end,
                                                         const uint64_t *__restrict__ tile_off, uint8_t *__restrict__ out10) {
@@ -1709,6 +1746,18 @@ void RunSampler::place(const SaView &sa, uint64_t pos_base, uint8_t *out10) {
 
 uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const SaView &sa, uint64_t n_out, bool run_end,
                          DBuf<uint8_t> &out10) {
+  const uint64_t *map = run_end ? sa.emap : sa.smap;
+  if (map && sa.sa_c) {      // the merge left the run starts / ends as bitmaps
+    const uint64_t pairs = run_end ? sa.n_ends : sa.n_starts;
+    out10.alloc(c, pairs * 10 + 16);
+    if (sa.n_words) {
+      KScope ks(c, "pfp::run_place_kernel", sa.n_words * 24 + pairs * 18);
+      hipLaunchKernelGGL(bitmap_place_kernel, gdim(cdiv(sa.n_words, 256)), gdim(256), 0, c->stream, map, run_end ? sa.epre : sa.spre, sa.bmap,
+                         sa.bpre, sa.sa_c, sa.n_words, out10.p);
+      PFP_HIP(hipGetLastError());
+    }
+    return pairs;
+  }
   RunSampler rs(c, bwt, n_out, -1, -1, run_end);
   out10.alloc(c, rs.pairs * 10 + 16);
   rs.place(sa, 0, out10.p);
