@@ -144,11 +144,13 @@ def main():
         step()
     ctx.set_kernel_trace(True)          # HIP events around every kernel, on the library's own stream
     barrier(); torch.cuda.synchronize()
+    pc0 = ctx.pool_counters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
+    pc1 = ctx.pool_counters()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -339,7 +341,9 @@ def main():
             "sa_rounds": {"dict": st["sa_rounds_dict"], "parse": st["sa_rounds_parse"]},
             "merge_stats": {k: st[k] for k in ("hard_groups", "hard_chars", "hard_big_groups", "hard_max_chars", "hard_max_members", "hard_minor_groups", "hard_minor_chars", "extra_triggers", "index_bits")},
             "runs": R,
-            "device_memory": {"peak_bytes_in_use": mem["peak"], "held_from_driver": mem["held"]},
+            "device_memory": {"peak_bytes_in_use": mem["peak"], "held_from_driver": mem["held"],
+                              "driver_allocations_in_timed_steps": pc1["driver_allocs"] - pc0["driver_allocs"],
+                              "pool_trims_in_timed_steps": pc1["trims"] - pc0["trims"]},
             "verified": {"outputs_match_reference_digests_whole_text": digests,
                          "bwt_is_permutation_of_text_plus_eos": permutation_ok,
                          "bit_exact_vs_reference_on_cpu_sample": parity_sample,

@@ -76,6 +76,8 @@ struct pfp_pool {
   hipStream_t stream = nullptr;
   std::string corrupt;                             // first canary damage seen (debug mode)
   uint64_t debug_blocks = 0;
+  size_t soft_limit = 0;                           // bytes held from the driver beyond which any cached block that fits is reused
+  uint64_t driver_allocs = 0, trims = 0;           // hipMalloc calls; times a failed one made the pool give its cache back
   void *get(size_t bytes, hipError_t *err, const char *file = "", int line = 0) {
     *err = hipSuccess;
     if (debug) return get_debug(bytes, err, file, line);
@@ -83,6 +85,14 @@ struct pfp_pool {
     for (size_t i = 0; i < free_list.size(); i++) {
       size_t b = free_list[i].bytes;
       if (b >= bytes && b <= bytes + bytes / 4 + 4096 && b < best) { best = b; bi = i; }
+    }
+    if (bi == (size_t)-1 && soft_limit && total_bytes + bytes > soft_limit) {
+      // the pool already holds most of the device: a cached block that is merely too large is better than a
+      // driver call that may fail and cost every cached block (smallest block that fits, whatever the slack)
+      for (size_t i = 0; i < free_list.size(); i++) {
+        size_t b = free_list[i].bytes;
+        if (b >= bytes && b < best) { best = b; bi = i; }
+      }
     }
     if (bi != (size_t)-1) {
       void *p = free_list[bi].p;
@@ -92,9 +102,11 @@ struct pfp_pool {
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
+    driver_allocs++;
     if (e != hipSuccess) {   // give cached blocks back to the driver and retry once
       (void)hipGetLastError();
       trim();
+      trims++;
       e = hipMalloc(&p, bytes);
     }
     if (e != hipSuccess) { *err = e; (void)hipGetLastError(); return nullptr; }

@@ -400,6 +400,7 @@ int pfp_ctx_create(pfp_ctx **out, int device) {
     PFP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->pool.stream = c->stream;
     { const char *pd = getenv("PFP_POOL_DEBUG"); c->pool.debug = pd && pd[0] && pd[0] != '0'; }
+    { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->pool.soft_limit = tot / 10 * 7; else (void)hipGetLastError(); }
     PFP_HIP(hipHostMalloc((void **)&c->h_scalars, 16 * sizeof(uint64_t), hipHostMallocDefault));
     const char *dbg = getenv("PFP_DEBUG");
     c->debug = dbg && dbg[0] && dbg[0] != '0';
@@ -452,6 +453,11 @@ void pfp_pool_trim(pfp_ctx *c) {      // give the cached device blocks back to t
 int pfp_get_mem_stats(const pfp_ctx *c, uint64_t out[4]) {
   if (!c || !out) return PFP_EINVAL;
   out[0] = c->pool.total_bytes; out[1] = c->pool.peak_bytes; out[2] = c->pool.live_bytes; out[3] = c->pool.debug ? c->pool.debug_blocks : 0;
+  return PFP_OK;
+}
+int pfp_get_pool_counters(const pfp_ctx *c, uint64_t out[2]) {
+  if (!c || !out) return PFP_EINVAL;
+  out[0] = c->pool.driver_allocs; out[1] = c->pool.trims;
   return PFP_OK;
 }
 void *pfp_ctx_stream(pfp_ctx *c) { return c ? (void *)c->stream : nullptr; }

@@ -59,6 +59,9 @@ int pfp_debug_check(pfp_ctx *ctx);
 void pfp_pool_trim(pfp_ctx *ctx);
 /* out = {bytes held from the driver, peak bytes in use, bytes in use now, blocks handed out in debug mode} */
 int pfp_get_mem_stats(const pfp_ctx *ctx, uint64_t out[4]);
+/* out = {allocations that reached the driver (hipMalloc) since the context was made, times a failed one made the
+ * pool hand its cached blocks back}: a steady-state call adds nothing to either */
+int pfp_get_pool_counters(const pfp_ctx *ctx, uint64_t out[2]);
 
 /* ------------------------------------------------------------------------------------
  * Stage 1a: rolling Karp-Rabin window scan + phrase-boundary compaction.
