@@ -85,6 +85,33 @@ def test_benchmark_workloads_match_reference_digests(pkg, ctx, synth, golden_ful
         check(got, g)
 
 
+def test_north_star_12_6_gb_with_sampled_sa(pkg, ctx, synth, golden_full):
+    """The north star's workload on one GPU: 1024 mutated copies, 12.6 GB, -w 10 -p 100 -s.  The reference took 42
+    minutes for it in the build container (tests/golden/make_golden_huge.py); its .bwt and .ssa digests against
+    the device results of pfp_bigbwt_formats_dev (the SA values stay inside the call: 8 bytes per run boundary)."""
+    import torch
+    if "huge_s" not in golden_full:
+        pytest.skip("no reference digest committed for this workload")
+    g = golden_full["huge_s"]
+    dev = torch.device("cuda", 0)
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 230 * (1 << 30):
+        pytest.skip("needs about 230 GB of free device memory")
+    ctx.pool_trim()
+    text = synth.workload_text_torch(dev, "huge_s")
+    torch.cuda.empty_cache()
+    assert text.numel() == g["n"] and sha_dev(text) == g["text_sha256"]
+    try:
+        got = run_formats(pkg, ctx, text, g["w"], g["p"], g["flags"])
+        assert set(got) == {"bwt", "ssa"}
+        check(got, g)
+        assert ctx.stats()["hard_big_groups"] > 0 and ctx.stats()["hard_minor_groups"] > 0      # every hard-group path ran
+    finally:
+        del text
+        ctx.pool_trim()
+        torch.cuda.empty_cache()
+
+
 def test_pack_and_sample_exports_on_slices(O, pkg, ctx):
     """pfp_pack5_dev / pfp_sample_runs_dev: slices with one halo byte on each side concatenate to the whole file"""
     import torch
