@@ -37,7 +37,25 @@ void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &v
   KScope ks(c, sort_name<K, V>(), n * sizeof(K) + passes * n * 2 * (sizeof(K) + sizeof(V)));
   rocprim::double_buffer<K> dk(k.p, kalt.p);
   rocprim::double_buffer<V> dv(v.p, valt.p);
-  PRIM2(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream));
+  bool done = false;
+#ifdef PFP_SORTCFG_EXPERIMENT
+  static const int cfg = []() { const char *e = getenv("PFP_SORTCFG"); return e ? atoi(e) : 0; }();
+  using rocprim::kernel_config; using rocprim::default_config; using rocprim::radix_sort_config; using rocprim::radix_sort_onesweep_config;
+  using A = rocprim::block_radix_rank_algorithm;
+#define PFP_TRY_CFG(id, BS, IPT, ALG)                                                                                          \
+  if constexpr (sizeof(K) == 8 && sizeof(V) == 4) if (cfg == id) {                                                                       \
+    using C_ = radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<BS, IPT>, kernel_config<BS, IPT>, 8, ALG>>; \
+    PRIM2(rocprim::radix_sort_pairs<C_>(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream));                            \
+  } else
+  PFP_TRY_CFG(1, 256, 16, A::match)
+  PFP_TRY_CFG(2, 512, 12, A::match)
+  PFP_TRY_CFG(3, 1024, 8, A::match)
+  PFP_TRY_CFG(4, 512, 20, A::match)
+  PFP_TRY_CFG(5, 256, 24, A::match)
+  PFP_TRY_CFG(6, 1024, 12, A::match)
+  PFP_TRY_CFG(8, 256, 12, A::match)
+#endif
+  if (!done) PRIM2(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream));
   if (dk.current() != k.p) std::swap(k, kalt);
   if (dv.current() != v.p) std::swap(v, valt);
 }

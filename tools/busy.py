@@ -32,5 +32,13 @@ for s, e, _ in chain[1:]:
     else:
         cur_e = max(cur_e, e)
 union += cur_e - cur_s
+import re
+agg = {}
+for st, en, name in chain:
+    m = re.search(r"pfp::(\w+)", name)
+    key = "pfp::" + m.group(1) if m and "rocprim" not in name[:40] else re.sub(r"<.*", "", name.replace("void ", ""))[:60]
+    a = agg.setdefault(key, [0, 0]); a[0] += 1; a[1] += en - st
+for k, (cnt, ns) in sorted(agg.items(), key=lambda x: -x[1][1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 25]:
+    print(f"  {k:62s} {cnt:5d} {ns / 1e6:9.3f} ms")
 print(f"dispatches {len(chain)}  span {span / 1e6:.2f} ms  kernel time {summed / 1e6:.2f} ms  busy (union) {union / 1e6:.2f} ms  "
       f"busy fraction {union / span:.3f}  idle {(span - union) / 1e6:.2f} ms")
