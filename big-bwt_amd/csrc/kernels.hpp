@@ -79,6 +79,7 @@ inline bool use_wide_index(const pfp_ctx *c, uint64_t dsize) { return c->force_w
 
 template <class I>
 struct SuffixOrderT {
+  double rep_hint = 0;   // set by the caller before sort_dict_suffixes: text bytes per dictionary byte (>= 2: a repetitive collection)
   uint64_t N = 0;        // slots held here: all NP suffixes, or (key-range sharded sort) one contiguous range of SA(D)
   uint64_t NP = 0;       // positions of the sorted string
   uint64_t slot_base = 0;        // range mode: SA(D) slot of local slot 0

@@ -221,6 +221,7 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
     with_width(ch.ord.wide, [&](auto tag) {
       using I = decltype(tag);
       auto &so = ch.ord.get<I>();
+      so.rep_hint = (double)ch.n_used / (double)std::max<uint64_t>(ch.D.dsize, 1);
       sort_dict_suffixes<I>(c, ch.D.bytes.p, ch.D.dsize, ch.ix.slen.p, so, dense_sa ? nullptr : &pay);
       if (c->debug) validate_suffix_order<I>(c, ch.D.bytes.p, so, true, "dict SA");
       compute_lexrank<I>(c, ch.D, so, ch.ix);

@@ -59,6 +59,17 @@ void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &v
   if (dk.current() != k.p) std::swap(k, kalt);
   if (dv.current() != v.p) std::swap(v, valt);
 }
+template <class K>
+void sort_keys_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, size_t n, int bb, int eb) {
+  if (!n) return;
+  PFP_REQUIRE(k.n >= n && kalt.n >= n, PFP_EINVAL, "sort_keys_db: a buffer is shorter than n");
+  const uint64_t passes = (uint64_t)(eb - bb + 7) / 8;
+  KScope ks(c, "rocprim::radix_sort_keys<u64>", n * sizeof(K) + passes * n * 2 * sizeof(K));
+  rocprim::double_buffer<K> dk(k.p, kalt.p);
+  PRIM2(rocprim::radix_sort_keys(tmp, tb, dk, n, (unsigned)bb, (unsigned)eb, c->stream));
+  if (dk.current() != k.p) std::swap(k, kalt);
+}
+template void sort_keys_db<uint64_t>(pfp_ctx *, DBuf<uint64_t> &, DBuf<uint64_t> &, size_t, int, int);
 template void sort_pairs<uint64_t, uint32_t>(pfp_ctx *, const uint64_t *, uint64_t *, const uint32_t *, uint32_t *, size_t, int, int);
 template void sort_pairs<uint32_t, uint32_t>(pfp_ctx *, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, size_t, int, int);
 template void sort_pairs<uint64_t, uint64_t>(pfp_ctx *, const uint64_t *, uint64_t *, const uint64_t *, uint64_t *, size_t, int, int);

@@ -48,7 +48,7 @@ __device__ __forceinline__ uint64_t suf_len(const SufGeom &g, uint64_t i) {
 // lut[b] = (code << 6) | length.
 struct KeyCode {
   uint32_t lut[256];
-  int kbits, hmin;
+  int kbits, hmin, maxlen;
 };
 
 __global__ __launch_bounds__(256) void byte_histogram_kernel(const uint8_t *__restrict__ s, uint64_t N,
@@ -128,6 +128,7 @@ static KeyCode make_key_code(const uint64_t hist[256]) {
   for (int kb : {39, 47, 55}) if (Lm > 0 && kb * H / Lm >= need) { kc.kbits = kb; break; }
   { const char *e = getenv("PFP_KEYBITS"); if (e) kc.kbits = std::max(8, std::min(63, atoi(e))); }
   kc.hmin = std::max(1, std::min(32, kc.kbits / maxlen));
+  kc.maxlen = maxlen;
   return kc;
 }
 
@@ -249,21 +250,32 @@ template <class I>
 __global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
                                                                const uint32_t *__restrict__ slen, SlotPayloadSrc P,
                                                                int paybits, uint64_t *__restrict__ key,
-                                                               I *__restrict__ val) {
+                                                               I *__restrict__ val, int idx_bits) {
   __shared__ KeyStreamLds L;
   const uint64_t B0 = (uint64_t)BID * kKeyPos;
   uint64_t k = block_stream_key(L, s, N, kp, slen, B0);
   const uint64_t pos = B0 + threadIdx.x;
   if (threadIdx.x >= kKeyPos || pos >= N) return;
+  if (idx_bits) { key[pos] = (k << idx_bits) | pos; return; }      // keys-only sort: the position rides in the low bits
   if (paybits) k |= (uint64_t)slot_record(s, pos, P) << 48;
   key[pos] = k; val[pos] = (I)pos;
 }
+// sorted (key << idx_bits | position) words -> the sorted keys and the sorted positions
+template <class I>
+__global__ void split_keys_kernel(const uint64_t *__restrict__ comb, uint64_t n, int idx_bits, uint64_t *__restrict__ key,
+                                  I *__restrict__ val) {
+  const uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const uint64_t x = comb[a];
+  key[a] = x >> idx_bits;
+  val[a] = (I)(x & ((1ull << idx_bits) - 1ull));
+}
 // PFP_DEBUG: the bit-stream keys against the character-by-character ones
 __global__ void check_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp, const uint64_t *__restrict__ key,
-                                  uint64_t keymask, unsigned long long *__restrict__ bad) {
+                                  uint64_t keymask, unsigned long long *__restrict__ bad, int idx_bits) {
   uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  if ((key[i] & keymask) != packed_key_at(s, i, kp.kbits, kp.lut)) atomicAdd(bad, 1ull);
+  if (((key[i] >> idx_bits) & keymask) != packed_key_at(s, i, kp.kbits, kp.lut)) atomicAdd(bad, 1ull);
 }
 template <class I>
 __global__ void init_keys_bytes_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t *__restrict__ key,
@@ -368,7 +380,8 @@ template <class I>
 __global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const I *__restrict__ act_grp,
                                                              const uint32_t *__restrict__ key, const I *__restrict__ val,
                                                              uint8_t *__restrict__ gs, uint32_t *__restrict__ keyo,
-                                                             I *__restrict__ valo, uint32_t *__restrict__ overflow) {
+                                                             I *__restrict__ valo, uint32_t *__restrict__ overflow,
+                                                             uint8_t *__restrict__ big) {
   constexpr int K = (int)kSmallSeg, W = 256 + 2 * K;
   __shared__ uint32_t lkey[W];
   __shared__ I lgrp[W];
@@ -387,7 +400,13 @@ __global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const I
   gs[a] = lgrp[la - 1] != g ? 1 : 0;
   int ls = la;
   while (ls > la - (K - 1) && lgrp[ls - 1] == g) ls--;
-  if (lgrp[ls - 1] == g) { atomicOr(overflow, 1u); return; }      // the group starts K or more positions back
+  // a group of more than K members: with `big` its elements are passed through in place and flagged (the caller
+  // sorts just those), without it the round is the library's
+  if (lgrp[ls - 1] == g) {      // the group starts K or more positions back
+    atomicOr(overflow, 1u);
+    if (big) { big[a] = 1; keyo[a] = lkey[la]; valo[a] = val[a]; }
+    return;
+  }
   const uint32_t ka = lkey[la];
   uint32_t r = 0;
   int j = ls;
@@ -395,10 +414,35 @@ __global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const I
     const uint32_t kj = lkey[j];
     r += (kj < ka || (kj == ka && j < la)) ? 1u : 0u;
   }
-  if (lgrp[j] == g) { atomicOr(overflow, 1u); return; }      // more than K members (j <= ls + K < W)
+  if (lgrp[j] == g) {      // more than K members (j <= ls + K < W)
+    atomicOr(overflow, 1u);
+    if (big) { big[a] = 1; keyo[a] = ka; valo[a] = val[a]; }
+    return;
+  }
+  if (big) big[a] = 0;
   const uint64_t s0 = a - (uint64_t)(la - ls);
   keyo[s0 + r] = ka;
   valo[s0 + r] = val[a];
+}
+// the elements of the groups seg_small_sort_kernel passed through: (group, key) words for one sort of just those,
+// and the way back - the sorted side list has the groups in list order, so its j-th element belongs at idx[j]
+template <class I>
+__global__ void big_seg_gather_kernel(uint64_t nb, const I *__restrict__ idx, const I *__restrict__ act_grp, const uint32_t *__restrict__ keyo,
+                                      const I *__restrict__ valo, uint64_t *__restrict__ k64, I *__restrict__ v) {
+  const uint64_t j = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (j >= nb) return;
+  const I a = idx[j];
+  k64[j] = ((uint64_t)act_grp[a] << 32) | keyo[a];
+  v[j] = valo[a];
+}
+template <class I>
+__global__ void big_seg_scatter_kernel(uint64_t nb, const I *__restrict__ idx, const uint64_t *__restrict__ k64, const I *__restrict__ v,
+                                       uint32_t *__restrict__ keyo, I *__restrict__ valo) {
+  const uint64_t j = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (j >= nb) return;
+  const I a = idx[j];
+  keyo[a] = (uint32_t)k64[j];
+  valo[a] = v[j];
 }
 __global__ void seg_end_kernel(uint32_t ng, uint32_t m, const uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
                                uint32_t *__restrict__ maxlen) {
@@ -725,7 +769,7 @@ template RankViewT<uint64_t> rank_view(const SuffixOrderT<uint64_t> &);
 
 template <class I>
 static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, uint64_t h0, SuffixOrderT<I> &out,
-                     int key0_bits = 64, bool dict_keys = false, uint64_t n_elems = ~0ull) {
+                     int key0_bits = 64, bool dict_keys = false, uint64_t n_elems = ~0ull, int idx_bits = 0) {
   // precondition: key/val hold the initial (prefix key, position) pairs of the N suffixes to sort: all
   // NP positions, or (range mode, n_elems given) the ones of this rank's key range
   using K = typename IdxTraits<I>::DKey;        // key of a doubling round: (group head, 1 + rank of the continuation)
@@ -742,8 +786,16 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   //      pairs (no third copy inside the library); afterwards keyo/valo hold the sorted pairs
   DBuf<uint64_t> keyo(c, N);
   DBuf<I> valo(c, N);
-  sort_pairs_db(c, key, keyo, val, valo, N, 0, key0_bits);
-  std::swap(key, keyo); std::swap(val, valo);
+  if (idx_bits) {
+    // keys-only first round: the words are (key << idx_bits | position), 16 bytes per element and pass instead of 24;
+    // the sort is stable on the key bits alone, so ties stay in position order; one streaming pass splits the result
+    sort_keys_db(c, key, keyo, N, idx_bits, idx_bits + key0_bits);
+    KScope ks(c, "pfp::split_keys_kernel", N * (16 + sizeof(I)));
+    hipLaunchKernelGGL(split_keys_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, key.p, N, idx_bits, keyo.p, valo.p);
+  } else {
+    sort_pairs_db(c, key, keyo, val, valo, N, 0, key0_bits);
+    std::swap(key, keyo); std::swap(val, valo);
+  }
   if (lazy) { key.release(); val.release(); }      // dictionary mode: later rounds sort the (much smaller) unresolved set
   // active list (slot, suffix, group) of the unresolved suffixes and per-round scratch, `cap` elements each;
   // dictionary mode allocates them when the first round has told how many suffixes stay unresolved
@@ -809,12 +861,30 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   };
   // k32/val -> k32o/valo, every group of the (grouped) active list sorted by its 32-bit key; false: some group has
   // more than kSmallSeg members (nothing usable was written)
+  // 32-bit index build: the groups of more than kSmallSeg members are passed through in place, flagged, and finished
+  // by ONE library sort of just their elements (a few long families no longer send the whole round to the library)
+  static const bool big_side = getenv("PFP_NO_BIGSIDE") == nullptr;
+  DBuf<uint8_t> bigf;
   auto seg_small_sort = [&](uint64_t mm) -> bool {
     ovf_d.zero();
+    const bool side = big_side && !kWide;
+    if (side && (!bigf.p || bigf.n < mm + 16)) bigf.alloc(c, list_cap + 16);
     { KScope ks(c, "pfp::seg_small_sort_kernel", mm * (8 + 3 * sizeof(I) + 1));
       hipLaunchKernelGGL(seg_small_sort_kernel<I>, gdim(cdiv(mm, TB)), gdim(TB), 0, c->stream, mm, act_grp.p, k32.p, val.p, gs.p, k32o.p,
-                         valo.p, ovf_d.p); }
-    return read_scalar(c, ovf_d.p) == 0;
+                         valo.p, ovf_d.p, side ? bigf.p : (uint8_t *)nullptr); }
+    if (read_scalar(c, ovf_d.p) == 0) return true;
+    if (!side) return false;
+    PFP_HIP(hipMemsetAsync(bigf.p + mm, 0, 16, c->stream));      // (the flag reader looks at 16 bytes at a time)
+    const uint64_t nbig = count_flags(c, bigf.p, mm);
+    if (nbig * 2 > mm) return false;                // mostly long groups: the round is the library's after all
+    DBuf<I> idx(c, nbig + 1), sv(c, nbig), sva(c, nbig);
+    DBuf<uint64_t> sk(c, nbig), ska(c, nbig), cnt(c, 1);
+    select_index<I>(c, bigf.p, idx.p, cnt.p, mm);
+    hipLaunchKernelGGL(big_seg_gather_kernel<I>, gdim(cdiv(nbig, TB)), gdim(TB), 0, c->stream, nbig, idx.p, act_grp.p, k32o.p, valo.p, sk.p, sv.p);
+    sort_pairs_db(c, sk, ska, sv, sva, nbig, 0, 32 + nb);
+    hipLaunchKernelGGL(big_seg_scatter_kernel<I>, gdim(cdiv(nbig, TB)), gdim(TB), 0, c->stream, nbig, idx.p, sk.p, sv.p, k32o.p, valo.p);
+    PFP_HIP(hipGetLastError());
+    return true;
   };
   auto seg_setup = [&](uint64_t mm, uint32_t &ng, uint32_t &maxlen) {      // segments = groups of the (grouped) active list
     seg_bufs();
@@ -1089,19 +1159,38 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   PFP_REQUIRE(N >= 1 && (sizeof(I) == 8 ? N < (1ull << 40) : N < 0xFFFFFFF0ull), PFP_ELIMIT,
               sizeof(I) == 8 ? "dictionary of 2^40 bytes or more" : "dictionary too large for 32-bit suffix indices");
   SufGeom g{MODE_DICT, N, slen};
-  const KeyCode kc = dict_key_code(c, bytes, N);
+  KeyCode kc = dict_key_code(c, bytes, N);
+  // Keys-only first round.  A dictionary of a repetitive collection (text / dictionary >= 2) is mostly families of
+  // variants that no first-round key separates, whatever its width: the first round only has to bring the families
+  // together.  Then the position fits into the same 64-bit word as a (shorter) key, the sort moves 16 bytes per
+  // element and pass instead of 24 and makes 4-5 passes instead of 7, and the merge records in the key's spare bits
+  // (which such an input hardly uses: most slots are re-ordered later) are given up.
+  static const int keysonly_env = []() { const char *e = getenv("PFP_KEYSONLY"); return e ? atoi(e) : -1; }();
+  int idx_bits = 0;
+  if (sizeof(I) == 4 && N >= 2 && (keysonly_env == 1 || (keysonly_env != 0 && out.rep_hint >= 2.0 && N >= (1u << 20)))) {
+    const int ib = bits_for(N - 1);
+    int width = 64 - ib;                      // key bits incl. the terminator flag
+    if (width > 24 && width % 8 <= 2) width -= width % 8;       // a radix pass for one or two bits is a whole pass
+    // (measured: 36 key bits on 129 M suffixes - first sort 7.8 -> 3.9 ms, same rounds after it; 31 key bits on 1.7 G
+    //  suffixes leave three times as many unresolved after the first pivot round - the pair sort stays there)
+    if (width - 1 >= 35 || keysonly_env == 1) {
+      if (kc.kbits > width - 1) { kc.kbits = std::max(8, width - 1); kc.hmin = std::max(1, std::min(32, kc.kbits / kc.maxlen)); }
+      idx_bits = ib;
+    }
+  }
   DBuf<uint64_t> key(c, N);
-  DBuf<I> val(c, N);
+  DBuf<I> val;
+  if (!idx_bits) val.alloc(c, N);
   static const bool no_payload = getenv("PFP_NO_PAYLOAD") != nullptr;
-  out.paybits = (pay && !no_payload && kc.kbits + 1 <= 48) ? 16 : 0;
+  out.paybits = (pay && !no_payload && !idx_bits && kc.kbits + 1 <= 48) ? 16 : 0;
   out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
-  { KScope ks(c, "pfp::init_keys_packed_kernel", N * (9 + sizeof(I) + (out.paybits ? 9 : 0)));
+  { KScope ks(c, "pfp::init_keys_packed_kernel", N * (9 + (idx_bits ? 0 : sizeof(I)) + (out.paybits ? 9 : 0)));
     hipLaunchKernelGGL(init_keys_packed_kernel<I>, gdim((unsigned)cdiv64(N, kKeyPos)), gdim(256), 0, c->stream, bytes, N, kc, slen,
-                       pay ? *pay : SlotPayloadSrc{}, out.paybits, key.p, val.p); }
+                       pay ? *pay : SlotPayloadSrc{}, out.paybits, key.p, val.p, idx_bits); }
   if (c->debug) {
     DBuf<unsigned long long> bad(c, 1);
     bad.zero();
-    hipLaunchKernelGGL(check_keys_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, bytes, N, kc, key.p, out.keymask, bad.p);
+    hipLaunchKernelGGL(check_keys_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, bytes, N, kc, key.p, out.keymask, bad.p, idx_bits);
     PFP_HIP(hipMemcpyAsync(c->h_scalars, bad.p, 8, hipMemcpyDeviceToHost, c->stream));
     sync(c);
     PFP_REQUIRE(c->h_scalars[0] == 0, PFP_EHIP, "bit-stream keys differ from packed_key_at at " + std::to_string(c->h_scalars[0]) + " positions");
@@ -1110,7 +1199,7 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   PFP_HIP(hipMemcpyAsync(out.lut.p, kc.lut, 1024, hipMemcpyHostToDevice, c->stream));
   sync(c);      // kc is a stack object
   out.bytes = bytes; out.kbits = kc.kbits;
-  doubling<I>(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true);
+  doubling<I>(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true, ~0ull, idx_bits);
 }
 template void sort_dict_suffixes<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, SuffixOrderT<uint32_t> &, const SlotPayloadSrc *);
 template void sort_dict_suffixes<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, SuffixOrderT<uint64_t> &, const SlotPayloadSrc *);
