@@ -5,7 +5,7 @@ usage: pmc_to_json.py <fetch.csv> <write.csv> <workload> <out.json>
 Per kernel (bench.py's names): raw FETCH/WRITE bytes per chain execution and the corrected HBM bytes
 2*FETCH + WRITE (gfx950: FETCH_SIZE reports half of the bytes of wide coalesced streaming reads,
 MI355X_MICROARCH.md 'HBM'; exact for WRITE_SIZE).  A chain = one pfp_bigbwt_dev call; the number of
-chains in the profiled run is the number of pfp::expand_kernel dispatches."""
+chains in the profiled run is the number of pfp::dict_index_fill_kernel dispatches (one per chain in every mode)."""
 import collections, csv, json, re, sys
 
 def bench_name(n):
@@ -33,7 +33,7 @@ def load(f):
 
 fetch, disp = load(sys.argv[1])
 write, _ = load(sys.argv[2])
-chains = max(1, disp.get('pfp::expand_kernel', 1))
+chains = max(1, disp.get('pfp::dict_index_fill_kernel', 1))
 out = dict(workload=sys.argv[3], chains_in_profiled_run=chains,
            source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), tools/pmc_to_json.py",
            correction="traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB*1024); the x2 is calibrated for 16 B/lane streaming loads, gathers are over-corrected",
