@@ -1084,6 +1084,12 @@ __global__ void dist_sym_gid_kernel(uint64_t P, const uint32_t *__restrict__ lpi
   if (k < P) sym[k] = lexrank[gid_local[lpid[k]]] + 1;
 }
 
+__global__ __launch_bounds__(256) void sum_u32_kernel(const uint32_t *__restrict__ v, uint64_t n, unsigned long long *__restrict__ total) {
+  unsigned long long s = 0;
+  for (uint64_t i = (uint64_t)BID * 256 + threadIdx.x; i < n; i += (uint64_t)GDIM * 256) s += v[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
+}
 template <class I>
 __global__ void add_one_kernel(uint32_t n, const I *__restrict__ in, uint64_t *__restrict__ out) {
   uint32_t j = BID * blockDim.x + threadIdx.x;
@@ -1184,10 +1190,20 @@ static void dist_sort_global(pfp_ctx *c, DistState *ds, uint32_t part, uint32_t 
   const SlotPayloadSrc pay{ds->ix.pos_word.p, ds->ix.slen.p, ds->G.wocc.p, d, ds->w};
   const SlotPayloadSrc *payp = (ds->flags & PFP_FLAG_SA) ? nullptr : &pay;      // full SA: the merge gathers wider records itself
   ds->ord.wide = use_wide_index(c, ds->G.dsize);
+  // phrases per distinct word = text bytes per dictionary byte, near enough (the same on every rank: the keys-only
+  // first round of the sorter is chosen from it)
+  double rep_hint = 0;
+  {
+    DBuf<unsigned long long> tot(c, 1);
+    tot.zero();
+    hipLaunchKernelGGL(sum_u32_kernel, gdim((int)std::min<uint64_t>(cdiv64(d, 256), 1024)), gdim(256), 0, c->stream, ds->G.wocc.p, (uint64_t)d, tot.p);
+    rep_hint = (double)read_scalar(c, (const uint64_t *)tot.p) / (double)std::max<uint32_t>(d, 1);
+  }
   uint64_t info_rounds = 0, info_complete = 1, info_N = 0, info_base = 0;
   with_width(ds->ord.wide, [&](auto tag) {
     using I = decltype(tag);
     auto &so = ds->ord.get<I>();
+    so.rep_hint = rep_hint;
     if (parts == 1) {
       sort_dict_suffixes<I>(c, ds->G.bytes.p, ds->G.dsize, ds->ix.slen.p, so, payp);
       if (c->debug) validate_suffix_order<I>(c, ds->G.bytes.p, so, true, "global dict SA");

@@ -398,26 +398,25 @@ __global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const I
   const int la = (int)threadIdx.x + K;
   const I g = lgrp[la];
   gs[a] = lgrp[la - 1] != g ? 1 : 0;
-  int ls = la;
-  while (ls > la - (K - 1) && lgrp[ls - 1] == g) ls--;
   // a group of more than K members: with `big` its elements are passed through in place and flagged (the caller
-  // sorts just those), without it the round is the library's
-  if (lgrp[ls - 1] == g) {      // the group starts K or more positions back
-    atomicOr(overflow, 1u);
-    if (big) { big[a] = 1; keyo[a] = lkey[la]; valo[a] = val[a]; }
-    return;
-  }
+  // sorts just those), without it the round is the library's.  Groups are contiguous, so two probes tell: the
+  // position K back, and - once the start is known - the position K past it.
   const uint32_t ka = lkey[la];
-  uint32_t r = 0;
-  int j = ls;
-  for (; j < ls + K && j < W && lgrp[j] == g; j++) {
-    const uint32_t kj = lkey[j];
-    r += (kj < ka || (kj == ka && j < la)) ? 1u : 0u;
+  bool too_long = lgrp[la - K] == g;      // the group starts K or more positions back
+  int ls = la;
+  if (!too_long) {
+    while (lgrp[ls - 1] == g) ls--;       // (stops within K - 1 steps)
+    too_long = ls + K < W && lgrp[ls + K] == g;      // more than K members
   }
-  if (lgrp[j] == g) {      // more than K members (j <= ls + K < W)
+  if (too_long) {
     atomicOr(overflow, 1u);
     if (big) { big[a] = 1; keyo[a] = ka; valo[a] = val[a]; }
     return;
+  }
+  uint32_t r = 0;
+  for (int j = ls; j < ls + K && lgrp[j] == g; j++) {
+    const uint32_t kj = lkey[j];
+    r += (kj < ka || (kj == ka && j < la)) ? 1u : 0u;
   }
   if (big) big[a] = 0;
   const uint64_t s0 = a - (uint64_t)(la - ls);
@@ -1045,7 +1044,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       static const uint32_t seg_min_avg = []() { const char *e = getenv("PFP_SEG_MINAVG"); return e ? (uint32_t)atoi(e) : 24u; }();
       static const bool use_small = getenv("PFP_NO_SMALLSEG") == nullptr;
       // families of a handful of members: placed directly (after a group proved too long, only once the average is tiny)
-      small = use_segsort && use_small && m / ngrp <= kSmallSeg / 4 && (!small_failed || m / ngrp <= 3);
+      // (32-bit build: long families go to the side sort, so the average may be larger)
+      small = use_segsort && use_small && m / ngrp <= (kWide ? kSmallSeg / 4 : kSmallSeg / 2) && (!small_failed || m / ngrp <= 3);
       auto try_seg = [&]() {
         if (use_segsort && m >= (1u << 20) && m < 0xFFFFFFFFull && m / ngrp >= seg_min_avg) {
           uint32_t maxlen = 0;
@@ -1087,7 +1087,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     dbl_round = true;
     if constexpr (!kWide) {
       static const bool use_small = getenv("PFP_NO_SMALLSEG") == nullptr;
-      if (use_segsort && use_small && ngrp && m / ngrp <= kSmallSeg / 4 && (!small_failed || m / ngrp <= 3)) {
+      if (use_segsort && use_small && ngrp && m / ngrp <= (kWide ? kSmallSeg / 4 : kSmallSeg / 2) && (!small_failed || m / ngrp <= 3)) {
         seg_bufs();
         { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
           hipLaunchKernelGGL(build_keys32_kernel, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
@@ -1153,6 +1153,22 @@ static KeyCode dict_key_code(pfp_ctx *c, const uint8_t *bytes, uint64_t N) {
   return make_key_code(hh.data());
 }
 
+// keys-only first round (see sort_dict_suffixes): index bits of the combined word, 0 = sort (key, position) pairs;
+// shortens kc's key to what is left of 64 bits
+template <class I>
+static int keysonly_bits(uint64_t N, double rep_hint, KeyCode &kc) {
+  static const int keysonly_env = []() { const char *e = getenv("PFP_KEYSONLY"); return e ? atoi(e) : -1; }();
+  if (!(sizeof(I) == 4 && N >= 2 && (keysonly_env == 1 || (keysonly_env != 0 && rep_hint >= 2.0 && N >= (1u << 20))))) return 0;
+  const int ib = bits_for(N - 1);
+  int width = 64 - ib;                      // key bits incl. the terminator flag
+  if (width > 24 && width % 8 <= 2) width -= width % 8;       // a radix pass for one or two bits is a whole pass
+  // (measured: 36 key bits on 129 M suffixes - first sort 7.8 -> 3.9 ms, same rounds after it; 31 key bits on 1.7 G
+  //  suffixes leave three times as many unresolved after the first pivot round - the pair sort stays there)
+  if (!(width - 1 >= 35 || keysonly_env == 1)) return 0;
+  if (kc.kbits > width - 1) { kc.kbits = std::max(8, width - 1); kc.hmin = std::max(1, std::min(32, kc.kbits / kc.maxlen)); }
+  return ib;
+}
+
 template <class I>
 void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *slen, SuffixOrderT<I> &out,
                         const SlotPayloadSrc *pay) {
@@ -1165,19 +1181,7 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   // together.  Then the position fits into the same 64-bit word as a (shorter) key, the sort moves 16 bytes per
   // element and pass instead of 24 and makes 4-5 passes instead of 7, and the merge records in the key's spare bits
   // (which such an input hardly uses: most slots are re-ordered later) are given up.
-  static const int keysonly_env = []() { const char *e = getenv("PFP_KEYSONLY"); return e ? atoi(e) : -1; }();
-  int idx_bits = 0;
-  if (sizeof(I) == 4 && N >= 2 && (keysonly_env == 1 || (keysonly_env != 0 && out.rep_hint >= 2.0 && N >= (1u << 20)))) {
-    const int ib = bits_for(N - 1);
-    int width = 64 - ib;                      // key bits incl. the terminator flag
-    if (width > 24 && width % 8 <= 2) width -= width % 8;       // a radix pass for one or two bits is a whole pass
-    // (measured: 36 key bits on 129 M suffixes - first sort 7.8 -> 3.9 ms, same rounds after it; 31 key bits on 1.7 G
-    //  suffixes leave three times as many unresolved after the first pivot round - the pair sort stays there)
-    if (width - 1 >= 35 || keysonly_env == 1) {
-      if (kc.kbits > width - 1) { kc.kbits = std::max(8, width - 1); kc.hmin = std::max(1, std::min(32, kc.kbits / kc.maxlen)); }
-      idx_bits = ib;
-    }
-  }
+  const int idx_bits = keysonly_bits<I>(N, out.rep_hint, kc);
   DBuf<uint64_t> key(c, N);
   DBuf<I> val;
   if (!idx_bits) val.alloc(c, N);
@@ -1264,7 +1268,7 @@ __global__ __launch_bounds__(256) void sum2_u64_kernel(const unsigned long long 
 template <class I>
 __global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__restrict__ s, uint64_t n, KeyCode kp,
                                                              SlotPayloadSrc P, int paybits, const I *__restrict__ idx,
-                                                             uint64_t *__restrict__ key, I *__restrict__ val) {
+                                                             uint64_t *__restrict__ key, I *__restrict__ val, int idx_bits) {
   __shared__ uint32_t lut[256];
   lut[threadIdx.x] = kp.lut[threadIdx.x];
   __syncthreads();
@@ -1272,6 +1276,7 @@ __global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__re
   if (a >= n) return;
   const I i = idx[a];
   uint64_t k = packed_key_at(s, i, kp.kbits, lut);
+  if (idx_bits) { key[a] = (k << idx_bits) | (uint64_t)i; return; }      // keys-only sort (the list is in position order)
   if (paybits) k |= (uint64_t)slot_record(s, i, P) << 48;
   key[a] = k; val[a] = i;
 }
@@ -1283,7 +1288,8 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
               sizeof(I) == 8 ? "dictionary of 2^40 bytes or more" : "dictionary too large for 32-bit suffix indices");
   PFP_REQUIRE(parts >= 1 && part < parts, PFP_EINVAL, "bad key-range share");
   SufGeom g{MODE_DICT, N, slen};
-  const KeyCode kc = dict_key_code(c, bytes, N);
+  KeyCode kc = dict_key_code(c, bytes, N);
+  const int idx_bits = keysonly_bits<I>(N, out.rep_hint, kc);      // (before the splitters: every rank cuts the same keys)
   // splitters: every stride-th suffix's key, sorted; the same on every rank
   uint64_t klo = 0, khi = ~0ull;
   if (parts > 1) {
@@ -1322,21 +1328,22 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   const uint64_t range_emits = c->h_scalars[2];
   flag.release();
   DBuf<uint64_t> key(c, std::max<uint64_t>(n_mine, 1));
-  DBuf<I> val(c, std::max<uint64_t>(n_mine, 1));
+  DBuf<I> val;
+  if (!idx_bits) val.alloc(c, std::max<uint64_t>(n_mine, 1));
   static const bool no_payload = getenv("PFP_NO_PAYLOAD") != nullptr;
-  out.paybits = (pay && !no_payload && kc.kbits + 1 <= 48) ? 16 : 0;
+  out.paybits = (pay && !no_payload && !idx_bits && kc.kbits + 1 <= 48) ? 16 : 0;
   out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
   if (n_mine) {
     KScope ks(c, "pfp::init_keys_packed_kernel", (uint64_t)n_mine * 17);
     hipLaunchKernelGGL(init_keys_list_kernel<I>, gdim(cdiv(n_mine, 256)), gdim(256), 0, c->stream, bytes, (uint64_t)n_mine, kc,
-                       pay ? *pay : SlotPayloadSrc{}, out.paybits, idx.p, key.p, val.p);
+                       pay ? *pay : SlotPayloadSrc{}, out.paybits, idx.p, key.p, val.p, idx_bits);
   }
   idx.release();
   out.lut.alloc(c, 256);
   PFP_HIP(hipMemcpyAsync(out.lut.p, kc.lut, 1024, hipMemcpyHostToDevice, c->stream));
   sync(c);      // kc is a stack object
   out.bytes = bytes; out.kbits = kc.kbits;
-  doubling<I>(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true, (uint64_t)n_mine);
+  doubling<I>(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true, (uint64_t)n_mine, idx_bits);
   out.slot_base = slot_base; out.klo = klo; out.khi = khi_open ? ~0ull : khi; out.range_emits = range_emits;
 }
 template void sort_dict_suffixes_range<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, uint32_t, uint32_t,

@@ -1,0 +1,10 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/r2ad_tests.log 2>&1; echo "tests rc=$?"; tail -1 gpurun_out/r2ad_tests.log
+for V in "X=1" "PFP_NO_BIGSIDE=1"; do
+  env $V timeout -k 10 400 python bench.py --steps 3 --warmup 1 --workload huge --no-cpu-baseline --no-host-boundary > gpurun_out/r2ad_huge.log 2>&1
+  echo "rc=$? $V"
+  python3 tools/benchsum.py gpurun_out/r2ad_huge.log | sed -n 1,1p | cut -c1-300
+  python3 tools/benchsum.py gpurun_out/r2ad_huge.log | grep -E "seg_small|segmented|radix_sort_pairs<u64,u32>"
+done
+timeout -k 10 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-boundary > gpurun_out/r2ad_c3.log 2>&1; python3 tools/benchsum.py gpurun_out/r2ad_c3.log | sed -n 1,1p | cut -c1-300
