@@ -89,7 +89,7 @@ static void balanced_code(const std::vector<uint64_t> &w, int lo, int hi, uint32
   balanced_code(w, lo, cut, code << 1, len + 1, codes, lens);
   balanced_code(w, cut, hi, (code << 1) | 1u, len + 1, codes, lens);
 }
-static KeyCode make_key_code(const uint64_t hist[256]) {
+static KeyCode make_key_code(const uint64_t hist[256], double rep_hint = 0) {
   KeyCode kc{};
   std::vector<int> sym;
   for (int b2 = 0; b2 < 256; b2++) if (hist[b2] || b2 <= 1) sym.push_back(b2);       // 0x00 / 0x01 always coded
@@ -123,7 +123,8 @@ static KeyCode make_key_code(const uint64_t hist[256]) {
     const double pr = (double)hist[sym[k]] / (double)total;
     H -= pr * std::log2(pr); Lm += pr * lens[k];
   }
-  const double need = std::log2((double)std::max<uint64_t>(total, 2)) + 6.0;
+  // (a repetitive collection's dictionary holds about total / rep distinct contexts: the rest are family members no key width separates)
+  const double need = std::log2(std::max((double)total / std::max(rep_hint, 1.0), 2.0)) + 6.0;
   kc.kbits = 63;
   for (int kb : {39, 47, 55}) if (Lm > 0 && kb * H / Lm >= need) { kc.kbits = kb; break; }
   { const char *e = getenv("PFP_KEYBITS"); if (e) kc.kbits = std::max(8, std::min(63, atoi(e))); }
@@ -1142,7 +1143,7 @@ void gather_ranks(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, 
 template void gather_ranks<uint32_t>(pfp_ctx *, const SuffixOrderT<uint32_t> &, const uint64_t *, uint64_t, uint32_t *);
 template void gather_ranks<uint64_t>(pfp_ctx *, const SuffixOrderT<uint64_t> &, const uint64_t *, uint64_t, uint64_t *);
 
-static KeyCode dict_key_code(pfp_ctx *c, const uint8_t *bytes, uint64_t N) {
+static KeyCode dict_key_code(pfp_ctx *c, const uint8_t *bytes, uint64_t N, double rep_hint = 0) {
   DBuf<unsigned long long> hist(c, 256);
   hist.zero();
   hipLaunchKernelGGL(byte_histogram_kernel, gdim(std::min<uint64_t>(cdiv64(N, 4096), (uint64_t)c->n_cu * 8)), gdim(256), 0,
@@ -1150,7 +1151,7 @@ static KeyCode dict_key_code(pfp_ctx *c, const uint8_t *bytes, uint64_t N) {
   std::vector<uint64_t> hh(256);
   PFP_HIP(hipMemcpyAsync(hh.data(), hist.p, 2048, hipMemcpyDeviceToHost, c->stream));
   sync(c);
-  return make_key_code(hh.data());
+  return make_key_code(hh.data(), rep_hint);
 }
 
 // keys-only first round (see sort_dict_suffixes): index bits of the combined word, 0 = sort (key, position) pairs;
@@ -1175,7 +1176,7 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   PFP_REQUIRE(N >= 1 && (sizeof(I) == 8 ? N < (1ull << 40) : N < 0xFFFFFFF0ull), PFP_ELIMIT,
               sizeof(I) == 8 ? "dictionary of 2^40 bytes or more" : "dictionary too large for 32-bit suffix indices");
   SufGeom g{MODE_DICT, N, slen};
-  KeyCode kc = dict_key_code(c, bytes, N);
+  KeyCode kc = dict_key_code(c, bytes, N, out.rep_hint);
   // Keys-only first round.  A dictionary of a repetitive collection (text / dictionary >= 2) is mostly families of
   // variants that no first-round key separates, whatever its width: the first round only has to bring the families
   // together.  Then the position fits into the same 64-bit word as a (shorter) key, the sort moves 16 bytes per
@@ -1288,7 +1289,7 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
               sizeof(I) == 8 ? "dictionary of 2^40 bytes or more" : "dictionary too large for 32-bit suffix indices");
   PFP_REQUIRE(parts >= 1 && part < parts, PFP_EINVAL, "bad key-range share");
   SufGeom g{MODE_DICT, N, slen};
-  KeyCode kc = dict_key_code(c, bytes, N);
+  KeyCode kc = dict_key_code(c, bytes, N, out.rep_hint);
   const int idx_bits = keysonly_bits<I>(N, out.rep_hint, kc);      // (before the splitters: every rank cuts the same keys)
   // splitters: every stride-th suffix's key, sorted; the same on every rank
   uint64_t klo = 0, khi = ~0ull;
