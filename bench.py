@@ -300,8 +300,10 @@ def main():
                 ok = pr.returncode == 0 and os.path.getsize(fn + ".bwt") == n + 1
                 if ok and digests is not None:
                     ok = hashlib.sha256(open(fn + ".bwt", "rb").read()).hexdigest() == gold["bwt_sha256"]
+                trace = [ln for ln in pr.stderr.splitlines() if "file to files" in ln]      # PFP_TRACE_HOST=1: where the time goes
                 cli = dict(MBps_process=round(n / cli_s / 1e6, 1), seconds_process=round(cli_s, 3),
                            seconds_construction=float(inner[0].split(":")[1]) if inner else None, outputs_ok=bool(ok),
+                           **({"trace": trace[-1]} if trace else {}),
                            note="bigbwt (C driver) on a file in /dev/shm: mmap -> chunked pinned H2D -> chain -> outputs streamed from HBM into the files")
             finally:
                 import shutil

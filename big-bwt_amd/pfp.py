@@ -130,6 +130,18 @@ def _take(ptr, n, dtype):
     return np.ctypeslib.as_array(ptr, shape=(int(n),)).astype(dtype, copy=True)
 
 
+def _adopt(lib, ptr, n):
+    """a malloc'ed result buffer of the library as a numpy array WITHOUT copying it (a copy of a 0.8 GB .bwt costs more
+    than its trip across PCIe); the buffer is handed to pfp_free when the array is collected"""
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=np.uint8)
+    import weakref
+    addr = C.cast(ptr, C.c_void_p).value
+    arr = np.ctypeslib.as_array(ptr, shape=(int(n),))
+    weakref.finalize(arr, lib.pfp_free, C.c_void_p(addr))
+    return arr
+
+
 def unpack5(b):
     """5-byte little-endian ints (utils.c:112-129) -> u64 array"""
     b = np.frombuffer(bytes(b), dtype=np.uint8).reshape(-1, 5)
@@ -313,9 +325,8 @@ class Context:
         return ilist, bwlast, bwsai
 
     def _bwt_result(self, r):
-        out = dict(bwt=_take(r.bwt, r.bwt_size, np.uint8), sa=_take(r.sa, r.sa_bytes, np.uint8),
-                   ssa=_take(r.ssa, r.ssa_bytes, np.uint8), esa=_take(r.esa, r.esa_bytes, np.uint8))
-        self.lib.pfp_bwt_result_free(C.byref(r))
+        out = dict(bwt=_adopt(self.lib, r.bwt, r.bwt_size), sa=_adopt(self.lib, r.sa, r.sa_bytes),
+                   ssa=_adopt(self.lib, r.ssa, r.ssa_bytes), esa=_adopt(self.lib, r.esa, r.esa_bytes))
         return out
 
     # -- stage 3: pfbwt.cpp main
