@@ -327,9 +327,9 @@ def main():
                        "phrases": st["n_phrases"], "words": st["n_words"], "dict_bytes": st["dict_size"],
                        "outputs_in_timed_step": ["bwt"] + [k for k in ("sa", "ssa", "esa") if k in outbuf or (collection and ("sa5" if k == "sa" else k) in last.get("r", {}))],
                        "parallelism": ("1 GPU" if world == 1 else
-                                       (f"{world} shards of one collection: halo + allgatherv of dictionaries and parse over RCCL, "
-                                        f"suffix array of the global dictionary sharded by key range, every rank emits the BWT "
-                                        f"range its share of SA(D) produces") if collection else
+                                       (f"{world} shards of one collection over RCCL: halo allgather, hash-partitioned all-to-all phrase dedup, "
+                                        f"allgatherv of the distinct words and of the parse, suffix array of the global dictionary sharded "
+                                        f"by key range, every rank emits (and samples / packs) the BWT range its share of SA(D) produces") if collection else
                                        f"{world} independent texts (one per GPU), no collective")},
             "roofline": roofline,
             "roofline_passes": passes,
