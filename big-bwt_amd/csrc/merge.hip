@@ -1475,7 +1475,8 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   uint32_t nh = 0;
   auto run_expand = [&]() {
     { KScope ks(c, "pfp::expand_kernel", a.pass == PASS_SA ? N * 5 + pb.P * 28 : N * 14 + n_out * (dense ? 17 : 1));
-      if (sparse) hipLaunchKernelGGL((expand_kernel<I, 1>), gdim(nblk), gdim(256), 0, c->stream, a, heavy.p, nheavy.p, nblk);
+      // (the whole-word list of the sparse SA round costs 12 KB of LDS: only that round's launch carries it)
+      if (sparse && (a.pass & PASS_SA)) hipLaunchKernelGGL((expand_kernel<I, 1>), gdim(nblk), gdim(256), 0, c->stream, a, heavy.p, nheavy.p, nblk);
       else hipLaunchKernelGGL((expand_kernel<I, 0>), gdim(nblk), gdim(256), 0, c->stream, a, heavy.p, nheavy.p, nblk); }
     if (a.pass & PASS_BWT) nh = read_scalar(c, nheavy.p);
     KScope ks2(c, "pfp::expand_heavy_kernel", 0);   // bytes are accounted in expand_kernel's n_out term
