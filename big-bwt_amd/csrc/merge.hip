@@ -456,7 +456,9 @@ __device__ __forceinline__ uint32_t slot_ist(const MergeArgsT<I> &a, uint64_t t)
 //                     by BWT(P) position - own index + lower_bound in every other member's
 //                     inverted list - and written to that slot of the group's range: the
 //                     data-parallel form of the reference's heap merge (pfbwt.cpp:537-556).
-constexpr int kHardLds = 1024;   // occurrences of one batch ranked in LDS
+constexpr int kHardLds = 1024;   // occurrences of a group one wave sorts in LDS (hard_sort_kernel)
+constexpr int kHardRank = 512;   // occurrences of one batch ranked in LDS (hard_groups_kernel): larger groups are sorted anyway,
+                                 // and 7.6 KB of tables per wave instead of 10 let five workgroups share a CU instead of three
 constexpr int kHardMem = 256;    // members of one batch
 constexpr int kHardSortMin = 512;   // a group with more occurrences than this (and <= kHardLds) is sorted, not ranked all-pairs
 constexpr int kSlots = 2048;
@@ -1034,8 +1036,8 @@ __global__ void hard_minor_sa_kernel(MergeArgsT<I> a, const MinorRec *__restrict
 // hard_big_kernel.  (One group at a time per wave took 7.7 us per group, 22 ms at 8.8 M groups.)
 struct BigGroup { uint64_t g; uint64_t E; uint32_t k; uint32_t pad; };
 struct HardLds {
-  uint32_t lpos[kHardLds];
-  uint8_t lq[kHardLds];
+  uint32_t lpos[kHardRank];
+  uint8_t lq[kHardRank];
   uint32_t lmoff[kHardMem + 1], lmist[kHardMem], lmsl[kHardMem];
   uint8_t lmch[kHardMem], lmg[kHardMem];
   uint64_t gbase[64], ghead[64];
@@ -1079,7 +1081,7 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgsT<I> a, const
       if (kk && !(base + Eg <= a.out_lo || base >= a.out_hi)) {      // inside this rank's slice
         my_chars += Eg; my_groups += 1;
         const bool sorted_path = a.dbg_mode ? a.dbg_mode == 3 : Eg > (uint64_t)kHardSortMin;
-        if (Eg <= (uint64_t)kHardLds && kk <= (uint32_t)kHardMem && !sorted_path) { live = true; k = kk; E = (uint32_t)Eg; }
+        if (Eg <= (uint64_t)kHardRank && kk <= (uint32_t)kHardMem && !sorted_path) { live = true; k = kk; E = (uint32_t)Eg; }
         else if (Eg <= (uint64_t)kHardLds && sorted_path) {      // one wave sorts it in LDS: hard_sort_kernel
           const unsigned long long idx = atomicAdd(&stats[3], 1ull);
           if (idx < mid_cap) mid[idx] = BigGroup{g, Eg, kk, 0};
@@ -1099,7 +1101,7 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgsT<I> a, const
         const uint32_t vk = __shfl_up(pk, o, 64), vE = __shfl_up(pE, o, 64);
         if (lane >= o) { pk += vk; pE += vE; }
       }
-      const bool fit = mine && pk <= (uint32_t)kHardMem && pE <= (uint32_t)kHardLds;
+      const bool fit = mine && pk <= (uint32_t)kHardMem && pE <= (uint32_t)kHardRank;
       const unsigned long long take = __ballot(fit);       // never empty: a single live group fits
       todo &= ~take;
       const int nG = __popcll(take);
