@@ -213,6 +213,39 @@ def test_large_hard_groups_without_a_dominating_char(O, pkg, wctx, monkeypatch, 
             assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
 
 
+def test_steady_state_calls_do_not_reach_the_driver(O, pkg):
+    """the context's pool: a repeated call of the same size is served from cached blocks (no hipMalloc, no trim),
+    and the device-format buffers handed out go back into the pool with pfp_dev_free"""
+    import torch
+    text = O.gen_fasta(300000, 6, 0.002, 23)
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(text).to(dev)
+    bwt = torch.empty(len(text) + 1 + 16, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    c = pkg.Context(0)
+    try:
+        flags = pkg.FLAG_SSA | pkg.FLAG_ESA
+        def call():
+            used, outs = c.bigbwt_formats_dev(t.data_ptr(), len(text), bwt.data_ptr(), 10, 100, flags)
+            got = {k: c.fetch_dev(ptr, nb) for k, (ptr, nb) in outs.items()}
+            for ptr, _ in outs.values():
+                c.dev_free(ptr)
+            return used, got
+        used, first = call()
+        call()
+        before = c.pool_counters()
+        used2, again = call()
+        after = c.pool_counters()
+        assert after == before, (before, after)
+        assert used == used2 == len(text) and all(np.array_equal(first[k], again[k]) for k in first)
+        want = O.bigbwt(text, 10, 100, O.FLAG_SSA | O.FLAG_ESA)
+        assert np.array_equal(bwt[: len(text) + 1].cpu().numpy(), want["bwt"])
+        assert np.array_equal(pkg.unpack5(again["ssa"]).reshape(-1, 2), want["ssa"])
+        assert np.array_equal(pkg.unpack5(again["esa"]).reshape(-1, 2), want["esa"])
+    finally:
+        c.close()
+
+
 def _check_bwt_sa_properties(text, bwt, sa_vals, rng):
     n = len(text)
     assert len(bwt) == n + 1
