@@ -29,6 +29,7 @@ enum : int { MODE_DICT = 0, MODE_PLAIN = 1 };
 
 struct SufGeom {
   int mode; uint64_t N; const uint32_t *slen;   // slen[i] = distance from i to the terminator of i's word
+  const uint32_t *sym = nullptr;                // plain mode on an integer string (unique smallest last symbol): the string
 };
 // length of the suffix string starting at i, terminator included
 __device__ __forceinline__ uint64_t suf_len(const SufGeom &g, uint64_t i) {
@@ -752,6 +753,74 @@ __global__ void repair_ranks_kernel(uint64_t N, const uint8_t *__restrict__ refi
   if (t < N && refined[t] && !active[t]) rank[sa[t]] = grp[t] | finbit;
 }
 
+// The last few thousand suffixes.  A round costs a dozen launches and three host round trips however little is left,
+// and the tail of a sort is many such rounds (-p 200: ten rounds for the last 40 K of 63 M suffixes).  Once at most
+// kFinishMax suffixes are unresolved - in groups of at most kFinishGrp - every one of them is ranked inside its group by
+// comparing the strings themselves (terminated words, or the integer string up to the first difference): lt = members
+// that sort before it, eq = identical members before it in the list; nothing is written until no comparison ran past
+// kFinishCmp bytes and no group was too long, so a refusal leaves the round machinery where it was.
+constexpr uint64_t kFinishMax = 1u << 17;
+constexpr int kFinishGrp = 64;
+constexpr uint32_t kFinishCmp = 8192;
+__device__ __forceinline__ int finish_cmp_dict(const uint8_t *__restrict__ s, uint64_t i, uint64_t j, uint32_t *ovf) {
+  for (uint32_t k = 0; k < kFinishCmp; k += 8) {
+    const uint64_t x = ld8u(s + i + k), y = ld8u(s + j + k);
+    const uint64_t tb = (x - 0x0202020202020202ull) & ~x & 0x8080808080808080ull;   // bytes < 2 of x; lowest flag exact
+    if (x == y) { if (tb) return 0; continue; }
+    const int fd = __builtin_ctzll(x ^ y) >> 3;
+    const int ft = tb ? (__builtin_ctzll(tb) >> 3) : 8;
+    if (ft < fd) return 0;       // both end before they differ
+    const uint32_t bx = (uint32_t)(x >> (8 * fd)) & 0xffu, by = (uint32_t)(y >> (8 * fd)) & 0xffu;
+    return bx < by ? -1 : 1;
+  }
+  *ovf = 1;
+  return 0;
+}
+__device__ __forceinline__ int finish_cmp_int(const uint32_t *__restrict__ sym, uint64_t i, uint64_t j, uint32_t *ovf) {
+  for (uint32_t k = 0; k < kFinishCmp / 4; k++) {      // (the sentinel ends the shorter suffix with a difference)
+    const uint32_t x = sym[i + k], y = sym[j + k];
+    if (x != y) return x < y ? -1 : 1;
+  }
+  *ovf = 1;
+  return 0;
+}
+template <class I>
+__global__ void finish_rank_kernel(SufGeom g, const uint8_t *__restrict__ s, uint64_t m, const I *__restrict__ act_i,
+                                   const I *__restrict__ act_grp, uint32_t *__restrict__ lt, uint32_t *__restrict__ eq,
+                                   uint32_t *__restrict__ gstart, uint32_t *__restrict__ overflow) {
+  const uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  const I grp = act_grp[a];
+  uint64_t gs = a, ge = a + 1;
+  while (gs > 0 && a - gs < (uint64_t)kFinishGrp && act_grp[gs - 1] == grp) gs--;
+  while (ge < m && ge - gs <= (uint64_t)kFinishGrp && act_grp[ge] == grp) ge++;
+  if (ge - gs > (uint64_t)kFinishGrp || (gs > 0 && act_grp[gs - 1] == grp)) { atomicOr(overflow, 1u); return; }
+  const uint64_t ia = act_i[a];
+  uint32_t nlt = 0, neq = 0, ovf = 0;
+  for (uint64_t b = gs; b < ge; b++) {
+    if (b == a) continue;
+    if (*(volatile uint32_t *)overflow) return;      // somebody met a case for the rounds: no point in finishing the comparisons
+    const uint64_t ib = act_i[b];
+    const int cmp = g.mode == MODE_DICT ? finish_cmp_dict(s, ib, ia, &ovf) : finish_cmp_int(g.sym, ib, ia, &ovf);
+    if (cmp < 0) nlt++;
+    else if (cmp == 0 && b < a) neq++;
+  }
+  if (ovf) atomicOr(overflow, 1u);
+  lt[a] = nlt; eq[a] = neq; gstart[a] = (uint32_t)gs;
+}
+template <class I>
+__global__ void finish_write_kernel(uint64_t m, const I *__restrict__ aslot, const I *__restrict__ act_i, const uint32_t *__restrict__ lt,
+                                    const uint32_t *__restrict__ eq, const uint32_t *__restrict__ gstart, I finbit,
+                                    I *__restrict__ sa, I *__restrict__ grp, I *__restrict__ rank) {
+  const uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  const uint64_t gs = gstart[a];
+  const I i = act_i[a], slot = aslot[gs + lt[a] + eq[a]], head = aslot[gs + lt[a]];
+  sa[slot] = i;
+  grp[slot] = head;            // identical strings share their group's first slot
+  rank[i] = head | finbit;
+}
+
 // after the first round, pivot rounds are tried while the groups are families (average size up to
 // kPivotAvg) and each one at least halves the unresolved set; at most kPivotCap bytes per comparison
 static const uint32_t kPivotAvg = []() { const char *e = getenv("PFP_PIVOT_AVG"); return e ? (uint32_t)atoll(e) : 1024u; }();
@@ -901,6 +970,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   uint32_t piv_cap = kPivotCap;  // bytes compared per member in the next pivot round
   bool long_cap_tried = false;
   bool small_failed = false;     // a direct-placement attempt met a group longer than its window
+  bool finisher_ok = true;       // the comparison finisher has not refused yet
   for (;;) {
     DBuf<I> tile_last, tile_scan;      // first round of dictionary mode: last head per 256 slots, and its running maximum
     if (first && lazy) {
@@ -1014,10 +1084,13 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
               (unsigned long long)out.rounds, (unsigned long long)h, (unsigned long long)m, (unsigned long long)m2,
               (unsigned long long)ngrp, seg_round ? " (seg)" : (pivot_round ? " (pivot)" : ""));
     // a pivot round that did not at least halve the unresolved set: what is left are members equal to
-    // their pivot for the whole comparison window.  While they are few, one more round with the longest
-    // window settles the long phrases' variants; after that the rest is doubling's business.
+    // their pivot for the whole comparison window.  The window then grows fourfold (512 -> 2 K -> 8 K bytes) as long
+    // as the bytes such a round may read - every member the full window - stay below 256 per dictionary byte; the
+    // variants of long phrases settle there (-p 200: 3.3 M suffixes went through nine doubling rounds instead).
+    // After the widest window the rest is doubling's business.
     if (pivot_round && m2 * 2 > m) {
-      if (!long_cap_tried && m2 * 64 < N) { long_cap_tried = true; piv_cap = kPivCapMax - 16; }
+      const uint32_t next_cap = std::min<uint32_t>(piv_cap * 4, kPivCapMax - 16);
+      if (piv_cap < kPivCapMax - 16 && piv_cap >= 16 && m2 * (uint64_t)next_cap < N * 128) { long_cap_tried = true; piv_cap = next_cap; }
       else pivot_ok = false;
     }
     std::swap(aslot, aslot2);
@@ -1028,6 +1101,25 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     if (!key.p || key.n < m) key.alloc(c, m);
     if (!valo.p || valo.n < m) valo.alloc(c, m);
     if (!val.p || val.n < m) val.alloc(c, m);
+    static const bool use_finisher = getenv("PFP_NO_FINISHER") == nullptr;
+    if (use_finisher && finisher_ok && m <= kFinishMax && out.rounds >= 1 && (g.mode == MODE_DICT || (g.mode == MODE_PLAIN && g.sym))) {
+      DBuf<uint32_t> flt(c, m), feq(c, m), fgs(c, m), fov(c, 1);
+      fov.zero();
+      KScope ks(c, "pfp::finish_kernels", m * (sizeof(I) * 4 + 12));
+      hipLaunchKernelGGL(finish_rank_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, out.bytes, m, act_i.p, act_grp.p, flt.p, feq.p,
+                         fgs.p, fov.p);
+      if (read_scalar(c, fov.p) == 0) {
+        hipLaunchKernelGGL(finish_write_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, aslot.p, act_i.p, flt.p, feq.p, fgs.p,
+                           out.finbit, out.sa.p, out.grp.p, out.rank.p);
+        PFP_HIP(hipGetLastError());
+        if (trace_rounds) fprintf(stderr, "[pfp] doubling N=%llu round=%llu: the last %llu suffixes ranked by comparison\n",
+                                  (unsigned long long)N, (unsigned long long)out.rounds, (unsigned long long)m);
+        out.rounds++;
+        m = 0;
+        break;
+      }
+      finisher_ok = false;      // a long group or a long common prefix: the rounds go on as they would have
+    }
     // Rounds after the first: the unresolved suffixes are already grouped, only the 32-bit "next"
     // key has to be ordered inside every group.  When the groups are many and of moderate size (a
     // dictionary of near-identical variants) a segmented sort moves 16 B per suffix instead of the
@@ -1397,6 +1489,7 @@ void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder 
   const uint32_t real_max = read_scalar(c, mx.p);
   PFP_REQUIRE(real_max <= max_sym, PFP_EFORMAT, "integer string holds a symbol above its alphabet size");
   const int sb = bits_for(real_max);
+  g.sym = sym;
   static const bool no_runkeys = getenv("PFP_NO_RUNKEYS") != nullptr;
   if (64 - 2 * sb >= 6 && !no_runkeys) {
     DBuf<uint32_t> v(c, N), pm(c, N);
