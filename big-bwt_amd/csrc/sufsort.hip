@@ -669,6 +669,11 @@ __global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t 
   if (!key32 || both) key[a] = ((uint64_t)grp << kPivBits) | ok;
   val[a] = i | settled;
 }
+template <class I>
+__global__ void veto_clear_kernel(uint64_t m, const I *__restrict__ newhead, uint8_t *__restrict__ veto) {
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (a < m) veto[newhead[a]] = 0;
+}
 // a member of P's class without the settled bit (equal to P for cap bytes, unknown beyond): nobody in
 // that class may settle this round
 template <class I>
@@ -1004,7 +1009,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     } else {
       if (pivot_round) {
         if (!veto.p) veto.alloc(c, N);
-        veto.zero();
+        // only the entries of this round's groups are looked at: clear those (m bytes at most), not all N
+        hipLaunchKernelGGL(veto_clear_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, newhead.p, veto.p);
         hipLaunchKernelGGL(pivot_veto_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, keyo.p,
                            seg_round ? k32o.p : (const uint32_t *)nullptr, valo.p, newhead.p, out.finbit, veto.p);
       }
