@@ -15,6 +15,8 @@ run r2z_bench_c3 500 python bench.py
 run r2z_bench_c2 400 python bench.py --steps 5 --warmup 2 --workload c2 --no-cpu-baseline
 run r2z_bench_huge 500 python bench.py --steps 3 --warmup 1 --workload huge --no-cpu-baseline
 run r2z_bench_huge_s 500 python bench.py --steps 3 --warmup 1 --workload huge_s --no-cpu-baseline
+run r2z_bench_c4s 300 python bench.py --steps 5 --warmup 2 --workload c4s --no-cpu-baseline
+run r2z_bench_c5s 300 python bench.py --steps 5 --warmup 2 --workload c5s --no-cpu-baseline
 export TMPDIR=/tmp
 D=$PWD/gpurun_out/r2z_prof
 rm -rf $D; mkdir -p $D
