@@ -973,7 +973,6 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   DBuf<uint32_t> tile_keep, tile_heads;
   DBuf<I> tile_off, tile_hoff;
   uint32_t piv_cap = kPivotCap;  // bytes compared per member in the next pivot round
-  bool long_cap_tried = false;
   bool small_failed = false;     // a direct-placement attempt met a group longer than its window
   bool finisher_ok = true;       // the comparison finisher has not refused yet
   for (;;) {
@@ -1096,7 +1095,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     // After the widest window the rest is doubling's business.
     if (pivot_round && m2 * 2 > m) {
       const uint32_t next_cap = std::min<uint32_t>(piv_cap * 4, kPivCapMax - 16);
-      if (piv_cap < kPivCapMax - 16 && piv_cap >= 16 && m2 * (uint64_t)next_cap < N * 128) { long_cap_tried = true; piv_cap = next_cap; }
+      if (piv_cap < kPivCapMax - 16 && piv_cap >= 16 && m2 * (uint64_t)next_cap < N * 128) piv_cap = next_cap;
       else pivot_ok = false;
     }
     std::swap(aslot, aslot2);
