@@ -63,6 +63,11 @@ template <class K>
 void sort_keys_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, size_t n, int bb, int eb) {
   if (!n) return;
   PFP_REQUIRE(k.n >= n && kalt.n >= n, PFP_EINVAL, "sort_keys_db: a buffer is shorter than n");
+  // rocPRIM sorts up to 2^20 elements by merging, with a comparator whose mask is (1 << end_bit) - 1: a shift by the
+  // key's whole width when end_bit == 64 - undefined, and in practice a mask of the bits BELOW begin_bit only
+  // (found by fuzzing the keys-only suffix sort on small dictionaries).  The caller's low bits are a unique,
+  // ascending index, so sorting the whole word gives the same order: do that where the merge path can be taken.
+  if (bb > 0 && eb == (int)(8 * sizeof(K)) && n <= (size_t(1) << 21)) bb = 0;
   const uint64_t passes = (uint64_t)(eb - bb + 7) / 8;
   KScope ks(c, "rocprim::radix_sort_keys<u64>", n * sizeof(K) + passes * n * 2 * sizeof(K));
   rocprim::double_buffer<K> dk(k.p, kalt.p);

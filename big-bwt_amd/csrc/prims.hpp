@@ -18,7 +18,8 @@ inline void sort_pairs_u32_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, 
 // Both pairs must hold at least n elements.
 template <class K, class V>
 void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &valt, size_t n, int begin_bit, int end_bit);
-// keys only, ping-ponging between k and kalt (swapped when the last pass ended in the alternate)
+// keys only, ping-ponging between k and kalt (swapped when the last pass ended in the alternate).  The bits below
+// begin_bit must be a unique index that ascends with the input order (small inputs are sorted on the whole word)
 template <class K>
 void sort_keys_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, size_t n, int begin_bit, int end_bit);
 // stable radix sort inside each segment [begin[k], end[k]) (one already-grouped array, n < 2^32)

@@ -1255,7 +1255,7 @@ static KeyCode dict_key_code(pfp_ctx *c, const uint8_t *bytes, uint64_t N, doubl
 // shortens kc's key to what is left of 64 bits
 template <class I>
 static int keysonly_bits(uint64_t N, double rep_hint, KeyCode &kc) {
-  static const int keysonly_env = []() { const char *e = getenv("PFP_KEYSONLY"); return e ? atoi(e) : -1; }();
+  const int keysonly_env = []() { const char *e = getenv("PFP_KEYSONLY"); return e ? atoi(e) : -1; }();      // (per call: tests switch it)
   if (!(sizeof(I) == 4 && N >= 2 && (keysonly_env == 1 || (keysonly_env != 0 && rep_hint >= 2.0 && N >= (1u << 20))))) return 0;
   const int ib = bits_for(N - 1);
   int width = 64 - ib;                      // key bits incl. the terminator flag

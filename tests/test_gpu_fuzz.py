@@ -118,3 +118,32 @@ def test_structured_random_inputs_match_oracle(pkg, O, wctx, seed):
     finally:
         ctx.set_max_phrase(32768)
     assert done >= 40 and dist_done >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["keysonly_sa_536", "keysonly_sa_164", "keysonly_686"])
+def test_keys_only_first_round_on_small_dictionaries(pkg, O, ctx, monkeypatch, case):
+    """Inputs the fuzz drivers found (tools/fuzz.py, tools/fuzz_sa.py with PFP_KEYSONLY=1): near-constant periodic
+    texts whose first-round keys fill the word up to bit 64.  rocPRIM sorts up to 2^20 elements by merging with a
+    comparator mask of (1 << end_bit) - 1, i.e. a shift by 64 there, and ordered the words by their index bits; the
+    library now sorts the whole word for small inputs (prims.hip sort_keys_db)."""
+    import os
+    t = np.load(os.path.join(os.path.dirname(__file__), "golden", "fuzzcases", case + ".npy"))
+    monkeypatch.setenv("PFP_KEYSONLY", "1")
+    checked = 0
+    for w, p in ((4, 10), (10, 10), (10, 20), (10, 100)):
+        try:
+            pr = O.parse(t, w, p)
+        except Exception:
+            continue
+        a = ctx.gsacak(pr["dict"])
+        b, _ = O.gsacak(pr["dict"], want_lcp=False)
+        assert np.array_equal(a, b), (w, p)
+        try:
+            want = O.bigbwt(t, w, p, O.FLAG_SA)
+        except RuntimeError:
+            continue
+        got = ctx.bigbwt(t, w, p, pkg.FLAG_SA)
+        assert np.array_equal(got["bwt"], want["bwt"]) and np.array_equal(pkg.unpack5(got["sa"]), want["sa"]), (w, p)
+        checked += 1
+    assert checked
