@@ -43,6 +43,7 @@ for it in range(ntr):
     t, kind = gen()
     w = int(rng.choice([4, 5, 10, 17])); p = int(rng.choice([10, 11, 20, 100]))
     flags = int(rng.choice([0, 1, 6]))
+    if it and it % 20 == 0: print("progress it=%d compared=%d bad=%d" % (it, compared, bad), flush=True)
     try:
         want = O.bigbwt(t, w, p, flags)
     except Exception as ex:
