@@ -186,6 +186,7 @@ struct BwtOutputs {
   // prefix counts: the sampled files are then written from the bitmaps alone, without another pass over the BWT bytes
   DBuf<uint64_t> smap, spre, emap, epre;
   uint64_t n_starts = 0, n_ends = 0;
+  uint64_t slice_n = 0;        // positions the maps cover (the emitted slice; a slice's two edge positions count as boundaries)
 };
 // where the SA value of BWT position i (relative to the slice the arrays describe) is found
 struct SaView {
@@ -200,7 +201,7 @@ inline SaView sa_view(const BwtOutputs &o) {
   if (o.sa_c.p) {
     v.bmap = o.bmap.p; v.bpre = o.bpre.p; v.sa_c = o.sa_c.p;
     v.smap = o.smap.p; v.spre = o.spre.p; v.emap = o.emap.p; v.epre = o.epre.p;
-    v.n_starts = o.n_starts; v.n_ends = o.n_ends; v.n_words = (o.n_out + 63) / 64;
+    v.n_starts = o.n_starts; v.n_ends = o.n_ends; v.n_words = ((o.slice_n ? o.slice_n : o.n_out) + 63) / 64;
   } else v.dense = o.d_sa;
   return v;
 }
@@ -216,6 +217,10 @@ void unpack5_dev(pfp_ctx *c, const uint8_t *in5, uint64_t cnt, uint64_t *vals);
 // pairs (pos,sa) packed as 10 bytes each; returns pair count; out buffer allocated inside
 uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const SaView &sa, uint64_t n_out, bool run_end,
                          DBuf<uint8_t> &out10);
+// the same for a slice whose maps a merge left (multi-GPU): pairs of the run starts (ends) at slice position r as
+// <pos_base + r, SA value>; drop_edge: the slice's first (last) position is NOT a run start (end) after all - its
+// neighbour in the adjacent slice carries the same byte.  out10 == nullptr: count only.
+uint64_t sample_runs_maps(pfp_ctx *c, const SaView &sa, uint64_t slice_n, bool run_end, bool drop_edge, uint64_t pos_base, uint8_t *out10);
 // the same in two steps over a slice of the BWT (multi-GPU): count the boundaries, then place the pairs.
 // left / right = the BWT byte just before / after the slice, -1 at the ends of the whole BWT.
 struct RunSampler {

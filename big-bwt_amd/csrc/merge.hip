@@ -820,17 +820,22 @@ __global__ __launch_bounds__(256) void run_bitmap_kernel(const uint8_t *__restri
 // set bit from its rank among all boundaries
 __global__ __launch_bounds__(256) void bitmap_place_kernel(const uint64_t *__restrict__ map, const uint64_t *__restrict__ pre,
                                                            const uint64_t *__restrict__ bmap, const uint64_t *__restrict__ bpre,
-                                                           const uint64_t *__restrict__ sa_c, uint64_t nw, uint8_t *__restrict__ out10) {
+                                                           const uint64_t *__restrict__ sa_c, uint64_t nw, uint8_t *__restrict__ out10,
+                                                           uint64_t pos_base, int drop_first, uint64_t drop_pos) {
   const uint64_t w = (uint64_t)BID * 256 + threadIdx.x;
   if (w >= nw) return;
   uint64_t m = map[w];
+  uint64_t o = pre[w];
+  // a slice's edge that is no boundary after all (multi-GPU): position 0 leaves the list and every later pair moves
+  // up by one; drop_pos (the slice's last position, or ~0) just leaves
+  if (drop_first) { if (w == 0) m &= ~1ull; else o -= 1; }
+  if ((drop_pos >> 6) == w) m &= ~(1ull << (drop_pos & 63));
   if (!m) return;
   const uint64_t all = bmap[w], rb = bpre[w];
-  uint64_t o = pre[w];
   while (m) {
     const int b = __builtin_ctzll(m);
     m &= m - 1;
-    const uint64_t x = w * 64 + b, v = sa_c[rb + (uint64_t)__popcll(all & ((1ull << b) - 1ull))];
+    const uint64_t x = pos_base + w * 64 + b, v = sa_c[rb + (uint64_t)__popcll(all & ((1ull << b) - 1ull))];
     uint8_t *dst = out10 + 10 * o++;
     reinterpret_cast<U64u *>(dst)->v = (x & 0xFFFFFFFFFFull) | (v << 40);       // 5 bytes of x, 3 low bytes of v
     reinterpret_cast<U16u *>(dst + 8)->v = (uint16_t)(v >> 24);                  // bytes 3, 4 of v
@@ -1570,9 +1575,10 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   const uint64_t cnt_slice = a.out_hi > a.out_lo ? a.out_hi - a.out_lo : 0;
   const uint64_t nw = cdiv64(cnt_slice, 64);
   out.bmap.alloc(c, nw + 1); out.bpre.alloc(c, nw + 1);
-  // the emitted slice is the whole BWT and the caller keeps no SA array: the sampled files come from the bitmaps
-  const bool whole = !out.d_sa && a.out_lo == 0 && a.out_hi == n_out && pos_base == 0 && a.n_out_global == n_out;
-  const bool want_s = whole && (flags & PFP_FLAG_SSA), want_e = whole && (flags & PFP_FLAG_ESA);
+  // ... and no SA array to write to: the sampled files come from bitmaps (a slice's two edge positions count as run
+  // starts / ends here; the multi-GPU caller drops them again when the neighbour's halo byte says so)
+  const bool want_s = !out.d_sa && (flags & PFP_FLAG_SSA), want_e = !out.d_sa && (flags & PFP_FLAG_ESA);
+  out.slice_n = cnt_slice;
   {
     DBuf<uint32_t> wcnt(c, nw + 1), scnt, ecnt;
     PFP_HIP(hipMemsetAsync(wcnt.p + nw, 0, 4, c->stream));
@@ -1620,8 +1626,12 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   if (c->debug && a.sa_c) {      // every boundary of the BWT must have received its value
     DBuf<unsigned long long> unset(c, 1);
     unset.zero();
-    if (out.n_bound)
-      hipLaunchKernelGGL(count_unset_kernel, gdim(cdiv(out.n_bound, 256)), gdim(256), 0, c->stream, out.sa_c.p, out.n_bound, unset.p);
+    // (a slice's own two edge positions are marked as boundaries whatever their neighbours in the other slices hold:
+    //  when they lie inside a run of the whole BWT nobody owes them a value - and nobody will sample them)
+    const uint64_t skip_lo = (a.pos_base + a.out_lo > 0) ? 1 : 0, skip_hi = (a.pos_base + a.out_hi < a.n_out_global) ? 1 : 0;
+    if (out.n_bound > skip_lo + skip_hi)
+      hipLaunchKernelGGL(count_unset_kernel, gdim(cdiv(out.n_bound, 256)), gdim(256), 0, c->stream, out.sa_c.p + skip_lo,
+                         out.n_bound - skip_lo - skip_hi, unset.p);
     const uint64_t u = read_scalar(c, (const uint64_t *)unset.p);
     PFP_REQUIRE(u == 0, PFP_EHIP, "sparse SA: " + std::to_string(u) + " run boundaries of the BWT received no SA value");
   }
@@ -1756,7 +1766,7 @@ uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const SaView &sa, uint6
     if (sa.n_words) {
       KScope ks(c, "pfp::run_place_kernel", sa.n_words * 24 + pairs * 18);
       hipLaunchKernelGGL(bitmap_place_kernel, gdim(cdiv(sa.n_words, 256)), gdim(256), 0, c->stream, map, run_end ? sa.epre : sa.spre, sa.bmap,
-                         sa.bpre, sa.sa_c, sa.n_words, out10.p);
+                         sa.bpre, sa.sa_c, sa.n_words, out10.p, (uint64_t)0, 0, ~0ull);
       PFP_HIP(hipGetLastError());
     }
     return pairs;
@@ -1765,6 +1775,20 @@ uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const SaView &sa, uint6
   out10.alloc(c, rs.pairs * 10 + 16);
   rs.place(sa, 0, out10.p);
   return rs.pairs;
+}
+
+uint64_t sample_runs_maps(pfp_ctx *c, const SaView &sa, uint64_t slice_n, bool run_end, bool drop_edge, uint64_t pos_base, uint8_t *out10) {
+  const uint64_t *map = run_end ? sa.emap : sa.smap;
+  PFP_REQUIRE(map && sa.sa_c, PFP_EINVAL, "no run maps: the merge was not run for a sampled SA without an SA array");
+  const uint64_t all = run_end ? sa.n_ends : sa.n_starts;
+  const uint64_t pairs = all - ((drop_edge && all) ? 1 : 0);
+  if (!out10 || !pairs || !sa.n_words) return pairs;
+  KScope ks(c, "pfp::run_place_kernel", sa.n_words * 24 + pairs * 18);
+  hipLaunchKernelGGL(bitmap_place_kernel, gdim(cdiv(sa.n_words, 256)), gdim(256), 0, c->stream, map, run_end ? sa.epre : sa.spre, sa.bmap,
+                     sa.bpre, sa.sa_c, sa.n_words, out10, pos_base, (drop_edge && !run_end) ? 1 : 0,
+                     (drop_edge && run_end && slice_n) ? slice_n - 1 : ~0ull);
+  PFP_HIP(hipGetLastError());
+  return pairs;
 }
 
 }  // namespace pfp

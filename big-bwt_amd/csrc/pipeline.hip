@@ -1054,6 +1054,8 @@ struct DistState {
   DictOrder ord;
   DBuf<uint32_t> occ_lex;
   uint64_t local_total = 0;     // BWT positions the held slots emit
+  BwtOutputs out;               // -s / -e without an SA slice: run maps and per-boundary SA values of the emitted slice
+  uint64_t out_lo = 0;
   bool want_sai = false;
   int flags = 0;                // output flags announced at pfp_dist_local_parse (0: BWT only)
   // hash-partitioned dedup (pfp_dist_partition_words ...): local words in owner order, the words this rank owns,
@@ -1438,7 +1440,7 @@ int pfp_dist_global(pfp_ctx *c, const void *d_union, uint64_t union_bytes, const
 
 int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last, const void *d_sai, int flags,
                    uint64_t n_total, uint64_t out_lo, uint64_t out_hi, void *d_bwt_slice, void *d_sa_slice) {
-  if (!c || !c->dist || !d_sym || !d_last || !d_bwt_slice || (flags && (!d_sai || !d_sa_slice))) return PFP_EINVAL;
+  if (!c || !c->dist || !d_sym || !d_last || !d_bwt_slice || (flags && !d_sai) || ((flags & PFP_FLAG_SA) && !d_sa_slice)) return PFP_EINVAL;
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
   DistState *ds = dist_of(c);
@@ -1448,7 +1450,9 @@ int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last
   parse_bwt(c, (const uint32_t *)d_sym, P, (const uint8_t *)d_last, flags ? (const uint64_t *)d_sai : nullptr,
             ds->occ_lex.p, ds->G.d, pb);
   if (c->debug) validate_parse_bwt(c, pb);
-  BwtOutputs bo;
+  ds->out = BwtOutputs();       // (-s / -e with d_sa_slice == NULL: what pfp_dist_sample_runs reads afterwards)
+  ds->out_lo = out_lo;
+  BwtOutputs &bo = ds->out;
   bo.d_bwt = (uint8_t *)d_bwt_slice; bo.d_sa = (uint64_t *)d_sa_slice;
   bool empty_share = false;
   with_width(ds->ord.wide, [&](auto tag) {
@@ -1465,6 +1469,24 @@ int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last
     }
   });
   (void)empty_share;
+  sync(c);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_dist_sample_runs(pfp_ctx *c, int run_end, int drop_edge, void *d_out10, uint64_t cap_pairs, uint64_t *n_pairs) {
+  if (!c || !c->dist || !n_pairs) return PFP_EINVAL;
+  *n_pairs = 0;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  if (!ds->out.slice_n) return PFP_OK;      // an empty slice
+  const SaView sv = sa_view(ds->out);
+  const uint64_t k = sample_runs_maps(c, sv, ds->out.slice_n, run_end != 0, drop_edge != 0, ds->out_lo, nullptr);
+  *n_pairs = k;
+  if (!d_out10) return PFP_OK;
+  PFP_REQUIRE(k <= cap_pairs, PFP_ELIMIT, "output buffer holds " + std::to_string(cap_pairs) + " pairs, the slice has " + std::to_string(k));
+  sample_runs_maps(c, sv, ds->out.slice_n, run_end != 0, drop_edge != 0, ds->out_lo, (uint8_t *)d_out10);
   sync(c);
   return PFP_OK;
   PFP_CATCH(c)

@@ -283,10 +283,11 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
     else:
         lo, hi = slice_bounds(n_out, rank, size)
     bwt = torch.empty(hi - lo + 16, dtype=torch.uint8, device=dev)
-    sa = torch.empty(hi - lo + 1, dtype=torch.int64, device=dev) if flags else None
+    # -S: the slice of SA values; -s / -e: the values stay in the library (8 bytes per run boundary of the slice)
+    sa = torch.empty(hi - lo + 1, dtype=torch.int64, device=dev) if (flags & pfp.FLAG_SA) else None
     torch.cuda.synchronize(dev)
     step.run(lambda: ctx.dist_merge(sym_all.data_ptr(), sym_all.numel(), last_all.data_ptr(), sai_all.data_ptr() if want_sai else None,
-                                    flags, n_total, lo, hi, bwt.data_ptr(), sa.data_ptr() if flags else None))
+                                    flags, n_total, lo, hi, bwt.data_ptr(), sa.data_ptr() if sa is not None else None))
     # --- the reference's output formats.  Run sampling needs one byte of halo from either neighbour:
     #     the BWT byte just before and just after this rank's slice (slices may be empty).
     cnt = hi - lo
@@ -294,7 +295,7 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
                          int(step.status()[0])], dtype=torch.int64, device=dev)
     edges = yield ("allgather", edge)
     step.check([e[3:4] for e in edges], "merge")
-    out = dict(bwt=bwt[:cnt], sa=sa[:cnt] if flags else None, lo=lo, hi=hi, n_total=n_total)
+    out = dict(bwt=bwt[:cnt], sa=sa[:cnt] if sa is not None else None, lo=lo, hi=hi, n_total=n_total)
     if flags & pfp.FLAG_SA:
         # .sa holds SA[1..n] (SA[0] = n is not written: pfbwt.cpp:158-162)
         first = 1 if lo == 0 else 0
@@ -310,10 +311,12 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
         counts = {}
         for key, flag, run_end in (("ssa", pfp.FLAG_SSA, False), ("esa", pfp.FLAG_ESA, True)):
             if flags & flag:
-                k = ctx.sample_runs_dev(bwt.data_ptr(), sa.data_ptr(), cnt, lo, lb, rb, run_end) if cnt else 0
+                # the slice's own edge is a run start (end) unless the neighbour's adjacent byte is the same
+                drop = bool(cnt) and ((rb >= 0 and rb == int(edges[rank][2])) if run_end else (lb >= 0 and lb == int(edges[rank][1])))
+                k = ctx.dist_sample_runs(run_end, drop) if cnt else 0
                 buf = torch.empty(10 * k + 16, dtype=torch.uint8, device=dev)
                 if k:
-                    ctx.sample_runs_dev(bwt.data_ptr(), sa.data_ptr(), cnt, lo, lb, rb, run_end, buf.data_ptr(), k)
+                    ctx.dist_sample_runs(run_end, drop, buf.data_ptr(), k)
                 out[key] = buf[: 10 * k]
                 counts[key] = k
         ks = yield ("allgather", torch.tensor([counts.get("ssa", 0), counts.get("esa", 0)], dtype=torch.int64, device=dev))

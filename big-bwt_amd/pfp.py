@@ -32,7 +32,7 @@ SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror"
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_files", "pfp_bigbwt_dev", "pfp_bigbwt_formats_dev", "pfp_dev_free", "pfp_memcpy_d2h", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
            "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
            "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_partition_words", "pfp_dist_export_partition",
-           "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_release"]
+           "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_sample_runs", "pfp_dist_release"]
 
 
 class PfpError(RuntimeError):
@@ -472,6 +472,14 @@ class Context:
                                             C.c_void_p(d_sai) if d_sai else None, C.c_int(flags), C.c_uint64(n_total),
                                             C.c_uint64(out_lo), C.c_uint64(out_hi), C.c_void_p(d_bwt_slice),
                                             C.c_void_p(d_sa_slice) if d_sa_slice else None))
+
+    def dist_sample_runs(self, run_end, drop_edge, d_out10_ptr=None, cap_pairs=0):
+        """.ssa / .esa pairs of the slice the last dist_merge emitted (-s / -e without an SA slice), from its run maps;
+        returns the number of pairs (count only without an output pointer)"""
+        k = C.c_uint64()
+        self._check(self.lib.pfp_dist_sample_runs(self._h, C.c_int(1 if run_end else 0), C.c_int(1 if drop_edge else 0),
+                                                  C.c_void_p(d_out10_ptr) if d_out10_ptr else None, C.c_uint64(cap_pairs), C.byref(k)))
+        return k.value
 
     def dist_release(self):
         self.lib.pfp_dist_release(self._h)

@@ -309,6 +309,13 @@ int pfp_dist_global_sort_distinct(pfp_ctx *ctx, const void *d_dict, uint64_t dic
                                   uint64_t out_info[8]);
 int pfp_dist_merge(pfp_ctx *ctx, const void *d_sym, uint64_t P, const void *d_last, const void *d_sai, int flags,
                    uint64_t n_total, uint64_t out_lo, uint64_t out_hi, void *d_bwt_slice, void *d_sa_slice);
+/* After pfp_dist_merge with PFP_FLAG_SSA / PFP_FLAG_ESA and d_sa_slice == NULL (the SA values then stay inside: 8 bytes
+ * per run boundary of the slice instead of 8 per position): the slice's pieces of .ssa (run_end == 0) / .esa
+ * (run_end != 0) as 10-byte pairs <global position, SA value> (pfbwt.cpp:605-676), written from the run maps the merge
+ * left - no pass over the BWT bytes.  drop_edge: the slice's first (.ssa) / last (.esa) position is not a run start /
+ * end after all, because the neighbouring slice's adjacent byte is the same (the caller has exchanged those bytes).
+ * d_out10 == NULL: count only. */
+int pfp_dist_sample_runs(pfp_ctx *ctx, int run_end, int drop_edge, void *d_out10, uint64_t cap_pairs, uint64_t *n_pairs);
 void pfp_dist_release(pfp_ctx *ctx);
 
 /* ---- micro entry points used by bench.py's roofline leg and by the parity tests ---- */

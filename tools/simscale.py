@@ -42,7 +42,7 @@ def wrap(obj, meth):
 
 for m_ in ('dist_propose_triggers', 'dist_local_parse', 'dist_export_local', 'dist_partition_words', 'dist_export_partition',
            'dist_owner_dedup', 'dist_export_owned', 'dist_global_sort', 'dist_global_sort_distinct', 'dist_global_finish', 'dist_merge',
-           'pack5_dev', 'sample_runs_dev'):
+           'pack5_dev', 'sample_runs_dev', 'dist_sample_runs'):
     wrap(ctxs[R - 1], m_)
 for it in range(2):
     acc.clear()
