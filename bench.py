@@ -66,6 +66,23 @@ def cpu_baseline(text_host, w, p, flags, O, threads):
                 seconds=round(secs, 3)), outs
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without RANK in the environment: run `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same arguments>` as a child (this parent has not touched the GPU and never will), pass its output
+    through and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,7 +94,14 @@ def main():
     ap.add_argument("--no-host-boundary", action="store_true")
     ap.add_argument("--multi", default="collection", choices=["collection", "independent"],
                     help="N>1: one BWT of a sharded collection (RCCL exchanges) or one independent text per GPU")
+    ap.add_argument("--north-star", dest="north_star", default="auto", choices=["auto", "on", "off"],
+                    help="N=1, default workload: also time 2 steps of the >= 10 GB north-star workload (huge_s) with its digest check")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher around us: start the N ranks ourselves (one process per GPU) BEFORE anything touches the GPU, as
+        # child processes - a process that has initialised HIP must never exec - and relay rank 0's JSON line
+        sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -89,7 +113,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # PFP_BENCH_BACKEND=gloo PFP_BENCH_ONE_GPU=1: rehearsal of the N>1 path on a one-GPU box (all ranks on cuda:0)
         dist.init_process_group(backend=os.environ.get("PFP_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} rank(s)"
     if os.environ.get("PFP_BENCH_ONE_GPU"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -142,7 +166,6 @@ def main():
     step(sizing=True)
     for _ in range(max(0, args.warmup - 1)):
         step()
-    ctx.set_kernel_trace(True)          # HIP events around every kernel, on the library's own stream
     barrier(); torch.cuda.synchronize()
     pc0 = ctx.pool_counters()
     t0 = time.perf_counter()
@@ -162,7 +185,16 @@ def main():
         total_bytes = float(n)
     ms_per_step = elapsed / args.steps * 1e3
     value = total_bytes * args.steps / elapsed / 1e6
-    ktable = ctx.kernel_trace()         # resolves the events recorded during the timed steps
+    # per-kernel device times: HIP events around every kernel on the library's own stream, over TRACE_STEPS further steps
+    # of the same input right after the timed ones (two events per launch inside the timed region cost ~1 ms per step)
+    TRACE_STEPS = 2
+    ctx.set_kernel_trace(True)
+    t1 = time.perf_counter()
+    for _ in range(TRACE_STEPS):
+        step()
+    torch.cuda.synchronize()
+    traced_ms_per_step = (time.perf_counter() - t1) / TRACE_STEPS * 1e3
+    ktable = ctx.kernel_trace()
     ctx.set_kernel_trace(False)
 
     # per-phase breakdown of one extra (untimed) profiled step
@@ -188,7 +220,6 @@ def main():
         dist.all_reduce(hist_t); dist.all_reduce(hist_b)
         hist_t[0] += 1
         dstats = res["stats"]
-        st["n_phrases"], st["n_words"], st["dict_size"] = dstats["phrases_total"], dstats["glob"]["words"], dstats["glob"]["dict_bytes"]
     else:
         hist_t[0] += 1
         hist_b = hist(bwt[: n + 1])
@@ -216,8 +247,8 @@ def main():
             if r["total_ms"] <= 0 or r["launches"] == 0:
                 continue
             gbs = r["algo_bytes"] / (r["total_ms"] * 1e-3) / 1e9
-            rows.append(dict(kernel=r["name"], ms_per_step=round(r["total_ms"] / args.steps, 3),
-                             launches_per_step=round(r["launches"] / args.steps, 1),
+            rows.append(dict(kernel=r["name"], ms_per_step=round(r["total_ms"] / TRACE_STEPS, 3),
+                             launches_per_step=round(r["launches"] / TRACE_STEPS, 1),
                              us_per_launch=round(r["total_ms"] / r["launches"] * 1e3, 2),
                              algo_bytes_per_launch=int(r["algo_bytes"] / r["launches"]),
                              achieved_GBps=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4)))
@@ -239,16 +270,24 @@ def main():
                 pass
 
         # ---- per-pass fractions with SURVEY.md 8(d)'s algorithmic-byte formulas over the synced phase times of the profiled step
+        # (N > 1: THIS RANK's share of every pass over this rank's phase timers - its shard and own phrases for the scan
+        #  and the hash, its slice of the BWT, the range of SA(D) it holds and the whole parse it reads for the merge)
         P, D_, H = st["n_phrases"], st["dict_size"], st["hard_chars"]
-        nn = st["n"] if not collection else n
+        nn = st["n"]
         R = {k: last.get(k + "_bytes", 0) // 10 for k in ("ssa", "esa")}
+        n_slice, P_merge = nn + 1, P
+        if collection:
+            res = last["r"]
+            n_slice, P_merge, D_ = res["hi"] - res["lo"], dstats["phrases_total"], dstats["glob"]["slots"]
+            R = {k: res[k].numel() // 10 for k in ("ssa", "esa") if k in res and res[k] is not None}
+            R = {k: R.get(k, 0) for k in ("ssa", "esa")}
         b_scan = nn + 8 * P
         b_hash = nn + w * P + 8 * P
-        b_merge = (nn + 1) + 12 * D_ + 5 * (P + 1) + 8 * H
+        b_merge = n_slice + 12 * D_ + 5 * (P_merge + 1) + 8 * H
         if flags & 1:
-            b_merge += 10 * nn
+            b_merge += 10 * n_slice
         if flags & 6:
-            b_merge += 10 * (R["ssa"] + R["esa"]) + 5 * nn
+            b_merge += 10 * (R["ssa"] + R["esa"]) + 5 * n_slice
         ktime = {r["kernel"]: r["ms_per_step"] for r in rows}
         t_hash = ktime.get("pfp::phrase_hash_kernel", 0.0)
         t_formats = sum(ktime.get(k, 0.0) for k in ("pfp::run_count_kernel", "pfp::run_place_kernel", "pfp::pack5_kernel"))
@@ -264,11 +303,10 @@ def main():
                   "merge ((n+1) + 12|D| + 5(P+1) + 8H [+ SA terms]; incl. run sampling / packing)": pass_row(b_merge, t_merge),
                   "scan + merge": pass_row(b_scan + b_merge, st["ms_scan"] + t_merge),
                   "end to end floor (2n)": pass_row(2 * nn, ms_per_step)}
+        bad = [k for k, v in passes.items() if v and v["frac"] > 1.0]
+        assert not bad, f"pass fraction above 1 ({bad}): the timed figure is not the work"
 
-        scan_row = next((x for x in rows if x["kernel"] == "pfp::kr_flag_kernel"), None)
-        if scan_row is not None:
-            scan_row = dict(scan_row, valu_bound_GBps=1966.0, frac_of_valu_bound=round(scan_row["achieved_GBps"] / 1966.0, 4),
-                            note="VALU-bound: ~20 instructions per byte for the exact rolling hash")
+        scan_row = next((x for x in rows if x["kernel"] in ("pfp::kr_flag_kernel", "pfp::kr_scan_kernel")), None)
         # the host-buffer entry point (H2D of the text + D2H of the outputs included): reported, never `value`
         host_boundary, host_ok = None, None
         if world == 1 and not args.no_host_boundary and n <= (2 << 30):
@@ -324,7 +362,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "name": wl_name, "bytes_per_gpu": n, "w": w, "p": p, "flags": flags,
-                       "phrases": st["n_phrases"], "words": st["n_words"], "dict_bytes": st["dict_size"],
+                       "phrases": dstats["phrases_total"] if collection else st["n_phrases"], "words": st["n_words"], "dict_bytes": st["dict_size"],
                        "outputs_in_timed_step": ["bwt"] + [k for k in ("sa", "ssa", "esa") if k in outbuf or (collection and ("sa5" if k == "sa" else k) in last.get("r", {}))],
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{world} shards of one collection over RCCL: halo allgather, hash-partitioned all-to-all phrase dedup, "
@@ -339,10 +377,11 @@ def main():
             "host_buffer_boundary": host_boundary,
             "cli_file_to_file": cli,
             "phases_ms": dict({k: round(st[k], 3) for k in ("ms_scan", "ms_phrases", "ms_sa_dict", "ms_sa_parse", "ms_merge", "ms_total")},
-                              formats=round(t_formats, 3), profiled_step=round(prof_ms, 3)),
+                              formats=round(t_formats, 3), profiled_step=round(prof_ms, 3), traced_step=round(traced_ms_per_step, 3)),
             "sa_rounds": {"dict": st["sa_rounds_dict"], "parse": st["sa_rounds_parse"]},
             "merge_stats": {k: st[k] for k in ("hard_groups", "hard_chars", "hard_big_groups", "hard_max_chars", "hard_max_members", "hard_minor_groups", "hard_minor_chars", "extra_triggers", "index_bits")},
             "runs": R,
+            "rccl": (dict(dstats["collectives"], ranks=world) if collection else None),
             "device_memory": {"peak_bytes_in_use": mem["peak"], "held_from_driver": mem["held"],
                               "driver_allocations_in_timed_steps": pc1["driver_allocs"] - pc0["driver_allocs"],
                               "pool_trims_in_timed_steps": pc1["trims"] - pc0["trims"]},

@@ -1056,6 +1056,7 @@ struct DistState {
   uint64_t local_total = 0;     // BWT positions the held slots emit
   BwtOutputs out;               // -s / -e without an SA slice: run maps and per-boundary SA values of the emitted slice
   uint64_t out_lo = 0;
+  bool slice_empty = true;      // the last pfp_dist_merge emitted no position
   bool want_sai = false;
   int flags = 0;                // output flags announced at pfp_dist_local_parse (0: BWT only)
   // hash-partitioned dedup (pfp_dist_partition_words ...): local words in owner order, the words this rank owns,
@@ -1165,18 +1166,21 @@ int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t ha
   if (!c || (!d_text && n) || !out_sizes || (n_extra && !extra_hashes)) return PFP_EINVAL;
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
-  check_args(w, p, 0);
+  check_args(w, p, want_sai & 7);      // (callers pass the output flags here: -S with -s/-e is refused like bigbwt:59-61)
   PFP_REQUIRE(n_extra <= KRParams::kMaxExtra, PFP_EINVAL, "too many extra trigger hashes");
   PFP_REQUIRE(is_first ? halo_len == 0 : halo_len >= (uint64_t)w, PFP_EINVAL, "halo must hold at least one window");
   PFP_REQUIRE(halo_len <= n, PFP_EINVAL, "halo longer than the local text");
   DistState *ds = dist_of(c);
   *ds = DistState();
   ds->w = w; ds->n_local = n;
+  pfp_stats &st = c->stats;
+  st = pfp_stats{};
   ds->tx.stage(c, d_text, true, n, w);
   uint64_t used = 0;
   KRParams kp = make_kr_params(w, p);                              // one trigger set on all ranks
   for (uint32_t q = 0; q < n_extra; q++) { kp.extra[kp.nextra++] = extra_hashes[q]; kp.bloom |= 1ull << (extra_hashes[q] & 63); }
-  ds->n_ends = scan_text(c, ds->tx, n, w, p, ds->ends, &used, &kp);
+  { PhaseTimer t(c, &st.ms_scan);
+    ds->n_ends = scan_text(c, ds->tx, n, w, p, ds->ends, &used, &kp); }
   PFP_REQUIRE(used == n, PFP_EFORMAT, "bytes <= 2 inside a text shard are not supported in the multi-GPU chain");
   DBuf<uint64_t> tmp(c, 2);
   hipLaunchKernelGGL(count_below_kernel, gdim(1), gdim(1), 0, c->stream, ds->ends.p, ds->n_ends, halo_len, tmp.p);
@@ -1192,7 +1196,9 @@ int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t ha
   const uint64_t sai_base = global_offset - halo_len;
   ds->want_sai = want_sai != 0;
   ds->flags = want_sai & 7;     // callers pass the output flags here (any non-zero value asks for sa info)
-  build_dictionary_shard(c, ds->tx, n, w, ds->ends, ds->n_ends, ds->k0, ds->P_local, want_sai != 0, sai_base, ds->L);
+  { PhaseTimer t(c, &st.ms_phrases);
+    build_dictionary_shard(c, ds->tx, n, w, ds->ends, ds->n_ends, ds->k0, ds->P_local, want_sai != 0, sai_base, ds->L); }
+  st.n = n - halo_len; st.n_phrases = ds->P_local; st.extra_triggers = n_extra;
   out_sizes[0] = ds->L.dsize - 1;      // local dictionary bytes without the final 0x00
   out_sizes[1] = ds->L.d;
   out_sizes[2] = ds->P_local;
@@ -1221,6 +1227,7 @@ int pfp_dist_export_local(pfp_ctx *c, void *d_dict, void *d_occ, void *d_last, v
 }  // extern "C"
 // the global dictionary ds->G is in place: index it and sort its suffixes (replicated, or this rank's key range)
 static void dist_sort_global(pfp_ctx *c, DistState *ds, uint32_t part, uint32_t parts, void *d_wslot_out, uint64_t out_info[8]) {
+  PhaseTimer t_sa(c, &c->stats.ms_sa_dict);
   ds->ix = DictIndex();
   ds->ord = DictOrder();
   build_dict_index(c, ds->G, ds->ix);
@@ -1263,6 +1270,8 @@ static void dist_sort_global(pfp_ctx *c, DistState *ds, uint32_t part, uint32_t 
   sync(c);
   out_info[0] = ds->G.d; out_info[1] = ds->G.dsize; out_info[2] = info_rounds; out_info[3] = info_complete;
   out_info[4] = info_N; out_info[5] = info_base; out_info[6] = ds->local_total; out_info[7] = ds->ord.wide ? 64 : 32;
+  c->stats.n_words = ds->G.d; c->stats.dict_size = ds->G.dsize; c->stats.sa_rounds_dict = info_rounds;
+  c->stats.index_bits = ds->ord.wide ? 64 : 32;
 }
 extern "C" {
 
@@ -1445,16 +1454,21 @@ int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last
   PFP_HIP(hipSetDevice(c->device));
   DistState *ds = dist_of(c);
   check_args(ds->w, 10, flags);
+  PFP_REQUIRE(flags == ds->flags, PFP_EINVAL, "output flags differ from those announced at pfp_dist_local_parse");
   PFP_REQUIRE(out_lo <= out_hi && out_hi <= n_total + 1, PFP_EINVAL, "bad output slice");
   ParseBWT pb;
-  parse_bwt(c, (const uint32_t *)d_sym, P, (const uint8_t *)d_last, flags ? (const uint64_t *)d_sai : nullptr,
-            ds->occ_lex.p, ds->G.d, pb);
+  { PhaseTimer t(c, &c->stats.ms_sa_parse);
+    parse_bwt(c, (const uint32_t *)d_sym, P, (const uint8_t *)d_last, flags ? (const uint64_t *)d_sai : nullptr,
+              ds->occ_lex.p, ds->G.d, pb);
+    c->stats.sa_rounds_parse = pb.rounds; }
   if (c->debug) validate_parse_bwt(c, pb);
   ds->out = BwtOutputs();       // (-s / -e with d_sa_slice == NULL: what pfp_dist_sample_runs reads afterwards)
   ds->out_lo = out_lo;
+  ds->slice_empty = out_hi == out_lo;
   BwtOutputs &bo = ds->out;
   bo.d_bwt = (uint8_t *)d_bwt_slice; bo.d_sa = (uint64_t *)d_sa_slice;
   bool empty_share = false;
+  PhaseTimer t_merge(c, &c->stats.ms_merge);
   with_width(ds->ord.wide, [&](auto tag) {
     using I = decltype(tag);
     auto &so = ds->ord.get<I>();
@@ -1469,6 +1483,9 @@ int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last
     }
   });
   (void)empty_share;
+  { pfp_stats &st = c->stats;
+    st.hard_groups = bo.hard_groups; st.hard_chars = bo.hard_chars; st.hard_big_groups = bo.hard_big_groups;
+    st.hard_max_members = bo.hard_max_members; st.hard_minor_groups = bo.hard_minor_groups; st.hard_minor_chars = bo.hard_minor_chars; }
   sync(c);
   return PFP_OK;
   PFP_CATCH(c)
@@ -1480,7 +1497,11 @@ int pfp_dist_sample_runs(pfp_ctx *c, int run_end, int drop_edge, void *d_out10, 
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
   DistState *ds = dist_of(c);
-  if (!ds->out.slice_n) return PFP_OK;      // an empty slice
+  PFP_REQUIRE((ds->flags & (PFP_FLAG_SSA | PFP_FLAG_ESA)) && !(ds->flags & PFP_FLAG_SA), PFP_EINVAL,
+              "pfp_dist_sample_runs: the chain was not run with -s / -e");
+  PFP_REQUIRE((run_end ? PFP_FLAG_ESA : PFP_FLAG_SSA) & ds->flags, PFP_EINVAL, "this sampled file was not asked for");
+  if (ds->slice_empty) return PFP_OK;      // this rank's slice of the BWT holds no position
+  PFP_REQUIRE(ds->out.slice_n && ds->out.sa_c.p, PFP_EINVAL, "the last pfp_dist_merge left no run maps (it must run before, with an SA-less slice)");
   const SaView sv = sa_view(ds->out);
   const uint64_t k = sample_runs_maps(c, sv, ds->out.slice_n, run_end != 0, drop_edge != 0, ds->out_lo, nullptr);
   *n_pairs = k;

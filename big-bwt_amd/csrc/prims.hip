@@ -22,40 +22,29 @@ template <class K, class V> static const char *sort_name() {
   if (sizeof(K) == 8 && sizeof(V) == 8) return "rocprim::radix_sort_pairs<u64,u64>";
   return "rocprim::radix_sort_pairs<u128,u64>";
 }
+// Algorithmic bytes of a library sort: every element read once and written once.  (An LSD radix sort moves them once
+// per 8-bit pass - plus one histogram read - and rounds 1-2 counted those passes as "algorithmic", which flattered the
+// library: 0.37 of the roofline for a sort that is 0.06 by this definition.  The per-pass traffic is reported next to
+// it by bench.py from the pass count: pfp::sort_passes(bb, eb).)
+// rocPRIM's merge-sort path (small inputs) compares with a mask (1 << end_bit) - 1: undefined for end_bit == key width
+// when begin_bit > 0.  No caller of the pair sorts passes that combination; refuse it should one appear.
+#define PFP_SORT_GUARD(K, bb, eb) PFP_REQUIRE(!((bb) > 0 && (eb) == (int)(8 * sizeof(K))), PFP_EINVAL, "pair sort with begin_bit > 0 up to the key's last bit (rocPRIM merge-path mask)")
 template <class K, class V>
 void sort_pairs(pfp_ctx *c, const K *kin, K *kout, const V *vin, V *vout, size_t n, int bb, int eb) {
   if (!n) return;
-  const uint64_t passes = (uint64_t)(eb - bb + 7) / 8;
-  KScope ks(c, sort_name<K, V>(), n * sizeof(K) + passes * n * 2 * (sizeof(K) + sizeof(V)));
+  PFP_SORT_GUARD(K, bb, eb);
+  KScope ks(c, sort_name<K, V>(), n * 2 * (sizeof(K) + sizeof(V)));
   PRIM2(rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, (unsigned)bb, (unsigned)eb, c->stream));
 }
 template <class K, class V>
 void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &valt, size_t n, int bb, int eb) {
   if (!n) return;
   PFP_REQUIRE(k.n >= n && kalt.n >= n && v.n >= n && valt.n >= n, PFP_EINVAL, "sort_pairs_db: a buffer is shorter than n");
-  const uint64_t passes = (uint64_t)(eb - bb + 7) / 8;
-  KScope ks(c, sort_name<K, V>(), n * sizeof(K) + passes * n * 2 * (sizeof(K) + sizeof(V)));
+  PFP_SORT_GUARD(K, bb, eb);
+  KScope ks(c, sort_name<K, V>(), n * 2 * (sizeof(K) + sizeof(V)));
   rocprim::double_buffer<K> dk(k.p, kalt.p);
   rocprim::double_buffer<V> dv(v.p, valt.p);
-  bool done = false;
-#ifdef PFP_SORTCFG_EXPERIMENT
-  static const int cfg = []() { const char *e = getenv("PFP_SORTCFG"); return e ? atoi(e) : 0; }();
-  using rocprim::kernel_config; using rocprim::default_config; using rocprim::radix_sort_config; using rocprim::radix_sort_onesweep_config;
-  using A = rocprim::block_radix_rank_algorithm;
-#define PFP_TRY_CFG(id, BS, IPT, ALG)                                                                                          \
-  if constexpr (sizeof(K) == 8 && sizeof(V) == 4) if (cfg == id) {                                                                       \
-    using C_ = radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<BS, IPT>, kernel_config<BS, IPT>, 8, ALG>>; \
-    PRIM2(rocprim::radix_sort_pairs<C_>(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream));                            \
-  } else
-  PFP_TRY_CFG(1, 256, 16, A::match)
-  PFP_TRY_CFG(2, 512, 12, A::match)
-  PFP_TRY_CFG(3, 1024, 8, A::match)
-  PFP_TRY_CFG(4, 512, 20, A::match)
-  PFP_TRY_CFG(5, 256, 24, A::match)
-  PFP_TRY_CFG(6, 1024, 12, A::match)
-  PFP_TRY_CFG(8, 256, 12, A::match)
-#endif
-  if (!done) PRIM2(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream));
+  PRIM2(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream));
   if (dk.current() != k.p) std::swap(k, kalt);
   if (dv.current() != v.p) std::swap(v, valt);
 }
@@ -67,9 +56,11 @@ void sort_keys_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, size_t n, int bb, int e
   // key's whole width when end_bit == 64 - undefined, and in practice a mask of the bits BELOW begin_bit only
   // (found by fuzzing the keys-only suffix sort on small dictionaries).  The caller's low bits are a unique,
   // ascending index, so sorting the whole word gives the same order: do that where the merge path can be taken.
-  if (bb > 0 && eb == (int)(8 * sizeof(K)) && n <= (size_t(1) << 21)) bb = 0;
-  const uint64_t passes = (uint64_t)(eb - bb + 7) / 8;
-  KScope ks(c, "rocprim::radix_sort_keys<u64>", n * sizeof(K) + passes * n * 2 * sizeof(K));
+  // (the library's merge_sort_limit is 2^20 elements today; up to four times that the three extra passes cost well under
+  //  a millisecond, beyond it the onesweep path is taken whatever a release sets the limit to - the full-size digests
+  //  of the reference pin that path)
+  if (bb > 0 && eb == (int)(8 * sizeof(K)) && n <= (size_t(1) << 22)) bb = 0;
+  KScope ks(c, "rocprim::radix_sort_keys<u64>", n * 2 * sizeof(K));
   rocprim::double_buffer<K> dk(k.p, kalt.p);
   PRIM2(rocprim::radix_sort_keys(tmp, tb, dk, n, (unsigned)bb, (unsigned)eb, c->stream));
   if (dk.current() != k.p) std::swap(k, kalt);

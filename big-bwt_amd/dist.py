@@ -100,11 +100,17 @@ class _Step:
         self.rank, self.dev, self.err = rank, dev, None
 
     def run(self, fn):
+        if self.err is not None:          # an earlier step of this rank already failed: do nothing until the ranks have agreed
+            return None
         try:
             return fn()
         except pfp.PfpError as ex:
             self.err = ex
-            return None
+        except torch.cuda.OutOfMemoryError as ex:      # a torch.empty between two collectives
+            self.err = pfp.PfpError(-7, f"rank {self.rank}: {ex}")
+        except RuntimeError as ex:                     # HIP errors surfaced by torch
+            self.err = pfp.PfpError(-3, f"rank {self.rank}: {ex}")
+        return None
 
     def status(self):
         code = self.err.code if self.err is not None else 0
@@ -136,6 +142,8 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
     dev = shard.device
     n_shard = shard.numel()
     want_sai = bool(flags)
+    if (flags & pfp.FLAG_SA) and (flags & (pfp.FLAG_SSA | pfp.FLAG_ESA)):      # bigbwt:59-61, pfbwt.cpp:298; every rank alike
+        raise pfp.PfpError(-1, "You can either compute the full SA or a sample of it, not both (bigbwt:59-61)")
     step = _Step(rank, dev)
     # --- halo: the tail of every shard travels to its right neighbour
     tail = shard[-min(halo, n_shard):].contiguous()
@@ -296,42 +304,87 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
     edges = yield ("allgather", edge)
     step.check([e[3:4] for e in edges], "merge")
     out = dict(bwt=bwt[:cnt], sa=sa[:cnt] if sa is not None else None, lo=lo, hi=hi, n_total=n_total)
+    # every allocation / library call below runs through `step`: a rank that fails here (out of memory, a limit) still
+    # enters the next all-gather with its status, and all ranks stop together
     if flags & pfp.FLAG_SA:
         # .sa holds SA[1..n] (SA[0] = n is not written: pfbwt.cpp:158-162)
         first = 1 if lo == 0 else 0
         k = max(cnt - first, 0)
-        sa5 = torch.empty(5 * k + 16, dtype=torch.uint8, device=dev)
-        if k:
-            ctx.pack5_dev(sa.data_ptr() + 8 * first, k, sa5.data_ptr())
+
+        def pack():
+            sa5 = torch.empty(5 * k + 16, dtype=torch.uint8, device=dev)
+            if k:
+                ctx.pack5_dev(sa.data_ptr() + 8 * first, k, sa5.data_ptr())
+            return sa5
+        sa5 = step.run(pack)
+        st = yield ("allgather", step.status())
+        step.check(st, "5-byte packing")
         out["sa5"], out["sa5_off"] = sa5[: 5 * k], 5 * (lo + first - 1)
     if flags & (pfp.FLAG_SSA | pfp.FLAG_ESA):
         lefts = [int(e[2]) for e in edges[:rank] if int(e[0]) > 0]
         rights = [int(e[1]) for e in edges[rank + 1:] if int(e[0]) > 0]
         lb, rb = (lefts[-1] if lefts else -1), (rights[0] if rights else -1)
         counts = {}
+
+        def sample(run_end):
+            # the slice's own edge is a run start (end) unless the neighbour's adjacent byte is the same
+            drop = bool(cnt) and ((rb >= 0 and rb == int(edges[rank][2])) if run_end else (lb >= 0 and lb == int(edges[rank][1])))
+            k = ctx.dist_sample_runs(run_end, drop) if cnt else 0
+            buf = torch.empty(10 * k + 16, dtype=torch.uint8, device=dev)
+            if k:
+                ctx.dist_sample_runs(run_end, drop, buf.data_ptr(), k)
+            return buf[: 10 * k], k
         for key, flag, run_end in (("ssa", pfp.FLAG_SSA, False), ("esa", pfp.FLAG_ESA, True)):
             if flags & flag:
-                # the slice's own edge is a run start (end) unless the neighbour's adjacent byte is the same
-                drop = bool(cnt) and ((rb >= 0 and rb == int(edges[rank][2])) if run_end else (lb >= 0 and lb == int(edges[rank][1])))
-                k = ctx.dist_sample_runs(run_end, drop) if cnt else 0
-                buf = torch.empty(10 * k + 16, dtype=torch.uint8, device=dev)
-                if k:
-                    ctx.dist_sample_runs(run_end, drop, buf.data_ptr(), k)
-                out[key] = buf[: 10 * k]
-                counts[key] = k
-        ks = yield ("allgather", torch.tensor([counts.get("ssa", 0), counts.get("esa", 0)], dtype=torch.int64, device=dev))
+                got = step.run(lambda: sample(run_end))
+                out[key], counts[key] = got if got is not None else (None, 0)
+        ks = yield ("allgather", torch.tensor([counts.get("ssa", 0), counts.get("esa", 0), int(step.status()[0])], dtype=torch.int64, device=dev))
+        step.check([t[2:3] for t in ks], "run sampling")
         for j, key in enumerate(("ssa", "esa")):
             if key in out:
                 out[key + "_off"] = 10 * sum(int(t[j]) for t in ks[:rank])
+        out["sampled_total"] = {key: sum(int(t[j]) for t in ks) for j, key in enumerate(("ssa", "esa")) if key in out}
     out["stats"] = dict(local=info, glob=ginfo, phrases_total=int(sym_all.numel()), shard_bytes=n_shard, extra_triggers=len(extra),
                         sa_shares=parts, dedup=dedup)
     return out
 
 
-def write_outputs(ctx, path, res):
+def output_sizes(res):
+    """final byte size of every output file of the run `res` is a piece of (the same on every rank)"""
+    n = res["n_total"]
+    sizes = {".bwt": n + 1}
+    if "sa5" in res:
+        sizes[".sa"] = 5 * n
+    for key in ("ssa", "esa"):
+        if key in res:
+            sizes["." + key] = 10 * res["sampled_total"][key]
+    return sizes
+
+
+def create_outputs(path, res):
+    """ONE rank, before anybody writes: create every output file with its final size.  The reference opens its outputs
+    "wb" (pfbwt.cpp:132-141): whatever an earlier, longer run left under the same name is gone."""
+    import os
+    for ext, size in output_sizes(res).items():
+        with open(path + ext, "wb") as f:
+            f.truncate(size)
+            os.fsync(f.fileno())
+
+
+def write_outputs(ctx, path, res, group=None, create=None):
     """Every rank writes its pieces of <path>.bwt / .sa / .ssa / .esa at their file offsets (the reference's
     threads pwrite their ranges the same way, pfthreads.hpp:369-376).  Device buffers are streamed to the
-    file through the library's pinned staging buffers (pfp_pwrite_dev, C host code)."""
+    file through the library's pinned staging buffers (pfp_pwrite_dev, C host code).
+    Under torch.distributed rank 0 first creates the files at their final sizes (create_outputs) and all ranks meet
+    at a barrier; `create` = True / False overrides that choice (simulated ranks: the caller creates once)."""
+    import torch.distributed as dist
+    ranked = dist.is_available() and dist.is_initialized()
+    if create is None:
+        create = (dist.get_rank(group) == 0) if ranked else True
+    if create:
+        create_outputs(path, res)
+    if ranked:
+        dist.barrier(group)
     ctx.pwrite_dev(path + ".bwt", res["lo"], res["bwt"].data_ptr(), res["bwt"].numel())
     for key, ext in (("sa5", ".sa"), ("ssa", ".ssa"), ("esa", ".esa")):
         if key in res:
@@ -344,18 +397,29 @@ def run(ctx, shard, w=10, p=100, flags=0, halo=DEFAULT_HALO, group=None, shard_s
     rank, size = dist.get_rank(group), dist.get_world_size(group)
     gen = phases(ctx, shard, rank, size, w, p, flags, halo, shard_sa, dedup)
     reply = None
+    import time
+    log = []          # (kind, bytes this rank contributed, bytes it received, ms) per collective, in order
     try:
         while True:
             kind, payload = gen.send(reply)
+            t0 = time.perf_counter()
             if kind == "allgather":
                 reply = all_gather_var(payload, group)
+                sent = payload.numel() * payload.element_size()
             else:
                 assert kind == "alltoall"
                 reply = all_to_all_var(payload, group)
+                sent = sum(x.numel() * x.element_size() for x in payload)
             if shard.is_cuda:
                 torch.cuda.synchronize(shard.device)
+            log.append((kind, sent, sum(x.numel() * x.element_size() for x in reply), (time.perf_counter() - t0) * 1e3))
     except StopIteration as fin:
-        return fin.value
+        res = fin.value
+        res["stats"]["collectives"] = dict(
+            backend=dist.get_backend(group), ranks=size, count=len(log), ms=round(sum(x[3] for x in log), 3),
+            bytes_sent=sum(x[1] for x in log), bytes_received=sum(x[2] for x in log),
+            largest=[dict(kind=k, bytes_sent=b, bytes_received=r, ms=round(m, 3)) for k, b, r, m in sorted(log, key=lambda x: -x[2])[:6]])
+        return res
 
 
 def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True, dedup="alltoall", trim=False):

@@ -79,3 +79,34 @@ def test_textgen_is_deterministic(O):
     assert np.array_equal(a, b) and set(a.tolist()) <= set(b"ACGT")
     g = O.gen_fasta(1000, 2, 0.01, 3)
     assert bytes(g[:7]) == b">copy0\n" and g[-1] == 10
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no RANK in the environment must start N ranks itself - as a child process of a
+    parent that has not touched the GPU - instead of benchmarking one GPU under the name of N."""
+    import importlib
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("RANK", raising=False)
+    try:
+        bench.main()
+        assert False, "bench.main() went on in the parent"
+    except SystemExit as e:
+        assert e.code == 7          # the child's exit code is the parent's
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--master-addr" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -127,8 +127,11 @@ def test_baseline_flag_sets_across_ranks(O, pkg, R, cfg, width, tmp_path):
         assert {r["stats"]["glob"]["index_bits"] for r in res} == {64 if width else 32}
         _check_files(pkg, res, want, flags, n)
         base = str(tmp_path / "t")
-        for r in range(R - 1, -1, -1):          # any order: every piece lands at its own offset
-            d.write_outputs(ctxs[r], base, res[r])
+        for ext in (".bwt", ".sa", ".ssa", ".esa"):      # leftovers of an earlier, longer run under the same name must not survive
+            with open(base + ext, "wb") as f:
+                f.write(b"\xee" * (6 * n + 77))
+        for r in range(R - 1, -1, -1):          # any order: every piece lands at its own offset (one rank creates the files first)
+            d.write_outputs(ctxs[r], base, res[r], create=(r == R - 1))
         assert np.array_equal(np.fromfile(base + ".bwt", dtype=np.uint8), want["bwt"])
         if flags & pkg.FLAG_SA:
             assert np.array_equal(np.fromfile(base + ".sa", dtype=np.uint8), O.pack5(want["sa"]))
@@ -136,6 +139,10 @@ def test_baseline_flag_sets_across_ranks(O, pkg, R, cfg, width, tmp_path):
             assert np.array_equal(np.fromfile(base + ".ssa", dtype=np.uint8), O.pack5(want["ssa"].reshape(-1)))
         if flags & pkg.FLAG_ESA:
             assert np.array_equal(np.fromfile(base + ".esa", dtype=np.uint8), O.pack5(want["esa"].reshape(-1)))
+        # -S together with -s / -e is refused on every rank, before anything is exchanged (bigbwt:59-61)
+        for bad in (3, 5, 7):
+            with pytest.raises(pkg.PfpError):
+                d.simulate(ctxs, shards, w, p, bad, halo=8192)
     finally:
         for c in ctxs:
             c.close()
