@@ -150,6 +150,7 @@ struct DictIndex {        // per-position / per-word helper arrays over the dict
   DBuf<uint32_t> slen;       // [dsize] distance from i to that word's terminator
   DBuf<uint64_t> wend;       // [d+1] terminator position of word j (wend[d] = dsize-1)
   DBuf<uint32_t> lexrank;    // [d] 0-based lexicographic rank of word j
+  DBuf<uint64_t> wslot_lex;  // [d] SA(D) slot (global) of the whole-word suffix of the word of lexicographic rank q
 };
 void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix);      // needs D.woff / D.wlen
 // D.bytes/D.dsize given (words + 0x01, final 0x00): fills D.d, D.woff, D.wlen; at most max_words words expected

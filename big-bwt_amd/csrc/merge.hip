@@ -20,6 +20,7 @@
 namespace pfp {
 
 static constexpr int TB = 256;
+constexpr int kOffTileLog = 11;      // slots per offset tile (= one expand workgroup): 2048
 
 // ------------------------------------------------------------------ dictionary index
 
@@ -112,6 +113,7 @@ void compute_lexrank_from_slots(pfp_ctx *c, const Dictionary &D, const uint64_t 
   sort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
   hipLaunchKernelGGL(lexrank_from_order_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
   PFP_HIP(hipGetLastError());
+  ix.wslot_lex = std::move(keyo);      // the slots in ascending order = in the words' lexicographic order
 }
 
 // number of BWT positions the slots of `so` emit (sum of the occurrence counts of their words)
@@ -149,6 +151,11 @@ template uint64_t count_slot_outputs<uint32_t>(pfp_ctx *, const Dictionary &, co
 template uint64_t count_slot_outputs<uint64_t>(pfp_ctx *, const Dictionary &, const DictIndex &, const SuffixOrderT<uint64_t> &, int);
 
 template <class I>
+__global__ void widen_kernel(uint32_t n, const I *__restrict__ in, uint64_t *__restrict__ out) {
+  uint32_t j = BID * blockDim.x + threadIdx.x;
+  if (j < n) out[j] = (uint64_t)in[j];
+}
+template <class I>
 void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrderT<I> &so, DictIndex &ix) {
   const uint32_t d = (uint32_t)D.d;
   ix.lexrank.alloc(c, d);
@@ -158,6 +165,8 @@ void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrderT<I> &so, DictI
   hipLaunchKernelGGL(iota_u32_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, val.p);
   sort_pairs<I, uint32_t>(c, key.p, keyo.p, val.p, valo.p, d, 0, bits_for(D.dsize));
   hipLaunchKernelGGL(lexrank_from_order_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, valo.p, ix.lexrank.p);
+  ix.wslot_lex.alloc(c, d);
+  hipLaunchKernelGGL((widen_kernel<I>), gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, keyo.p, ix.wslot_lex.p);
   PFP_HIP(hipGetLastError());
 }
 template void compute_lexrank<uint32_t>(pfp_ctx *, const Dictionary &, SuffixOrderT<uint32_t> &, DictIndex &);
@@ -343,6 +352,124 @@ __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const I *
   }
   tile_full_count(p8, nk, t0, tile_full, first_full);
 }
+// ------------------------------------------------------------------ one gather per slot (BWT only / sparse SA)
+//
+// Random reads from HBM run at ~54 G accesses/s on this GPU whatever the element size up to 16 bytes (tools/microbench/
+// gather.hip; only tables of <= 4 MB, one XCD's L2, are faster), so the merge makes exactly ONE random access per
+// SA(D) slot and lets it carry everything any later kernel wants to know about the slot's suffix: a 16-byte record
+// per dictionary POSITION, written by a streaming pass, gathered once per slot, and laid down again as per-SLOT
+// arrays that every later kernel reads coalesced.  (Before: a 2-byte record per slot, then pos_word[sa[t]] ->
+// wrec[...] per member in unit_edges_kernel and per (occurrence, member) in hard_minor_kernel: 2-3 dependent random
+// sectors each, 9.5x / 34x the algorithmic bytes by the PMC counters of round 2.)
+//   occ   occurrences of the position's word, 0 = the suffix emits nothing (<= w long, pfbwt.cpp:151; final 0x00)
+//   first / last   smallest / largest BWT(P) position of the word's inverted list (ilist[ist], ilist[ist + occ - 1])
+//   pcsl  low byte: preceding char, 1 (EndOfWord) = the suffix is a whole word (pfbwt.cpp:153);
+//         bits 8..31: suffix length = distance to the word's terminator, capped at kSlCap (then: slen[] has it)
+struct alignas(16) PosRec { uint32_t occ, first, last, pcsl; };
+constexpr uint32_t kSlCap = 0xFFFFFFu;
+__global__ __launch_bounds__(256) void pprec16_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t d, int w,
+                                                      const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ slen,
+                                                      const uint4 *__restrict__ wrec /* WordRec as two uint4 */, PosRec *__restrict__ out) {
+  const uint64_t i = (uint64_t)BID * 256 + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t wd = pos_word[i], sl = slen[i];
+  PosRec r{0u, 0u, 0u, 0u};
+  if (wd < d && sl > (uint32_t)w) {
+    const uint4 wr = wrec[2 * (uint64_t)wd];      // {ist, occ, first, last}: consecutive positions share their word's record
+    const uint32_t pc = (i == 0) ? (uint32_t)kEndOfWord : (uint32_t)b[i - 1];
+    r = PosRec{wr.y, wr.z, wr.w, pc | ((sl < kSlCap ? sl : kSlCap) << 8)};
+  }
+  *reinterpret_cast<uint4 *>(out + i) = make_uint4(r.occ, r.first, r.last, r.pcsl);
+}
+
+// Per tile of 2048 slots (256 threads x 8 consecutive slots): gather the records, exclusive scan of the counts inside
+// the tile (loc[], tile total -> tsum[]), preceding chars, whole-word slots per tile, and the hard-group flags: a slot
+// whose preceding char differs from that of the slot before it IN THE SAME GROUP marks the group's head (members of a
+// group are contiguous, so "not all chars equal" is seen at some adjacent pair; pfbwt.cpp:524-536).  Replaces
+// slot_gather + slot_loc + group_flags: cnt[] (4 B per slot written and read again) is gone, pc[] is not re-read.
+template <class I>
+__global__ __launch_bounds__(256) void slot_records_kernel(uint64_t N, const I *__restrict__ sa, const I *__restrict__ grp,
+                                                           const PosRec *__restrict__ prec, uint32_t *__restrict__ loc,
+                                                           uint8_t *__restrict__ pc, uint32_t *__restrict__ sfirst,
+                                                           uint32_t *__restrict__ slast, uint32_t *__restrict__ ssl,
+                                                           uint64_t *__restrict__ tsum, uint32_t *__restrict__ overflow,
+                                                           uint32_t *__restrict__ tile_full, unsigned long long *__restrict__ first_full,
+                                                           uint8_t *__restrict__ hard) {
+  __shared__ uint64_t ws[4];
+  __shared__ uint32_t lpc[256];
+  __shared__ I lgrp[256];
+  if (((uint64_t)BID << kOffTileLog) > N) return;      // tiles 0 .. N >> 11 exist (a workgroup of the padded last grid row)
+  const uint64_t t0 = ((uint64_t)BID << kOffTileLog) + (uint64_t)threadIdx.x * 8;
+  const int nk = t0 >= N ? 0 : ((N - t0) >= 8 ? 8 : (int)(N - t0));
+  I idx[8], g8[8];
+  if (nk == 8) {
+    const Idx8<I> v8 = *reinterpret_cast<const Idx8<I> *>(sa + t0), w8 = *reinterpret_cast<const Idx8<I> *>(grp + t0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { idx[k] = v8.v[k]; g8[k] = w8.v[k]; }
+  } else {
+    for (int k = 0; k < 8; k++) { idx[k] = k < nk ? sa[t0 + k] : (I)0; g8[k] = k < nk ? grp[t0 + k] : IdxTraits<I>::kNone; }
+  }
+  uint4 r8[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) r8[k] = k < nk ? *reinterpret_cast<const uint4 *>(prec + idx[k]) : make_uint4(0u, 0u, 0u, 0u);
+  // the slot before this thread's first one: the previous thread's last slot, or (first thread) the last slot of the tile before
+  uint32_t p8[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) p8[k] = r8[k].w & 0xffu;
+  lpc[threadIdx.x] = p8[7]; lgrp[threadIdx.x] = g8[7];
+  uint32_t prev_pc = 0; I prev_g = IdxTraits<I>::kNone;
+  if (threadIdx.x == 0 && t0 > 0 && nk) { prev_pc = prec[sa[t0 - 1]].pcsl & 0xffu; prev_g = grp[t0 - 1]; }
+  // counts: exclusive scan inside the tile
+  uint64_t own = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) own += r8[k].x;
+  uint64_t inc = own;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+  if (lane == 63) ws[wv] = inc;
+  __syncthreads();
+  if (threadIdx.x > 0) { prev_pc = lpc[threadIdx.x - 1]; prev_g = lgrp[threadIdx.x - 1]; }
+  uint64_t run = inc - own;
+  for (int q = 0; q < wv; q++) run += ws[q];
+  uint32_t o8[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { o8[k] = (uint32_t)run; run += r8[k].x; }
+  // (loc[] is padded to whole tiles: the slots past N get the running total, slot N's is what slot_off(N) reads)
+  *reinterpret_cast<uint4 *>(loc + t0) = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+  *reinterpret_cast<uint4 *>(loc + t0 + 4) = make_uint4(o8[4], o8[5], o8[6], o8[7]);
+  if (threadIdx.x == 255) {
+    tsum[BID] = run;
+    if (run >> 32) atomicOr(overflow, 1u);      // a tile's offsets would not fit 32 bits
+  }
+  if (nk == 8) {
+    *reinterpret_cast<uint2 *>(pc + t0) = make_uint2(p8[0] | (p8[1] << 8) | (p8[2] << 16) | (p8[3] << 24),
+                                                     p8[4] | (p8[5] << 8) | (p8[6] << 16) | (p8[7] << 24));
+    if (sfirst) {
+      *reinterpret_cast<uint4 *>(sfirst + t0) = make_uint4(r8[0].y, r8[1].y, r8[2].y, r8[3].y);
+      *reinterpret_cast<uint4 *>(sfirst + t0 + 4) = make_uint4(r8[4].y, r8[5].y, r8[6].y, r8[7].y);
+      *reinterpret_cast<uint4 *>(slast + t0) = make_uint4(r8[0].z, r8[1].z, r8[2].z, r8[3].z);
+      *reinterpret_cast<uint4 *>(slast + t0 + 4) = make_uint4(r8[4].z, r8[5].z, r8[6].z, r8[7].z);
+    }
+    if (ssl) {
+      *reinterpret_cast<uint4 *>(ssl + t0) = make_uint4(r8[0].w >> 8, r8[1].w >> 8, r8[2].w >> 8, r8[3].w >> 8);
+      *reinterpret_cast<uint4 *>(ssl + t0 + 4) = make_uint4(r8[4].w >> 8, r8[5].w >> 8, r8[6].w >> 8, r8[7].w >> 8);
+    }
+  } else {
+    for (int k = 0; k < nk; k++) {
+      pc[t0 + k] = (uint8_t)p8[k];
+      if (sfirst) { sfirst[t0 + k] = r8[k].y; slast[t0 + k] = r8[k].z; }
+      if (ssl) ssl[t0 + k] = r8[k].w >> 8;
+    }
+  }
+  // hard groups: a differing char next to a member of the same group
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (k < nk && p8[k] != 0 && g8[k] == prev_g && p8[k] != prev_pc) hard[g8[k]] = 1;
+    prev_pc = p8[k]; prev_g = g8[k];
+  }
+  tile_full_count(p8, nk, t0, tile_full, first_full);
+}
+
 // whole words are singleton groups and stand in SA(D) in the words' lexicographic order: the q-th whole-word slot
 // belongs to the word of rank q.  Rank of the first whole-word slot held (0 unless the slots are one rank's range).
 template <class I>
@@ -397,6 +524,9 @@ struct MergeArgsT {
   const I *sa, *grp;
   const uint32_t *slen, *ist, *pos_word, *wistart;
   const WordRec *wrec;
+  // per-slot copies of the gathered position records (slot_records_kernel; null: look the word up through sa / pos_word):
+  // smallest / largest BWT(P) position of the slot's word, suffix length (kSlCap = look it up in slen[])
+  const uint32_t *sfirst, *slast, *ssl;
   const uint8_t *pc, *hard, *gmaj;     // gmaj[g]: majority char of hard group g when the minority path places the rest (else 0)
   const uint64_t *tbase; const uint32_t *loc;    // output offset of slot t = tbase[t >> 11] + loc[t] (slot_off)
   const uint32_t *ilist; const uint8_t *bwlast; const uint64_t *bwsai;
@@ -433,7 +563,6 @@ __device__ __forceinline__ bool sa_wanted(const MergeArgsT<I> &a, uint64_t x) { 
 // Exclusive prefix of the per-slot counts, kept as a 64-bit base per 2048 slots (= one expand workgroup) and a
 // 32-bit offset inside the tile: 4 bytes per slot to write and read instead of 8, and the N-long scan
 // becomes one streaming tile kernel plus a scan over N/2048 sums.
-constexpr int kOffTileLog = 11;
 template <class I>
 __device__ __forceinline__ uint64_t slot_off(const MergeArgsT<I> &a, uint64_t t) { return a.tbase[t >> kOffTileLog] + a.loc[t]; }
 
@@ -444,6 +573,18 @@ __device__ __forceinline__ uint8_t fix_char(uint8_t ch) { return ch == kDollar ?
 template <class I>
 __device__ __forceinline__ uint32_t slot_ist(const MergeArgsT<I> &a, uint64_t t) {
   return a.ist ? a.ist[t] : a.wistart[a.pos_word[a.sa[t]]];
+}
+
+// what the hard-group / unit-edge kernels ask about the word of slot t: from the per-slot arrays when the slot records
+// were gathered (one coalesced read), else through sa -> pos_word -> the word's record (three dependent random reads)
+template <class I>
+__device__ __forceinline__ uint32_t slot_first(const MergeArgsT<I> &a, uint64_t t) { return a.sfirst ? a.sfirst[t] : a.wrec[a.pos_word[a.sa[t]]].first; }
+template <class I>
+__device__ __forceinline__ uint32_t slot_last(const MergeArgsT<I> &a, uint64_t t) { return a.slast ? a.slast[t] : a.wrec[a.pos_word[a.sa[t]]].last; }
+template <class I>
+__device__ __forceinline__ uint64_t slot_slen(const MergeArgsT<I> &a, uint64_t t) {
+  if (a.ssl) { const uint32_t v = a.ssl[t]; if (v != kSlCap) return v; }
+  return a.slen[a.sa[t]];
 }
 
 // Expansion.  One workgroup owns kSlots consecutive SA(D) slots, i.e. one contiguous range of
@@ -662,6 +803,29 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(MergeArgsT<I> a, cons
   }
 }
 
+// Sparse SA mode, whole words: every occurrence of a whole word carries its own char (bwlast), so any of the P positions
+// they emit can be a run boundary.  One lane per occurrence e of the inverted lists laid end to end (ilist[1 + e], read
+// coalesced): its word is the one of lexicographic rank q with istart_lex[q] <= e (bisection over d entries that stay in
+// L2), the word's slot is wslot_lex[q], the position is that slot's offset plus the occurrence's index in its list.
+// Replaces the second launch of expand_kernel over all N slots (every tile staged again to find its dozen whole words).
+template <class I>
+__global__ __launch_bounds__(256) void word_sa_kernel(MergeArgsT<I> a, uint64_t P, const uint64_t *__restrict__ wslot_lex,
+                                                      uint64_t slot_base, const uint32_t *__restrict__ wlen_lex_word,
+                                                      const uint32_t *__restrict__ word_len) {
+  const uint64_t e = (uint64_t)BID * 256 + threadIdx.x;
+  if (e >= P) return;
+  uint32_t lo = 0, hi = a.d;                 // istart_lex[lo] <= e < istart_lex[hi]  (istart_lex[d] = P)
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)a.istart_lex[mid] <= e) lo = mid; else hi = mid; }
+  const uint64_t gs = wslot_lex[lo];
+  if (gs < slot_base || gs - slot_base >= a.N) return;      // (multi-GPU: the word's slot belongs to another rank's range)
+  const uint64_t t = gs - slot_base;
+  const uint64_t x = slot_off(a, t) + (e - (uint64_t)a.istart_lex[lo]);
+  if (!sa_wanted(a, x)) return;
+  const uint64_t pos = a.ilist[e + 1];       // +1: ilist[0] is the EOS symbol (pfbwt.cpp:389)
+  (void)wlen_lex_word; (void)word_len;
+  sa_put(a, x, a.pos_base + x == 0 ? a.n_out_global - 1 : a.bwsai[pos] - slot_slen(a, t));
+}
+
 // Sparse SA mode.  A *unit* is a slot that emits, or a group of slots of equal suffixes (several words share the
 // suffix): its output range is one fill char c (unknown for hard groups), so a run of the BWT can start only at
 // the unit's first position - when the unit before ends in a different char - and end only at its last position.
@@ -706,11 +870,9 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
   uint32_t mn = 0xFFFFFFFFu, mx = 0;
   uint64_t mysl = 0;      // length of the (common) suffix: distance to the word's terminator
   if (unit && (nf || nlz)) {
-    const I myi = a.sa[t];
-    const WordRec wr = a.wrec[a.pos_word[myi]];
-    if (nf) mn = wr.first;
-    if (nlz) mx = wr.last;
-    mysl = wr.wend - (uint64_t)myi;
+    if (nf) mn = slot_first(a, t);
+    if (nlz) mx = slot_last(a, t);
+    if (need_first || need_last) mysl = slot_slen(a, t);      // (equal suffixes: the same for every member; only the edge lanes store)
   }
   // segmented reductions: min towards the first lane of the unit, max towards its last lane
 #pragma unroll
@@ -737,7 +899,7 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
       const uint64_t m = m0 + lane;
       const bool mine = m < a.N && a.grp[m] == (I)g63;       // (members are contiguous; a slot of the group emits)
       uint32_t f = 0xFFFFFFFFu;
-      if (mine) f = a.wrec[a.pos_word[a.sa[m]]].first;
+      if (mine) f = slot_first(a, m);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(f, o, 64); f = v < f ? v : f; }
       ext = f < ext ? f : ext;
@@ -753,7 +915,7 @@ __global__ __launch_bounds__(256) void unit_edges_kernel(MergeArgsT<I> a) {
     for (uint64_t m0 = g0; m0 < wbase; m0 += 64) {
       const uint64_t m = m0 + lane;
       uint32_t l = 0;
-      if (m < wbase) l = a.wrec[a.pos_word[a.sa[m]]].last;
+      if (m < wbase) l = slot_last(a, m);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(l, o, 64); l = v > l ? v : l; }
       ext = l > ext ? l : ext;
@@ -856,7 +1018,9 @@ __global__ void count_unset_kernel(const uint64_t *__restrict__ v, uint64_t n, u
 // BWT(P) position over all lists): those and the group's two ends are the only places a run can start or end.
 // Groups where no char dominates and that fit the LDS kernels keep the old path (fallback list).
 struct HardGroupInfo { uint64_t g; uint64_t E; uint32_t k; uint32_t minor; };
-struct MinorMember { uint64_t g; uint32_t k, m; };      // member m (of k) of the hard group at head slot g does not carry the majority char
+// member m (of k) of the hard group at head slot g does not carry the majority char; roff: index of its first occurrence among
+// all minority occurrences (where hard_minor_kernel keeps its record for the SA round - no counter to contend for)
+struct MinorMember { uint64_t g; uint32_t k, m; uint64_t roff; };
 // sparse SA: what the second pass needs of a placed minority occurrence - its output position, its BWT(P) position
 // and those of its neighbours in the merged order (flags bit 0 / 1: there is a predecessor / successor), suffix length
 struct MinorRec { uint64_t o; uint32_t pos, pred, succ, flags, sl, pad; };
@@ -924,29 +1088,33 @@ __global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, con
 // the minority members of all groups, laid end to end (offsets = prefix sums of their count per group)
 template <class I>
 __global__ __launch_bounds__(256) void hard_minor_fill_kernel(MergeArgsT<I> a, const HardGroupInfo *__restrict__ info, uint64_t nH,
-                                                              const uint64_t *__restrict__ mm_off, const uint8_t *__restrict__ gmaj,
-                                                              MinorMember *__restrict__ out) {
+                                                              const uint64_t *__restrict__ mm_off, const uint64_t *__restrict__ minor_off,
+                                                              const uint8_t *__restrict__ gmaj, MinorMember *__restrict__ out) {
   const uint64_t h = (uint64_t)BID * 256 + threadIdx.x;
   if (h >= nH) return;
   uint64_t o = mm_off[h];
   if (mm_off[h + 1] == o) return;
   const HardGroupInfo gi = info[h];
   const uint32_t maj = gmaj[gi.g];
-  for (uint32_t m = 0; m < gi.k; m++)
-    if ((uint32_t)fix_char(a.pc[gi.g + m]) != maj) out[o++] = MinorMember{gi.g, gi.k, m};
+  uint64_t r = minor_off[h], prev = slot_off(a, gi.g);
+  for (uint32_t m = 0; m < gi.k; m++) {
+    const uint64_t nxt = slot_off(a, gi.g + m + 1);
+    if ((uint32_t)fix_char(a.pc[gi.g + m]) != maj) { out[o++] = MinorMember{gi.g, gi.k, m, r}; r += nxt - prev; }
+    prev = nxt;
+  }
 }
 // eight lanes per minority member: its occurrences (usually one) are ranked one after the other - own index +
 // lower_bound in every other member's inverted list, the group's members shared among the lanes (every lane fetches
 // the inverted-list start of its members and bisects there) - rank, predecessor and successor combined by shuffles
 template <class I>
 __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const MinorMember *__restrict__ mem, uint64_t total,
-                                                         MinorRec *__restrict__ recs, unsigned long long *__restrict__ nrecs) {
+                                                         MinorRec *__restrict__ recs) {
   const int l8 = threadIdx.x & 7;
   const uint64_t rounds = (total + GDIM * 32 - 1) / (GDIM * 32);      // every lane runs the same number of rounds (shuffles inside)
   for (uint64_t it = 0; it < rounds; it++) {
     const uint64_t q = (it * GDIM + BID) * 32 + (threadIdx.x >> 3);
     const bool live = q < total;
-    MinorMember mmv{0, 0, 0};
+    MinorMember mmv{0, 0, 0, 0};
     if (live) mmv = mem[q];
     const uint64_t g = mmv.g;
     const uint32_t k = mmv.k, me = mmv.m;
@@ -981,12 +1149,14 @@ __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const 
               if (j + 1 < my_occ) { sv = a.ilist[my_ist + j + 1]; hs = true; }
             }
           } else {
-            // the member's word record answers for a list that lies wholly on one side of pos (a variant that
-            // occurs once: always); only a list that straddles pos is bisected
-            const WordRec wr = a.wrec[a.pos_word[a.sa[g + m]]];
-            if (pos < wr.first) { lb = 0; sv = wr.first; hs = true; }
-            else if (pos > wr.last) { lb = wr.occ; pv = wr.last; hp = true; }
+            // the member's smallest / largest BWT(P) position (per-slot arrays: the members of a group are consecutive
+            // slots, eight lanes read eight neighbours) answer for a list that lies wholly on one side of pos (a variant
+            // that occurs once: always); only a list that straddles pos is looked up and bisected
+            const uint32_t mfirst = slot_first(a, g + m), mlast = slot_last(a, g + m);
+            if (pos < mfirst) { lb = 0; sv = mfirst; hs = true; }
+            else if (pos > mlast) { lb = (uint32_t)(slot_off(a, g + m + 1) - slot_off(a, g + m)); pv = mlast; hp = true; }
             else {
+              const WordRec wr = a.wrec[a.pos_word[a.sa[g + m]]];
               const uint32_t *lst = a.ilist + wr.ist;
               uint32_t l2 = 1, h2 = wr.occ - 1;          // # entries < pos: lst[0] < pos < lst[occ - 1]
               while (l2 < h2) { const uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
@@ -1011,7 +1181,7 @@ __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const 
       const uint64_t o = base + r;
       if (o >= a.out_lo && o < a.out_hi) a.bwt[o] = mych;
       if (a.want_sa)       // (also when the occurrence lies just outside this rank's slice: its neighbours may be inside)
-        recs[atomicAdd(nrecs, 1ull)] = MinorRec{o, pos, pred, succ, has_pred | (has_succ << 1), (uint32_t)sl, 0u};
+        recs[mmv.roff + j] = MinorRec{o, pos, pred, succ, has_pred | (has_succ << 1), (uint32_t)sl, 0u};
     }
   }
 }
@@ -1353,50 +1523,62 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   if (samode != SA_DENSE) wrec.alloc(c, d);      // the minority path of the hard groups and (sparse SA) the unit edges
   hipLaunchKernelGGL(wistart_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, D.wocc.p, pb.ilist.p,
                      ix.wend.p, wistart.p, wrec.p);
-  DBuf<uint16_t> pp16;
   DBuf<uint64_t> pp64;
-  DBuf<uint32_t> cnt(c, N + 8), ist;
+  DBuf<PosRec> prec;
+  DBuf<uint32_t> cnt, ist, sfirst, slast, ssl;
   // records already sit at their slots - unless most slots were re-ordered after the first round (a
   // dictionary of near-identical variants), where fetching each such record costs more than the gather
   const bool from_keys = !dense && so.paybits == 16 && so.skeys.p && so.n_refined * 5 < N;
-  if (dense) { ist.alloc(c, N + 8); pp64.alloc(c, NP); } else if (!from_keys) pp16.alloc(c, NP);
+  // BWT only / sparse SA without records in the keys: ONE 16-byte gather per slot (slot_records_kernel)
+  const bool fused = !dense && !from_keys;
+  if (dense) { ist.alloc(c, N + 8); pp64.alloc(c, NP); }
+  if (!fused) { cnt.alloc(c, N + 8); PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream)); }
   DBuf<uint8_t> pc(c, N + 8), hard(c, N);
   const uint64_t ntile = (N >> kOffTileLog) + 1;        // covers slot index N (one past the last)
   DBuf<uint32_t> loc(c, ntile << kOffTileLog), ovf(c, 1);
   DBuf<uint64_t> tsum(c, ntile + 1), tbase(c, ntile + 1);
-  PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream));
   hard.zero();
   DBuf<uint32_t> tile_full(c, ntile + 1), fullbase(c, ntile + 1), fullbase0(c, 1);
   DBuf<unsigned long long> first_full(c, 1);
   tile_full.zero();
   PFP_HIP(hipMemsetAsync(first_full.p, 0xFF, 8, c->stream));
+  ovf.zero();
+  PFP_HIP(hipMemsetAsync(tsum.p + ntile, 0, 8, c->stream));
+  if (fused) {
+    prec.alloc(c, NP);
+    { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + 16));
+      hipLaunchKernelGGL(pprec16_kernel, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, D.bytes.p, NP, d, w, ix.pos_word.p, ix.slen.p,
+                         reinterpret_cast<const uint4 *>(wrec.p), prec.p); }
+    // per-slot copies of what the unit-edge / minority kernels ask about a slot's word (read coalesced there)
+    sfirst.alloc(c, ntile << kOffTileLog); slast.alloc(c, ntile << kOffTileLog);
+    if (samode == SA_SPARSE) ssl.alloc(c, ntile << kOffTileLog);
+    { KScope ks(c, "pfp::slot_gather_kernel", N * (2 * sizeof(I) + 16 + 4 + 1 + 8 + (ssl.p ? 4 : 0)));
+      hipLaunchKernelGGL(slot_records_kernel<I>, gdim((unsigned)ntile), gdim(256), 0, c->stream, N, so.sa.p, so.grp.p, prec.p, loc.p, pc.p,
+                         sfirst.p, slast.p, ssl.p, tsum.p, ovf.p, tile_full.p, first_full.p, hard.p); }
+    prec.release();
+  } else {
   if (from_keys) {
     KScope ks(c, "pfp::slot_gather_kernel", N * (8 + 1 + 5));
     hipLaunchKernelGGL(slot_payload_kernel<I>, gdim(cdiv(cdiv64(N, 8), 256)), gdim(256), 0, c->stream, N, so.sa.p, so.skeys.p,
                        so.refined.p, D.bytes.p, ix.pos_word.p, ix.slen.p, D.wocc.p, d, w, cnt.p, pc.p, tile_full.p, first_full.p);
   } else {
-  { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + (dense ? 8 : 2)));
-    if (dense) hipLaunchKernelGGL(pprec_kernel<uint64_t>, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, D.bytes.p, NP, d, w,
-                                  ix.pos_word.p, ix.slen.p, D.wocc.p, pp64.p);
-    else hipLaunchKernelGGL(pprec_kernel<uint16_t>, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, D.bytes.p, NP, d, w,
-                            ix.pos_word.p, ix.slen.p, D.wocc.p, pp16.p); }
-  { KScope ks(c, "pfp::slot_gather_kernel", N * (sizeof(I) + 5 + (dense ? 12 : 2)));
+  { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + 8));
+    hipLaunchKernelGGL(pprec_kernel<uint64_t>, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, D.bytes.p, NP, d, w,
+                       ix.pos_word.p, ix.slen.p, D.wocc.p, pp64.p); }
+  { KScope ks(c, "pfp::slot_gather_kernel", N * (sizeof(I) + 5 + 12));
     const dim3 grid = gdim(cdiv(cdiv64(N, 8), 256));
-    if (dense) hipLaunchKernelGGL((slot_gather_kernel<uint64_t, I>), grid, gdim(256), 0, c->stream, N, so.sa.p, pp64.p,
-                                  ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, ist.p, tile_full.p, first_full.p);
-    else hipLaunchKernelGGL((slot_gather_kernel<uint16_t, I>), grid, gdim(256), 0, c->stream, N, so.sa.p, pp16.p,
-                            ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, (uint32_t *)nullptr, tile_full.p, first_full.p); }
+    hipLaunchKernelGGL((slot_gather_kernel<uint64_t, I>), grid, gdim(256), 0, c->stream, N, so.sa.p, pp64.p,
+                       ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, ist.p, tile_full.p, first_full.p); }
   }
-  pp16.release(); pp64.release();
-  ovf.zero();
-  PFP_HIP(hipMemsetAsync(tsum.p + ntile, 0, 8, c->stream));
+  pp64.release();
   { KScope ks(c, "pfp::slot_loc_kernel", N * 8);
     hipLaunchKernelGGL(slot_loc_kernel, gdim((unsigned)ntile), gdim(256), 0, c->stream, cnt.p, N, loc.p, tsum.p, ovf.p); }
+  { KScope ks(c, "pfp::group_flags_kernel", N * 5);
+    hipLaunchKernelGGL(group_flags_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, so.grp.p, pc.p, dense ? 1 : 0, hard.p); }
+  }
   exclusive_sum_u64(c, tsum.p, tbase.p, ntile + 1);
   exclusive_sum_u32(c, tile_full.p, fullbase.p, ntile + 1);
   hipLaunchKernelGGL(full_base0_kernel<I>, dim3(1), dim3(1), 0, c->stream, first_full.p, so.sa.p, ix.pos_word.p, ix.lexrank.p, fullbase0.p);
-  { KScope ks(c, "pfp::group_flags_kernel", N * 5);
-  hipLaunchKernelGGL(group_flags_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, so.grp.p, pc.p, dense ? 1 : 0, hard.p); }
   PFP_REQUIRE(read_scalar(c, ovf.p) == 0, PFP_ELIMIT, "2048 consecutive suffix-array slots emit 2^32 or more BWT positions");
   const uint64_t n_out = read_scalar(c, tbase.p + ntile);
   PFP_REQUIRE(expect_n_out == 0 || n_out == expect_n_out, PFP_EFORMAT,
@@ -1410,6 +1592,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
   a.sa = so.sa.p; a.slen = ix.slen.p; a.grp = so.grp.p; a.ist = dense ? ist.p : nullptr;
   a.pos_word = ix.pos_word.p; a.wistart = wistart.p; a.wrec = wrec.p;
+  a.sfirst = sfirst.p; a.slast = slast.p; a.ssl = ssl.p;
   a.pc = pc.p; a.hard = hard.p; a.tbase = tbase.p; a.loc = loc.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p;
   a.istart_lex = istart_lex.p; a.fullbase = fullbase.p; a.fullbase0 = fullbase0.p;
@@ -1456,8 +1639,8 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     if (n_mm) {
       mm_list.alloc(c, n_mm);
       KScope ks(c, "pfp::hard_minor_fill_kernel", n_heads * 40 + n_mm * 16);
-      hipLaunchKernelGGL(hard_minor_fill_kernel<I>, gdim(cdiv(n_heads, 256)), gdim(256), 0, c->stream, a, ginfo.p, n_heads, mm_off.p, gmaj.p,
-                         mm_list.p);
+      hipLaunchKernelGGL(hard_minor_fill_kernel<I>, gdim(cdiv(n_heads, 256)), gdim(256), 0, c->stream, a, ginfo.p, n_heads, mm_off.p,
+                         minor_off.p, gmaj.p, mm_list.p);
     }
     n_fallback = count_flags(c, fallback.p, n_heads);
     n_minor = read_scalar(c, minor_off.p + n_heads);
@@ -1492,13 +1675,11 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   };
   run_expand();
   DBuf<MinorRec> recs;
-  DBuf<unsigned long long> nrecs(c, 1);
-  nrecs.zero();
   if (n_mm) {
     if (sparse) recs.alloc(c, n_minor + 1);
     KScope ks(c, "pfp::hard_minor_kernel", n_minor * 64);
     hipLaunchKernelGGL(hard_minor_kernel<I>, gdim((unsigned)std::min<uint64_t>(cdiv64(n_mm, 32), (uint64_t)c->n_cu * 64)), gdim(256), 0,
-                       c->stream, a, mm_list.p, n_mm, recs.p, nrecs.p);
+                       c->stream, a, mm_list.p, n_mm, recs.p);
   }
   PFP_HIP(hipGetLastError());
   int gpb = 64;      // groups per wave batch: down to 8 while that still leaves every wave of the launch a batch
@@ -1604,12 +1785,15 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     a.sa_c = out.sa_c.p;
   }
   a.pass = PASS_SA;
-  run_expand();
+  if (ix.wslot_lex.p && pb.P) {      // whole words: one lane per occurrence of the inverted lists
+    KScope ks(c, "pfp::word_sa_kernel", pb.P * (4 + 8 + 8 + 8));
+    hipLaunchKernelGGL(word_sa_kernel<I>, gdim(cdiv(pb.P, 256)), gdim(256), 0, c->stream, a, pb.P, ix.wslot_lex.p, so.slot_base,
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+  } else run_expand();
   { KScope ks(c, "pfp::unit_edges_kernel", N * (1 + sizeof(I) * 2 + 4));
     hipLaunchKernelGGL(unit_edges_kernel<I>, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, a); }
   if (n_mm) {
-    const uint64_t nr = read_scalar(c, (const uint64_t *)nrecs.p);
-    PFP_REQUIRE(nr <= n_minor, PFP_EHIP, "minority placement recorded more occurrences than were counted");
+    const uint64_t nr = n_minor;      // one record per minority occurrence, at its precomputed index (MinorMember::roff)
     if (nr) hipLaunchKernelGGL(hard_minor_sa_kernel<I>, gdim(cdiv(nr, 256)), gdim(256), 0, c->stream, a, recs.p, nr);
   }
   if (n_fallback) {      // the groups the LDS kernels ranked: the same ranks again, SA values this time (queues as they stand)
