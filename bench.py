@@ -62,8 +62,99 @@ def cpu_baseline(text_host, w, p, flags, O, threads):
         kind, detail, cores = "port", {}, 1
         outs = {"bwt": o["bwt"]}
     return dict(value=round(len(text_host) / secs / 1e6, 3), unit="MB/s", cores=cores, kind=kind,
-                sample=f"first {len(text_host)} bytes of the same text, same flags, -t {threads}; stage seconds: {detail}",
+                sample=f"{len(text_host)} bytes of the same text (the first, = all of it unless --cpu-sample-mb says otherwise), same flags, -t {threads}; stage seconds: {detail}",
                 seconds=round(secs, 3)), outs
+
+
+def pass_rows(st, w, flags, n_slice, P_merge, D_slots, R, t_hash, t_formats, ms_per_step):
+    """algorithmic bytes of the scan, phrase-hash and merge passes over their measured times"""
+    P, H, nn = st["n_phrases"], st["hard_chars"], st["n"]
+    b_scan = nn + 8 * P
+    b_hash = nn + w * P + 8 * P
+    b_merge = n_slice + 12 * D_slots + 5 * (P_merge + 1) + 8 * H
+    if flags & 1:
+        b_merge += 10 * n_slice
+    if flags & 6:
+        b_merge += 10 * (R.get("ssa", 0) + R.get("esa", 0)) + 5 * n_slice
+    t_merge = st["ms_merge"] + t_formats
+
+    def row(nbytes, ms):
+        if ms <= 0:
+            return None
+        g = nbytes / (ms * 1e-3) / 1e9
+        return dict(algo_bytes=int(nbytes), ms=round(ms, 3), achieved_GBps=round(g, 1), frac=round(g / HBM_PEAK_GBS, 4))
+    passes = {"scan (K1+K2: n + 8P)": row(b_scan, st["ms_scan"]),
+              "phrase hash (n + wP + 8P)": row(b_hash, t_hash),
+              "merge ((n+1) + 12|D| + 5(P+1) + 8H [+ SA terms]; incl. run sampling / packing)": row(b_merge, t_merge),
+              "scan + merge": row(b_scan + b_merge, st["ms_scan"] + t_merge),
+              "end to end floor (2n)": row(2 * nn, ms_per_step)}
+    bad = [k for k, v in passes.items() if v and v["frac"] > 1.0]
+    assert not bad, f"pass fraction above 1 ({bad}): the timed figure is not the work"
+    return passes
+
+
+def north_star_leg(pkg, synth, ctx, dev, steps=2):
+    """the north star's own workload, driver-visible: >= 10 GB of repetitive FASTA (1024 mutated copies, 12.6 GB) -> .bwt +
+    .ssa on ONE GPU, `steps` timed steps after one warm-up, outputs compared with the digests of the real reference's files
+    (tests/golden/golden_full.json: 42 min of oracle/_ref on one core in the build container), pass fractions as above."""
+    name = "huge_s"
+    wl = synth.WORKLOADS[name]
+    w, p, flags = wl["w"], wl["p"], wl["flags"]
+    t_gen = time.perf_counter()
+    text = synth.workload_text_torch(dev, name)
+    n = text.numel()
+    bwt = torch.empty(n + 1 + 16, dtype=torch.uint8, device=dev)
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t_gen
+    outs = {}
+
+    def step():
+        for ptr, _ in outs.values():
+            ctx.dev_free(ptr)
+        outs.clear()
+        used, o = ctx.bigbwt_formats_dev(text.data_ptr(), n, bwt.data_ptr(), w, p, flags)
+        outs.update(o)
+        return used
+    step()
+    torch.cuda.synchronize()
+    pc0 = ctx.pool_counters()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    pc1 = ctx.pool_counters()
+    ctx.set_kernel_trace(True)
+    ctx.set_profiling(True)
+    step()
+    torch.cuda.synchronize()
+    st = ctx.stats()
+    kt = {r["name"]: r["total_ms"] for r in ctx.kernel_trace()}
+    ctx.set_profiling(False)
+    ctx.set_kernel_trace(False)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_full.json"))).get(name)
+    digests = None
+    if gold and gold["n"] == n:
+        digests = {"text": sha_dev(text) == gold["text_sha256"], "bwt": sha_dev(bwt[: n + 1]) == gold["bwt_sha256"]}
+        for key in ("ssa", "esa"):
+            if key in outs and key + "_sha256" in gold:
+                digests[key] = hashlib.sha256(ctx.fetch_dev(*outs[key]).tobytes()).hexdigest() == gold[key + "_sha256"]
+    R = {k: outs[k][1] // 10 for k in ("ssa", "esa") if k in outs}
+    t_formats = sum(kt.get(k, 0.0) for k in ("pfp::run_count_kernel", "pfp::run_place_kernel", "pfp::pack5_kernel"))
+    passes = pass_rows(st, w, flags, st["n"] + 1, st["n_phrases"], st["dict_size"], R, kt.get("pfp::phrase_hash_kernel", 0.0), t_formats, ms)
+    mem = ctx.mem_stats()
+    top = sorted(kt.items(), key=lambda x: -x[1])[:8]
+    res = dict(workload=wl["desc"], bytes=n, steps=steps, ms_per_step=round(ms, 2), value=round(n / ms / 1e3, 1), unit="MB/s",
+               outputs=["bwt"] + sorted(outs), outputs_match_reference_digests=digests, roofline_passes=passes,
+               phases_ms={k: round(st[k], 2) for k in ("ms_scan", "ms_phrases", "ms_sa_dict", "ms_sa_parse", "ms_merge")},
+               top_kernels_ms={k: round(v, 2) for k, v in top}, words=st["n_words"], dict_bytes=st["dict_size"], phrases=st["n_phrases"], runs=R,
+               peak_device_bytes=mem["peak"], driver_allocations_in_timed_steps=pc1["driver_allocs"] - pc0["driver_allocs"],
+               text_generation_s=round(gen_s, 2))
+    for ptr, _ in outs.values():
+        ctx.dev_free(ptr)
+    del text, bwt
+    return res
 
 
 def launch_ranks(n):
@@ -89,7 +180,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None)
-    ap.add_argument("--cpu-sample-mb", type=float, default=100.0, help="prefix of the text the reference is timed on (0: whole text)")
+    ap.add_argument("--cpu-sample-mb", type=float, default=0.0, help="prefix of the text the reference is timed on (0, the default: the whole text, ~100 s at -t 16)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="-t N of the reference's threaded parser / merge (a one-GPU box gives 16 host cores per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-boundary", action="store_true")
     ap.add_argument("--multi", default="collection", choices=["collection", "independent"],
@@ -272,39 +364,16 @@ def main():
         # ---- per-pass fractions with SURVEY.md 8(d)'s algorithmic-byte formulas over the synced phase times of the profiled step
         # (N > 1: THIS RANK's share of every pass over this rank's phase timers - its shard and own phrases for the scan
         #  and the hash, its slice of the BWT, the range of SA(D) it holds and the whole parse it reads for the merge)
-        P, D_, H = st["n_phrases"], st["dict_size"], st["hard_chars"]
-        nn = st["n"]
         R = {k: last.get(k + "_bytes", 0) // 10 for k in ("ssa", "esa")}
-        n_slice, P_merge = nn + 1, P
+        n_slice, P_merge, D_ = st["n"] + 1, st["n_phrases"], st["dict_size"]
         if collection:
             res = last["r"]
             n_slice, P_merge, D_ = res["hi"] - res["lo"], dstats["phrases_total"], dstats["glob"]["slots"]
-            R = {k: res[k].numel() // 10 for k in ("ssa", "esa") if k in res and res[k] is not None}
-            R = {k: R.get(k, 0) for k in ("ssa", "esa")}
-        b_scan = nn + 8 * P
-        b_hash = nn + w * P + 8 * P
-        b_merge = n_slice + 12 * D_ + 5 * (P_merge + 1) + 8 * H
-        if flags & 1:
-            b_merge += 10 * n_slice
-        if flags & 6:
-            b_merge += 10 * (R["ssa"] + R["esa"]) + 5 * n_slice
+            R = {k: (res[k].numel() // 10 if k in res and res[k] is not None else 0) for k in ("ssa", "esa")}
         ktime = {r["kernel"]: r["ms_per_step"] for r in rows}
         t_hash = ktime.get("pfp::phrase_hash_kernel", 0.0)
         t_formats = sum(ktime.get(k, 0.0) for k in ("pfp::run_count_kernel", "pfp::run_place_kernel", "pfp::pack5_kernel"))
-        t_merge = st["ms_merge"] + t_formats
-
-        def pass_row(nbytes, ms):
-            if ms <= 0:
-                return None
-            g = nbytes / (ms * 1e-3) / 1e9
-            return dict(algo_bytes=int(nbytes), ms=round(ms, 3), achieved_GBps=round(g, 1), frac=round(g / HBM_PEAK_GBS, 4))
-        passes = {"scan (K1+K2: n + 8P)": pass_row(b_scan, st["ms_scan"]),
-                  "phrase hash (n + wP + 8P)": pass_row(b_hash, t_hash),
-                  "merge ((n+1) + 12|D| + 5(P+1) + 8H [+ SA terms]; incl. run sampling / packing)": pass_row(b_merge, t_merge),
-                  "scan + merge": pass_row(b_scan + b_merge, st["ms_scan"] + t_merge),
-                  "end to end floor (2n)": pass_row(2 * nn, ms_per_step)}
-        bad = [k for k, v in passes.items() if v and v["frac"] > 1.0]
-        assert not bad, f"pass fraction above 1 ({bad}): the timed figure is not the work"
+        passes = pass_rows(st, w, flags, n_slice, P_merge, D_, R, t_hash, t_formats, ms_per_step)
 
         scan_row = next((x for x in rows if x["kernel"] in ("pfp::kr_flag_kernel", "pfp::kr_scan_kernel")), None)
         # the host-buffer entry point (H2D of the text + D2H of the outputs included): reported, never `value`
@@ -349,11 +418,14 @@ def main():
         cpu = None
         parity_sample = None
         if O is not None:
-            # N = this process's share of the host: a one-GPU box gives 16 cores per GPU (the affinity mask shows all 256 of the node)
-            threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+            # N = this process's share of the host: a one-GPU box gives 16 cores per GPU (the affinity mask shows all of the node's)
+            affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            threads = max(1, min(args.cpu_threads, affinity))
             sample_bytes = n if args.cpu_sample_mb <= 0 else int(min(n, args.cpu_sample_mb * 1e6))
             host = text[:sample_bytes].cpu().numpy()
             cpu, ref = cpu_baseline(host, w, p, flags, O, threads)
+            cpu["threads_passed"] = threads
+            cpu["host_affinity_count"] = affinity
             got = ctx.bigbwt(host, w, p, flags)           # the same sample through the HIP path: bit-exact?
             parity_sample = {k: bool(np.array_equal(got[k], ref[k])) for k in ref if k in got}
         out = {
@@ -390,6 +462,17 @@ def main():
                          "bit_exact_vs_reference_on_cpu_sample": parity_sample,
                          "host_and_device_entry_points_agree": host_ok},
         }
+    if rank == 0 and world == 1 and args.north_star != "off" and (args.north_star == "on" or args.workload is None):
+        # the north star's own >= 10 GB workload next to the headline configuration (BASELINE configs[2]): ~15 s of GPU time
+        del text, bwt
+        torch.cuda.empty_cache()
+        if torch.cuda.get_device_properties(dev).total_memory >= (200 << 30):
+            try:
+                out["north_star"] = north_star_leg(pkg, synth, ctx, dev)
+            except Exception as ex:          # reported, never hidden: the headline line above stands on its own
+                out["north_star"] = {"error": f"{type(ex).__name__}: {ex}"}
+        else:
+            out["north_star"] = {"skipped": "needs ~200 GB of device memory"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

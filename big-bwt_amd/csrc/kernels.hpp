@@ -1,6 +1,7 @@
 // kernels.hpp -- declarations shared by the pipeline translation units.
 #pragma once
 #include "common.hpp"
+#include "wordview.hpp"
 
 namespace pfp {
 
@@ -111,8 +112,8 @@ struct SuffixOrderT {
 };
 using SuffixOrder = SuffixOrderT<uint32_t>;
 using SuffixOrder64 = SuffixOrderT<uint64_t>;
-// slen[i] = characters from position i to the terminator of its word (the terminator not counted)
-struct SlotPayloadSrc { const uint32_t *pos_word, *slen, *wocc; uint32_t d; int w; };
+// what a merge record is made from: the word of a position (WordView), the words' occurrence counts, the window
+struct SlotPayloadSrc { WordView wv; const uint32_t *wocc; int w; };
 // device-side view for rank lookups (sufsort.hip: rank_at)
 template <class I>
 struct RankViewT {
@@ -122,22 +123,30 @@ struct RankViewT {
 template <class I> RankViewT<I> rank_view(const SuffixOrderT<I> &so);
 // out[k] = rank of the suffix starting at pos[k]
 template <class I> void gather_ranks(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, uint64_t count, I *d_out);
-// Suffixes of the dictionary as 0x01-terminated strings (gsacak semantics):
-// slen[i] = distance from i to the terminator of the word containing i (the final 0x00 is its own word).
+// Suffixes of the dictionary as 0x01-terminated strings (gsacak semantics); wv answers where the
+// word of a position ends (the final 0x00 is its own word).
 template <class I>
-void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *slen, SuffixOrderT<I> &out,
+void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const WordView &wv, SuffixOrderT<I> &out,
                         const SlotPayloadSrc *pay = nullptr);
 // multi-GPU: rank `part` of `parts` sorts the suffixes whose first-round key lies in its share of the key
 // space (splitters from a deterministic key sample: every rank derives the same ones, no exchange);
 // groups never straddle shares, and pivot rounds compare strings, not ranks, so a share is finished
 // without its neighbours.  out.complete == false: a group was left that only doubling could settle.
 template <class I>
-void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *slen, uint32_t part,
+void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const WordView &wv, uint32_t part,
                               uint32_t parts, SuffixOrderT<I> &out, const SlotPayloadSrc *pay = nullptr,
                               const SlotPayloadSrc *count = nullptr);
-// range mode: out[j] = 1 + SA(D) slot of the suffix starting at pos[j] if it belongs to this share, else 0
+// range mode: out[j] = 1 + SA(D) slot of the whole-word suffix of word j if it belongs to this share, else 0 (count = d)
 template <class I>
-void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, uint64_t count, uint64_t *d_out);
+void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const WordView &wv, uint64_t count, uint64_t *d_out);
+// Dictionary of a repetitive collection: the emitting suffixes (longer than w) grouped by equal strings WITHOUT sorting the
+// duplicates - equal suffixes are read off the words' reverse-lexicographic order, one representative per distinct string is
+// suffix-sorted, the groups are laid out from the representatives (sufsort.hip).  out.N = emitting suffixes (< NP), out.sa /
+// out.grp as from the full sort minus the slots that emit nothing; wslot[j] = 1 + slot of word j's whole-word suffix.
+// false: not applicable (a comparison would need doubling rounds) - nothing usable in out, sort everything instead.
+template <class I>
+bool sort_dict_suffixes_dedup(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, int w, double rep_hint, SuffixOrderT<I> &out,
+                              DBuf<uint64_t> &wslot);
 // plain suffix array of an integer string with unique smallest last symbol (sacak_int)
 // max_sym: largest symbol value (spare key bits then describe runs of equal symbols)
 void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym = 0xFFFFFFFFu);
@@ -145,14 +154,16 @@ void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder 
 template <class I> void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrderT<I> &out);
 
 // ---------------------------------------------------------------- stage 2+3 (merge.hip)
-struct DictIndex {        // per-position / per-word helper arrays over the dictionary (the same in both index widths)
-  DBuf<uint32_t> pos_word;   // [dsize] word containing position i (d for the final 0x00)
-  DBuf<uint32_t> slen;       // [dsize] distance from i to that word's terminator
+struct DictIndex {        // word lookup over the dictionary (wordview.hpp): |D| / 16 + 8 d bytes, no per-position array
+  DBuf<uint32_t> blk_word;   // [dsize / 64 + 1] word containing position 64 b
   DBuf<uint64_t> wend;       // [d+1] terminator position of word j (wend[d] = dsize-1)
   DBuf<uint32_t> lexrank;    // [d] 0-based lexicographic rank of word j
   DBuf<uint64_t> wslot_lex;  // [d] SA(D) slot (global) of the whole-word suffix of the word of lexicographic rank q
 };
 void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix);      // needs D.woff / D.wlen
+inline WordView word_view(const Dictionary &D, const DictIndex &ix) {
+  return WordView{D.bytes.p, ix.blk_word.p, ix.wend.p, (uint32_t)D.d, D.dsize};
+}
 // D.bytes/D.dsize given (words + 0x01, final 0x00): fills D.d, D.woff, D.wlen; at most max_words words expected
 void word_table_from_bytes(pfp_ctx *c, Dictionary &D, uint64_t max_words);
 template <class I> void compute_lexrank(pfp_ctx *c, const Dictionary &D, SuffixOrderT<I> &so, DictIndex &ix);

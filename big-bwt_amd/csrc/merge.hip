@@ -24,35 +24,39 @@ constexpr int kOffTileLog = 11;      // slots per offset tile (= one expand work
 
 // ------------------------------------------------------------------ dictionary index
 
-// Per-position word id and terminator position, written from the word table (8 lanes per word): the
-// dictionary is laid out from known word offsets and lengths, nothing has to be counted back out of
-// its bytes (an N-long scan and two N-long passes before).
-__global__ __launch_bounds__(256) void dict_index_fill_kernel(uint32_t d, const uint64_t *__restrict__ woff,
-                                                              const uint32_t *__restrict__ wlen, uint64_t dsize,
-                                                              uint32_t *__restrict__ pos_word, uint32_t *__restrict__ slen,
-                                                              uint64_t *__restrict__ wend) {
-  const uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
-  const uint64_t j = t >> 3;
-  const uint32_t l8 = (uint32_t)(t & 7);
+// Word lookup over the dictionary (wordview.hpp): terminators per 64-byte line, scanned, and the word ends from the
+// word table.  |D| / 16 + 8 d bytes instead of the 8 bytes per dictionary byte of pos_word[] / slen[] (rounds 1-2).
+__global__ __launch_bounds__(256) void line_terms_kernel(const uint8_t *__restrict__ b, uint64_t N, uint64_t nlines, uint32_t *__restrict__ cnt) {
+  const uint64_t ln = (uint64_t)BID * 256 + threadIdx.x;
+  if (ln > nlines) return;
+  if (ln == nlines) { cnt[ln] = 0; return; }
+  const uint64_t b0 = ln * 64;
+  const uint32_t nb = N - b0 >= 64 ? 64u : (uint32_t)(N - b0);      // (the padding behind the dictionary is zero, but keep the count exact)
+  const uint4 *line = reinterpret_cast<const uint4 *>(b + b0);
+  uint32_t n = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) if (nb > 16u * q) n += count_term_bytes16(line[q], nb - 16u * q < 16u ? nb - 16u * q : 16u);
+  cnt[ln] = n;
+}
+__global__ void word_ends_kernel(uint32_t d, const uint64_t *__restrict__ woff, const uint32_t *__restrict__ wlen, uint64_t dsize,
+                                 uint64_t *__restrict__ wend) {
+  const uint32_t j = BID * blockDim.x + threadIdx.x;
   if (j > d) return;
-  if (j == d) {      // the final 0x00 is its own word
-    if (l8 == 0) { pos_word[dsize - 1] = d; slen[dsize - 1] = 0; wend[d] = dsize - 1; }
-    return;
-  }
-  const uint64_t s0 = woff[j], e = s0 + wlen[j];     // e: the word's 0x01
-  if (l8 == 0) wend[j] = e;
-  for (uint64_t i = s0 + l8; i <= e; i += 8) { pos_word[i] = (uint32_t)j; slen[i] = (uint32_t)(e - i); }
+  wend[j] = j == d ? dsize - 1 : woff[j] + wlen[j];      // the word's 0x01; the final 0x00 is its own word
 }
 
 void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix) {
   const uint64_t N = D.dsize;
   PFP_REQUIRE(D.woff.p && D.wlen.p, PFP_EINVAL, "dictionary without a word table");
-  ix.pos_word.alloc(c, N);
-  ix.slen.alloc(c, N);
+  PFP_REQUIRE(((uintptr_t)D.bytes.p & 63) == 0, PFP_EINVAL, "dictionary bytes must be 64-byte aligned");
+  const uint64_t nlines = cdiv64(N, 64);
+  DBuf<uint32_t> cnt(c, nlines + 1);
+  ix.blk_word.alloc(c, nlines + 1);
   ix.wend.alloc(c, D.d + 1);
-  KScope ks(c, "pfp::dict_index_fill_kernel", N * 8);
-  hipLaunchKernelGGL(dict_index_fill_kernel, gdim(cdiv(((uint64_t)D.d + 1) * 8, TB)), gdim(TB), 0, c->stream, (uint32_t)D.d,
-                     D.woff.p, D.wlen.p, N, ix.pos_word.p, ix.slen.p, ix.wend.p);
+  KScope ks(c, "pfp::dict_index_fill_kernel", N + nlines * 12 + D.d * 20);
+  hipLaunchKernelGGL(line_terms_kernel, gdim(cdiv(nlines + 1, TB)), gdim(TB), 0, c->stream, D.bytes.p, N, nlines, cnt.p);
+  exclusive_sum_u32(c, cnt.p, ix.blk_word.p, nlines + 1);
+  hipLaunchKernelGGL(word_ends_kernel, gdim(cdiv((uint64_t)D.d + 1, TB)), gdim(TB), 0, c->stream, (uint32_t)D.d, D.woff.p, D.wlen.p, N, ix.wend.p);
   PFP_HIP(hipGetLastError());
 }
 
@@ -118,17 +122,15 @@ void compute_lexrank_from_slots(pfp_ctx *c, const Dictionary &D, const uint64_t 
 
 // number of BWT positions the slots of `so` emit (sum of the occurrence counts of their words)
 template <class I>
-__global__ __launch_bounds__(256) void slot_output_count_kernel(uint64_t n, const I *__restrict__ sa,
-                                                                const uint32_t *__restrict__ pos_word,
-                                                                const uint32_t *__restrict__ slen,
+__global__ __launch_bounds__(256) void slot_output_count_kernel(uint64_t n, const I *__restrict__ sa, WordView wv,
                                                                 const uint32_t *__restrict__ wocc, uint32_t d, int w,
                                                                 unsigned long long *__restrict__ total) {
   __shared__ unsigned long long ws[4];
   unsigned long long cnt = 0;
   for (uint64_t t = (uint64_t)BID * 256 + threadIdx.x; t < n; t += (uint64_t)GDIM * 256) {
     const I i = sa[t];
-    const uint32_t wd = pos_word[i];
-    if (wd < d && slen[i] > (uint32_t)w) cnt += wocc[wd];
+    const uint32_t wd = word_of(wv, i);
+    if (wd < d && wv.wend[wd] - i > (uint64_t)w) cnt += wocc[wd];
   }
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
@@ -141,7 +143,7 @@ uint64_t count_slot_outputs(pfp_ctx *c, const Dictionary &D, const DictIndex &ix
   total.zero();
   if (so.N)
     hipLaunchKernelGGL(slot_output_count_kernel<I>, gdim((int)std::min<uint64_t>(cdiv64(so.N, 256), (uint64_t)c->n_cu * 16)), gdim(256),
-                       0, c->stream, so.N, so.sa.p, ix.pos_word.p, ix.slen.p, D.wocc.p, (uint32_t)D.d, w, total.p);
+                       0, c->stream, so.N, so.sa.p, word_view(D, ix), D.wocc.p, (uint32_t)D.d, w, total.p);
   PFP_HIP(hipGetLastError());
   PFP_HIP(hipMemcpyAsync(c->h_scalars, total.p, 8, hipMemcpyDeviceToHost, c->stream));
   sync(c);
@@ -218,32 +220,6 @@ void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t 
 
 // ------------------------------------------------------------------ stage 3: merge
 
-// Per dictionary POSITION, one streaming pass: a 2-byte record {prev char, count code} so that the
-// per-SLOT pass gathers 2 bytes from an |D|*2-byte array (largely Infinity-Cache resident) instead
-// of dragging a 64-byte HBM sector per slot for a 16-byte record (rocprofv3 FETCH_SIZE showed 3.4x
-// the algorithmic bytes for that version, profiles/r01_pmc_traffic.txt).
-//   low byte  = preceding char, 1 (EndOfWord) when the suffix is a whole word (pfbwt.cpp:153),
-//               0 when the suffix emits nothing (<= w long, pfbwt.cpp:151)
-//   high byte = occurrences of its word, 255 = "255 or more: look it up"
-// With SA output every emitting slot also needs its word (inverted-list start): the record is then
-// 8 bytes {prev char, count code, 0, 0, word id} so that the slot pass still does ONE gather.
-template <class REC>
-__global__ void pprec_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t d, int w,
-                             const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ slen,
-                             const uint32_t *__restrict__ wocc, REC *__restrict__ pp) {
-  uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  uint32_t wd = pos_word[i];
-  bool valid = wd < d && slen[i] > (uint32_t)w;
-  uint32_t pc = (i == 0) ? kEndOfWord : b[i - 1];
-  uint32_t occ = valid ? wocc[wd] : 0u;
-  uint32_t lo = valid ? (pc | ((occ < 255u ? occ : 255u) << 8)) : 0u;
-  if (sizeof(REC) == 2) pp[i] = (REC)lo;
-  else pp[i] = (REC)((uint64_t)lo | ((uint64_t)wd << 32));
-}
-
-// per SA(D) slot: count and preceding char (0 = emits nothing), 8 slots per thread; with SA output
-// also the start of the word's inverted list
 template <class I> struct alignas(16) Idx8 { I v[8]; };
 // whole-word slots (preceding char = EndOfWord) of the block's 2048 slots -> tile_full[block]; smallest such slot -> first_full
 __device__ __forceinline__ void tile_full_count(const uint32_t p8[8], int nk, uint64_t t0, uint32_t *__restrict__ tile_full,
@@ -261,50 +237,6 @@ __device__ __forceinline__ void tile_full_count(const uint32_t p8[8], int nk, ui
   __syncthreads();
   if (threadIdx.x == 0) tile_full[BID] = ws[0] + ws[1] + ws[2] + ws[3];
 }
-template <class REC, class I>
-__global__ __launch_bounds__(256) void slot_gather_kernel(uint64_t N, const I *__restrict__ sa,
-                                                          const REC *__restrict__ pp,
-                                                          const uint32_t *__restrict__ pos_word,
-                                                          const uint32_t *__restrict__ wocc,
-                                                          const uint32_t *__restrict__ wistart,
-                                                          uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc,
-                                                          uint32_t *__restrict__ ist, uint32_t *__restrict__ tile_full,
-                                                          unsigned long long *__restrict__ first_full) {
-  if ((uint64_t)BID * 2048 >= N) return;      // a workgroup of the padded last grid row
-  uint64_t t0 = ((uint64_t)BID * 256 + threadIdx.x) * 8;
-  I idx[8];
-  uint32_t c8[8], p8[8], w8[8];
-  const int nk = t0 >= N ? 0 : ((N - t0) >= 8 ? 8 : (int)(N - t0));
-  if (nk == 8) {
-    const Idx8<I> v8 = *reinterpret_cast<const Idx8<I> *>(sa + t0);
-#pragma unroll
-    for (int k = 0; k < 8; k++) idx[k] = v8.v[k];
-  } else {
-    for (int k = 0; k < 8; k++) idx[k] = k < nk ? sa[t0 + k] : (I)0;
-  }
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const uint64_t v = k < nk ? (uint64_t)pp[idx[k]] : 0ull;
-    p8[k] = (uint32_t)v & 0xffu; c8[k] = ((uint32_t)v >> 8) & 0xffu; w8[k] = (uint32_t)(v >> 32);
-  }
-#pragma unroll
-  for (int k = 0; k < 8; k++) if (c8[k] == 255u) c8[k] = wocc[sizeof(REC) == 2 ? pos_word[idx[k]] : w8[k]];
-  if (nk == 8) {
-    *reinterpret_cast<uint4 *>(cnt + t0) = make_uint4(c8[0], c8[1], c8[2], c8[3]);
-    *reinterpret_cast<uint4 *>(cnt + t0 + 4) = make_uint4(c8[4], c8[5], c8[6], c8[7]);
-    *reinterpret_cast<uint2 *>(pc + t0) = make_uint2(p8[0] | (p8[1] << 8) | (p8[2] << 16) | (p8[3] << 24),
-                                                     p8[4] | (p8[5] << 8) | (p8[6] << 16) | (p8[7] << 24));
-  } else {
-    for (int k = 0; k < nk; k++) { cnt[t0 + k] = c8[k]; pc[t0 + k] = (uint8_t)p8[k]; }
-  }
-  if (ist) {
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (k < nk) ist[t0 + k] = p8[k] ? wistart[sizeof(REC) == 2 ? pos_word[idx[k]] : w8[k]] : 0u;
-  }
-  tile_full_count(p8, nk, t0, tile_full, first_full);
-}
-
 // The same per-slot outputs when the records travelled in the top 16 bits of the first-round keys
 // (SuffixOrder::paybits): a streaming read of skeys; only slots that later rounds re-ordered
 // (refined[t]) fetch their record, and a count code of 255 its word's count.
@@ -312,8 +244,7 @@ template <class I>
 __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const I *__restrict__ sa,
                                                            const uint64_t *__restrict__ skeys,
                                                            const uint8_t *__restrict__ refined, const uint8_t *__restrict__ b,
-                                                           const uint32_t *__restrict__ pos_word,
-                                                           const uint32_t *__restrict__ slen,
+                                                           WordView wv,
                                                            const uint32_t *__restrict__ wocc, uint32_t d, int w,
                                                            uint32_t *__restrict__ cnt, uint8_t *__restrict__ pc,
                                                            uint32_t *__restrict__ tile_full, unsigned long long *__restrict__ first_full) {
@@ -330,9 +261,9 @@ __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const I *
       rec = (uint32_t)(skeys[t0 + k] >> 48);
       if ((rf >> (8 * k)) & 0xffu) {
         const I i = sa[t0 + k];
-        const uint32_t wd = pos_word[i];
+        const uint32_t wd = word_of(wv, i);
         rec = 0;
-        if (wd < d && slen[i] > (uint32_t)w) {
+        if (wd < d && wv.wend[wd] - i > (uint64_t)w) {
           const uint32_t occ = wocc[wd];
           rec = (i == 0 ? (uint32_t)kEndOfWord : (uint32_t)b[i - 1]) | ((occ < 255u ? occ : 255u) << 8);
         }
@@ -341,7 +272,7 @@ __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const I *
     p8[k] = rec & 0xffu; c8[k] = rec >> 8;
   }
 #pragma unroll
-  for (int k = 0; k < 8; k++) if (c8[k] == 255u) c8[k] = wocc[pos_word[sa[t0 + k]]];
+  for (int k = 0; k < 8; k++) if (c8[k] == 255u) c8[k] = wocc[word_of(wv, sa[t0 + k])];
   if (nk == 8) {
     *reinterpret_cast<uint4 *>(cnt + t0) = make_uint4(c8[0], c8[1], c8[2], c8[3]);
     *reinterpret_cast<uint4 *>(cnt + t0 + 4) = make_uint4(c8[4], c8[5], c8[6], c8[7]);
@@ -367,19 +298,42 @@ __global__ __launch_bounds__(256) void slot_payload_kernel(uint64_t N, const I *
 //         bits 8..31: suffix length = distance to the word's terminator, capped at kSlCap (then: slen[] has it)
 struct alignas(16) PosRec { uint32_t occ, first, last, pcsl; };
 constexpr uint32_t kSlCap = 0xFFFFFFu;
-__global__ __launch_bounds__(256) void pprec16_kernel(const uint8_t *__restrict__ b, uint64_t N, uint32_t d, int w,
-                                                      const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ slen,
-                                                      const uint4 *__restrict__ wrec /* WordRec as two uint4 */, PosRec *__restrict__ out) {
-  const uint64_t i = (uint64_t)BID * 256 + threadIdx.x;
-  if (i >= N) return;
-  const uint32_t wd = pos_word[i], sl = slen[i];
+// 256 positions per workgroup: the word of the block's first position is one table read (blocks start at multiples of
+// 64), the words of the others follow from the terminators before them in the block (ballots); consecutive positions
+// share their word's record.  dense_ist: full SA output wants the start of the word's inverted list where the sparse
+// modes want its smallest position (field `first`).
+// Positions [pos0, pos1) only (pos0 a multiple of 256), out[i - pos0]: a dictionary whose records would not fit is done in blocks.
+__global__ __launch_bounds__(256) void pprec16_kernel(WordView wv, int w, const uint4 *__restrict__ wrec /* WordRec as two uint4 */,
+                                                      int dense_ist, uint64_t pos0, uint64_t pos1, PosRec *__restrict__ out) {
+  __shared__ uint32_t wt[4];
+  const uint64_t i = pos0 + (uint64_t)BID * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+  const uint32_t ch = i < wv.NP ? (uint32_t)wv.bytes[i] : 0u;
+  const unsigned long long tm = __ballot(ch == (uint32_t)kEndOfWord);
+  if (lane == 0) wt[wvi] = (uint32_t)__popcll(tm);
+  __syncthreads();
+  if (i >= pos1) return;
+  uint32_t wd = wv.blk_word[(pos0 >> 6) + (uint64_t)BID * 4] + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
+  for (int q = 0; q < wvi; q++) wd += wt[q];
   PosRec r{0u, 0u, 0u, 0u};
-  if (wd < d && sl > (uint32_t)w) {
-    const uint4 wr = wrec[2 * (uint64_t)wd];      // {ist, occ, first, last}: consecutive positions share their word's record
-    const uint32_t pc = (i == 0) ? (uint32_t)kEndOfWord : (uint32_t)b[i - 1];
-    r = PosRec{wr.y, wr.z, wr.w, pc | ((sl < kSlCap ? sl : kSlCap) << 8)};
+  if (wd < wv.d) {
+    const uint64_t sl = wv.wend[wd] - i;
+    if (sl > (uint64_t)w) {
+      const uint4 wr = wrec[2 * (uint64_t)wd];      // {ist, occ, first, last}
+      const uint32_t pc = (i == 0) ? (uint32_t)kEndOfWord : (uint32_t)wv.bytes[i - 1];
+      r = PosRec{wr.y, dense_ist ? wr.x : wr.z, wr.w, pc | ((sl < kSlCap ? (uint32_t)sl : kSlCap) << 8)};
+    }
   }
-  *reinterpret_cast<uint4 *>(out + i) = make_uint4(r.occ, r.first, r.last, r.pcsl);
+  *reinterpret_cast<uint4 *>(out + (i - pos0)) = make_uint4(r.occ, r.first, r.last, r.pcsl);
+}
+// blocked records: the slots whose suffix starts in [pos0, pos1) fetch theirs
+template <class I>
+__global__ void slot_fetch_kernel(uint64_t N, const I *__restrict__ sa, uint64_t pos0, uint64_t pos1, const PosRec *__restrict__ blk,
+                                  PosRec *__restrict__ srec) {
+  const uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const uint64_t i = sa[t];
+  if (i >= pos0 && i < pos1) *reinterpret_cast<uint4 *>(srec + t) = *reinterpret_cast<const uint4 *>(blk + (i - pos0));
 }
 
 // Per tile of 2048 slots (256 threads x 8 consecutive slots): gather the records, exclusive scan of the counts inside
@@ -394,7 +348,8 @@ __global__ __launch_bounds__(256) void slot_records_kernel(uint64_t N, const I *
                                                            uint32_t *__restrict__ slast, uint32_t *__restrict__ ssl,
                                                            uint64_t *__restrict__ tsum, uint32_t *__restrict__ overflow,
                                                            uint32_t *__restrict__ tile_full, unsigned long long *__restrict__ first_full,
-                                                           uint8_t *__restrict__ hard) {
+                                                           uint8_t *__restrict__ hard, int any_multi_is_hard, int per_slot) {
+  // per_slot: prec[] already holds one record per SLOT (blocked records, slot_fetch_kernel) - read, not gathered
   __shared__ uint64_t ws[4];
   __shared__ uint32_t lpc[256];
   __shared__ I lgrp[256];
@@ -411,14 +366,14 @@ __global__ __launch_bounds__(256) void slot_records_kernel(uint64_t N, const I *
   }
   uint4 r8[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) r8[k] = k < nk ? *reinterpret_cast<const uint4 *>(prec + idx[k]) : make_uint4(0u, 0u, 0u, 0u);
+  for (int k = 0; k < 8; k++) r8[k] = k < nk ? *reinterpret_cast<const uint4 *>(prec + (per_slot ? t0 + k : (uint64_t)idx[k])) : make_uint4(0u, 0u, 0u, 0u);
   // the slot before this thread's first one: the previous thread's last slot, or (first thread) the last slot of the tile before
   uint32_t p8[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) p8[k] = r8[k].w & 0xffu;
   lpc[threadIdx.x] = p8[7]; lgrp[threadIdx.x] = g8[7];
   uint32_t prev_pc = 0; I prev_g = IdxTraits<I>::kNone;
-  if (threadIdx.x == 0 && t0 > 0 && nk) { prev_pc = prec[sa[t0 - 1]].pcsl & 0xffu; prev_g = grp[t0 - 1]; }
+  if (threadIdx.x == 0 && t0 > 0 && nk) { prev_pc = prec[per_slot ? t0 - 1 : (uint64_t)sa[t0 - 1]].pcsl & 0xffu; prev_g = grp[t0 - 1]; }
   // counts: exclusive scan inside the tile
   uint64_t own = 0;
 #pragma unroll
@@ -447,6 +402,8 @@ __global__ __launch_bounds__(256) void slot_records_kernel(uint64_t N, const I *
     if (sfirst) {
       *reinterpret_cast<uint4 *>(sfirst + t0) = make_uint4(r8[0].y, r8[1].y, r8[2].y, r8[3].y);
       *reinterpret_cast<uint4 *>(sfirst + t0 + 4) = make_uint4(r8[4].y, r8[5].y, r8[6].y, r8[7].y);
+    }
+    if (slast) {
       *reinterpret_cast<uint4 *>(slast + t0) = make_uint4(r8[0].z, r8[1].z, r8[2].z, r8[3].z);
       *reinterpret_cast<uint4 *>(slast + t0 + 4) = make_uint4(r8[4].z, r8[5].z, r8[6].z, r8[7].z);
     }
@@ -457,14 +414,15 @@ __global__ __launch_bounds__(256) void slot_records_kernel(uint64_t N, const I *
   } else {
     for (int k = 0; k < nk; k++) {
       pc[t0 + k] = (uint8_t)p8[k];
-      if (sfirst) { sfirst[t0 + k] = r8[k].y; slast[t0 + k] = r8[k].z; }
+      if (sfirst) sfirst[t0 + k] = r8[k].y;
+      if (slast) slast[t0 + k] = r8[k].z;
       if (ssl) ssl[t0 + k] = r8[k].w >> 8;
     }
   }
   // hard groups: a differing char next to a member of the same group
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    if (k < nk && p8[k] != 0 && g8[k] == prev_g && p8[k] != prev_pc) hard[g8[k]] = 1;
+    if (k < nk && p8[k] != 0 && g8[k] == prev_g && (any_multi_is_hard || p8[k] != prev_pc)) hard[g8[k]] = 1;      // (SA output: any group of several words, pfbwt.cpp:568, 612)
     prev_pc = p8[k]; prev_g = g8[k];
   }
   tile_full_count(p8, nk, t0, tile_full, first_full);
@@ -474,9 +432,9 @@ __global__ __launch_bounds__(256) void slot_records_kernel(uint64_t N, const I *
 // belongs to the word of rank q.  Rank of the first whole-word slot held (0 unless the slots are one rank's range).
 template <class I>
 __global__ void full_base0_kernel(const unsigned long long *__restrict__ first_full, const I *__restrict__ sa,
-                                  const uint32_t *__restrict__ pos_word, const uint32_t *__restrict__ lexrank, uint32_t *__restrict__ out) {
+                                  WordView wv, const uint32_t *__restrict__ lexrank, uint32_t *__restrict__ out) {
   const unsigned long long f = *first_full;
-  *out = f == ~0ull ? 0u : lexrank[pos_word[sa[f]]];
+  *out = f == ~0ull ? 0u : lexrank[word_of(wv, sa[f])];
 }
 
 // a group is "hard" when its members disagree on the preceding char (pfbwt.cpp:524-536), or, with
@@ -522,7 +480,8 @@ struct MergeArgsT {
   uint64_t pos_base, n_out_global;   // global BWT position of local position 0; global n+1 (== n_out unless the slots are one rank's range)
   uint64_t out_lo, out_hi;   // this call emits BWT positions [out_lo,out_hi) only (multi-GPU slices); bwt/out_sa are indexed by global position
   const I *sa, *grp;
-  const uint32_t *slen, *ist, *pos_word, *wistart;
+  WordView wv;               // word / suffix length of a dictionary position where no per-slot copy exists
+  const uint32_t *ist, *wistart;
   const WordRec *wrec;
   // per-slot copies of the gathered position records (slot_records_kernel; null: look the word up through sa / pos_word):
   // smallest / largest BWT(P) position of the slot's word, suffix length (kSlCap = look it up in slen[])
@@ -572,19 +531,19 @@ __device__ __forceinline__ uint8_t fix_char(uint8_t ch) { return ch == kDollar ?
 // (BWT only needs it for whole words and hard groups)
 template <class I>
 __device__ __forceinline__ uint32_t slot_ist(const MergeArgsT<I> &a, uint64_t t) {
-  return a.ist ? a.ist[t] : a.wistart[a.pos_word[a.sa[t]]];
+  return a.ist ? a.ist[t] : a.wistart[word_of(a.wv, a.sa[t])];
 }
 
 // what the hard-group / unit-edge kernels ask about the word of slot t: from the per-slot arrays when the slot records
 // were gathered (one coalesced read), else through sa -> pos_word -> the word's record (three dependent random reads)
 template <class I>
-__device__ __forceinline__ uint32_t slot_first(const MergeArgsT<I> &a, uint64_t t) { return a.sfirst ? a.sfirst[t] : a.wrec[a.pos_word[a.sa[t]]].first; }
+__device__ __forceinline__ uint32_t slot_first(const MergeArgsT<I> &a, uint64_t t) { return a.sfirst ? a.sfirst[t] : a.wrec[word_of(a.wv, a.sa[t])].first; }
 template <class I>
-__device__ __forceinline__ uint32_t slot_last(const MergeArgsT<I> &a, uint64_t t) { return a.slast ? a.slast[t] : a.wrec[a.pos_word[a.sa[t]]].last; }
+__device__ __forceinline__ uint32_t slot_last(const MergeArgsT<I> &a, uint64_t t) { return a.slast ? a.slast[t] : a.wrec[word_of(a.wv, a.sa[t])].last; }
 template <class I>
 __device__ __forceinline__ uint64_t slot_slen(const MergeArgsT<I> &a, uint64_t t) {
   if (a.ssl) { const uint32_t v = a.ssl[t]; if (v != kSlCap) return v; }
-  return a.slen[a.sa[t]];
+  return slen_of(a.wv, a.sa[t]);
 }
 
 // Expansion.  One workgroup owns kSlots consecutive SA(D) slots, i.e. one contiguous range of
@@ -709,9 +668,8 @@ __device__ __forceinline__ void expand_sa_1(const MergeArgsT<I> &a, const Expand
   const uint8_t cl = L.lcls[lo];
   if (cl != CLS_FULL && (cl != CLS_FILL || a.want_sa == SA_SPARSE)) return;
   if (!sa_wanted(a, base + x)) return;
-  const I i = a.sa[t0 + lo];
   const uint64_t pos = a.ilist[(cl == CLS_FULL ? L.lfist[lo] : slot_ist(a, t0 + lo)) + (uint32_t)(x - L.loff[lo])];
-  sa_put(a, base + x, (cl == CLS_FULL && a.pos_base + base + x == 0) ? a.n_out_global - 1 : a.bwsai[pos] - (uint64_t)a.slen[i]);
+  sa_put(a, base + x, (cl == CLS_FULL && a.pos_base + base + x == 0) ? a.n_out_global - 1 : a.bwsai[pos] - slot_slen(a, t0 + lo));
 }
 
 // Sparse SA mode (-s / -e without -S): SA values are only looked at where a run of the BWT starts or ends.
@@ -775,9 +733,8 @@ __global__ __launch_bounds__(256) void expand_kernel(MergeArgsT<I> a, uint32_t *
       const int sl = (int)fulls[lo];
       const uint64_t x = L.loff[sl] + (idx - fpre[lo]);
       if (!sa_wanted(a, base + x)) continue;
-      const I i = a.sa[t0 + sl];
       const uint64_t pos = a.ilist[L.lfist[sl] + (uint32_t)(x - L.loff[sl])];
-      sa_put(a, base + x, a.pos_base + base + x == 0 ? a.n_out_global - 1 : a.bwsai[pos] - (uint64_t)a.slen[i]);
+      sa_put(a, base + x, a.pos_base + base + x == 0 ? a.n_out_global - 1 : a.bwsai[pos] - slot_slen(a, t0 + sl));
     }
   } else if (a.want_sa) {
     for (uint64_t x = threadIdx.x; x < mine; x += 256) expand_sa_1(a, L, t0, ns, base, x);
@@ -1024,13 +981,16 @@ struct MinorMember { uint64_t g; uint32_t k, m; uint64_t roff; };
 // sparse SA: what the second pass needs of a placed minority occurrence - its output position, its BWT(P) position
 // and those of its neighbours in the merged order (flags bit 0 / 1: there is a predecessor / successor), suffix length
 struct MinorRec { uint64_t o; uint32_t pos, pred, succ, flags, sl, pad; };
+// (One thread per group.  Eight lanes per group - members strided over the lanes, tables merged by a butterfly - was
+//  tried in round 3 and ran twice as long, 10 -> 20 ms on 1024 copies: most groups have a handful of members, and the
+//  chain of dependent loads that finds a group's extent is the same for eight lanes as for one.)
 template <class I>
 __global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, const I *__restrict__ heads, uint64_t nH,
                                                             uint8_t *__restrict__ gmaj, HardGroupInfo *__restrict__ info,
                                                             uint32_t *__restrict__ minor_cnt, uint8_t *__restrict__ fallback,
                                                             unsigned long long *__restrict__ chars_total, uint32_t *__restrict__ minor_members) {
   const uint64_t h = (uint64_t)BID * 256 + threadIdx.x;
-  unsigned long long mychars = 0;
+  unsigned long long mychars = 0, myk = 0;
   if (h < nH) {
   const uint64_t g = heads[h];
   // members are the slots g .. g+k-1 (grp == g): gallop, then bisect
@@ -1079,40 +1039,55 @@ __global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, con
   minor_cnt[h] = (fb || !in_slice) ? 0u : (uint32_t)minor;
   minor_members[h] = (fb || !in_slice) ? 0u : mm;
   info[h] = HardGroupInfo{g, E, (uint32_t)k, (uint32_t)(fb ? 0 : minor)};
-  if (!fb && in_slice) mychars = E;
+  if (!fb && in_slice) { mychars = E; myk = k; }
   }
-  for (int o = 32; o > 0; o >>= 1) mychars += __shfl_down(mychars, o, 64);      // "Hard bwt chars" (pfbwt.cpp:231-233) of these groups
-  if ((threadIdx.x & 63) == 0 && mychars) atomicAdd(chars_total, mychars);
+  for (int o = 32; o > 0; o >>= 1) { mychars += __shfl_down(mychars, o, 64); myk += __shfl_down(myk, o, 64); }      // "Hard bwt chars" (pfbwt.cpp:231-233) of these groups
+  if ((threadIdx.x & 63) == 0 && mychars) { atomicAdd(chars_total, mychars); atomicAdd(chars_total + 1, myk); }      // [1]: members, for the lane choice of hard_minor_kernel
 }
 
-// the minority members of all groups, laid end to end (offsets = prefix sums of their count per group)
+// the minority members of all groups, laid end to end (offsets = prefix sums of their count per group); eight lanes per
+// group, eight members per step, order and record offsets from prefix sums over the lanes
 template <class I>
 __global__ __launch_bounds__(256) void hard_minor_fill_kernel(MergeArgsT<I> a, const HardGroupInfo *__restrict__ info, uint64_t nH,
                                                               const uint64_t *__restrict__ mm_off, const uint64_t *__restrict__ minor_off,
                                                               const uint8_t *__restrict__ gmaj, MinorMember *__restrict__ out) {
-  const uint64_t h = (uint64_t)BID * 256 + threadIdx.x;
+  const uint64_t tq = (uint64_t)BID * 256 + threadIdx.x;
+  const uint64_t h = tq >> 3;
+  const int l8 = (int)(tq & 7);
   if (h >= nH) return;
   uint64_t o = mm_off[h];
   if (mm_off[h + 1] == o) return;
   const HardGroupInfo gi = info[h];
   const uint32_t maj = gmaj[gi.g];
-  uint64_t r = minor_off[h], prev = slot_off(a, gi.g);
-  for (uint32_t m = 0; m < gi.k; m++) {
-    const uint64_t nxt = slot_off(a, gi.g + m + 1);
-    if ((uint32_t)fix_char(a.pc[gi.g + m]) != maj) { out[o++] = MinorMember{gi.g, gi.k, m, r}; r += nxt - prev; }
-    prev = nxt;
+  uint64_t r = minor_off[h];
+  for (uint32_t m0 = 0; m0 < gi.k; m0 += 8) {
+    const uint32_t m = m0 + (uint32_t)l8;
+    const bool is_minor = m < gi.k && (uint32_t)fix_char(a.pc[gi.g + m]) != maj;
+    uint32_t cnt = is_minor ? 1u : 0u;
+    uint64_t oc = is_minor ? slot_off(a, gi.g + m + 1) - slot_off(a, gi.g + m) : 0ull;
+    const uint32_t own_c = cnt; const uint64_t own_o = oc;
+#pragma unroll
+    for (int d2 = 1; d2 < 8; d2 <<= 1) {
+      const uint32_t vc = __shfl_up(cnt, d2, 8); const uint64_t vo = __shfl_up(oc, d2, 8);
+      if (l8 >= d2) { cnt += vc; oc += vo; }
+    }
+    if (is_minor) out[o + cnt - own_c] = MinorMember{gi.g, gi.k, m, r + oc - own_o};
+    o += __shfl(cnt, 7, 8); r += __shfl(oc, 7, 8);
   }
 }
-// eight lanes per minority member: its occurrences (usually one) are ranked one after the other - own index +
-// lower_bound in every other member's inverted list, the group's members shared among the lanes (every lane fetches
-// the inverted-list start of its members and bisects there) - rank, predecessor and successor combined by shuffles
-template <class I>
+// LPM lanes per minority member (8, or the whole wave where groups have many members - the word families of a
+// collection of hundreds of copies): its occurrences (usually one) are ranked one after the other - own index +
+// lower_bound in every other member's inverted list, the group's members shared among the lanes - rank, predecessor
+// and successor combined by shuffles.  What a member's list looks like from outside (smallest / largest position,
+// length) comes from the per-slot arrays, LPM consecutive slots per load.
+template <class I, int LPM>
 __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const MinorMember *__restrict__ mem, uint64_t total,
                                                          MinorRec *__restrict__ recs) {
-  const int l8 = threadIdx.x & 7;
-  const uint64_t rounds = (total + GDIM * 32 - 1) / (GDIM * 32);      // every lane runs the same number of rounds (shuffles inside)
+  constexpr int PER = 256 / LPM;             // members per workgroup and round
+  const int ll = threadIdx.x & (LPM - 1);
+  const uint64_t rounds = (total + GDIM * PER - 1) / (GDIM * PER);      // every lane runs the same number of rounds (shuffles inside)
   for (uint64_t it = 0; it < rounds; it++) {
-    const uint64_t q = (it * GDIM + BID) * 32 + (threadIdx.x >> 3);
+    const uint64_t q = (it * GDIM + BID) * PER + (threadIdx.x / LPM);
     const bool live = q < total;
     MinorMember mmv{0, 0, 0, 0};
     if (live) mmv = mem[q];
@@ -1124,22 +1099,22 @@ __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const 
     if (live) {
       base = slot_off(a, g);
       const I myi = a.sa[g + me];
-      const WordRec wr = a.wrec[a.pos_word[myi]];
+      const WordRec wr = a.wrec[word_of(a.wv, myi)];
       my_occ = wr.occ; my_ist = wr.ist;
       mych = fix_char(a.pc[g + me]);
       sl = wr.wend - (uint64_t)myi;          // (equal suffixes: the same for every member)
     }
-    // longest occurrence count among the 8-lane groups of the wave decides the trip count (shuffles inside the loop)
+    // longest occurrence count among the members of the wave decides the trip count (shuffles inside the loop)
     uint32_t trips = my_occ;
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) { const uint32_t v = __shfl_xor(trips, o, 64); trips = v > trips ? v : trips; }
+    for (int o = LPM; o < 64; o <<= 1) { const uint32_t v = __shfl_xor(trips, o, 64); trips = v > trips ? v : trips; }
     for (uint32_t j = 0; j < trips; j++) {
       const bool act = live && j < my_occ;
       uint64_t r = 0;
       uint32_t pos = 0, pred = 0, succ = 0xFFFFFFFFu, has_pred = 0, has_succ = 0;
       if (act) {
         pos = a.ilist[my_ist + j];
-        for (uint32_t m = (uint32_t)l8; m < k; m += 8) {
+        for (uint32_t m = (uint32_t)ll; m < k; m += LPM) {
           uint32_t lb, pv = 0, sv = 0;
           bool hp = false, hs = false;
           if (m == me) {
@@ -1149,14 +1124,13 @@ __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const 
               if (j + 1 < my_occ) { sv = a.ilist[my_ist + j + 1]; hs = true; }
             }
           } else {
-            // the member's smallest / largest BWT(P) position (per-slot arrays: the members of a group are consecutive
-            // slots, eight lanes read eight neighbours) answer for a list that lies wholly on one side of pos (a variant
-            // that occurs once: always); only a list that straddles pos is looked up and bisected
+            // a list that lies wholly on one side of pos (a variant that occurs once: always) needs no look inside;
+            // only a list that straddles pos is looked up and bisected
             const uint32_t mfirst = slot_first(a, g + m), mlast = slot_last(a, g + m);
             if (pos < mfirst) { lb = 0; sv = mfirst; hs = true; }
             else if (pos > mlast) { lb = (uint32_t)(slot_off(a, g + m + 1) - slot_off(a, g + m)); pv = mlast; hp = true; }
             else {
-              const WordRec wr = a.wrec[a.pos_word[a.sa[g + m]]];
+              const WordRec wr = a.wrec[word_of(a.wv, a.sa[g + m])];
               const uint32_t *lst = a.ilist + wr.ist;
               uint32_t l2 = 1, h2 = wr.occ - 1;          // # entries < pos: lst[0] < pos < lst[occ - 1]
               while (l2 < h2) { const uint32_t mid = (l2 + h2) >> 1; if (lst[mid] < pos) l2 = mid + 1; else h2 = mid; }
@@ -1170,14 +1144,14 @@ __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const 
         }
       }
 #pragma unroll
-      for (int o = 1; o < 8; o <<= 1) {
+      for (int o = 1; o < LPM; o <<= 1) {
         r += __shfl_xor(r, o, 64);
         const uint32_t op = __shfl_xor(pred, o, 64), ohp = __shfl_xor(has_pred, o, 64);
         const uint32_t os = __shfl_xor(succ, o, 64), ohs = __shfl_xor(has_succ, o, 64);
         if (ohp && (!has_pred || op > pred)) { pred = op; has_pred = 1; }
         if (ohs && (!has_succ || os < succ)) { succ = os; has_succ = 1; }
       }
-      if (!act || l8 != 0) continue;
+      if (!act || ll != 0) continue;
       const uint64_t o = base + r;
       if (o >= a.out_lo && o < a.out_hi) a.bwt[o] = mych;
       if (a.want_sa)       // (also when the occurrence lies just outside this rank's slice: its neighbours may be inside)
@@ -1296,7 +1270,7 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgsT<I> a, const
         L.lmoff[q] = L.geoff[lo] + (uint32_t)(slot_off(a, t) - L.gbase[lo]);
         L.lmist[q] = slot_ist(a, t);
         uint32_t sl = 0;
-        if (a.want_sa) sl = a.slen[a.sa[t]];
+        if (a.want_sa) sl = (uint32_t)slot_slen(a, t);
         L.lmsl[q] = sl;
         L.lmch[q] = fix_char(a.pc[t]);
         L.lmg[q] = (uint8_t)lo;
@@ -1392,7 +1366,7 @@ __global__ __launch_bounds__(256) void hard_sort_kernel(MergeArgsT<I> a, const B
       while (hi - lo > 1) { const uint32_t mdl = (lo + hi) >> 1; if (slot_off(a, g + mdl) - base <= e) lo = mdl; else hi = mdl; }
       const uint64_t t = g + lo;
       if (a.pass & PASS_BWT) a.bwt[o] = fix_char(a.pc[t]);
-      if (a.want_sa && (a.pass & PASS_SA)) sa_put(a, o, a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]]);
+      if (a.want_sa && (a.pass & PASS_SA)) sa_put(a, o, a.bwsai[pos] - slot_slen(a, t));
     }
     wave_lds_sync();
   }
@@ -1426,7 +1400,7 @@ __global__ __launch_bounds__(256) void hard_big_kernel(MergeArgsT<I> a, const Bi
     }
     if (base + r >= a.out_lo && base + r < a.out_hi) {
       if (a.pass & PASS_BWT) a.bwt[base + r] = fix_char(a.pc[t]);
-      if (a.want_sa && (a.pass & PASS_SA)) sa_put(a, base + r, a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]]);
+      if (a.want_sa && (a.pass & PASS_SA)) sa_put(a, base + r, a.bwsai[pos] - slot_slen(a, t));
     }
   }
 }
@@ -1466,7 +1440,7 @@ __global__ __launch_bounds__(256) void big_place_kernel(MergeArgsT<I> a, const B
   const uint64_t o = slot_off(a, big[lo].g) + (estart[q0] + i - estart[lo]);
   if (o < a.out_lo || o >= a.out_hi) return;
   if (a.pass & PASS_BWT) a.bwt[o] = fix_char(a.pc[t]);
-  if (a.want_sa && (a.pass & PASS_SA) && sa_wanted(a, o)) sa_put(a, o, a.bwsai[pos] - (uint64_t)a.slen[a.sa[t]]);
+  if (a.want_sa && (a.pass & PASS_SA) && sa_wanted(a, o)) sa_put(a, o, a.bwsai[pos] - slot_slen(a, t));
 }
 
 // loc[t] = sum of cnt over the slots of t's tile before t; tsum[tile] = the tile's total.  256 threads x 8 slots.
@@ -1519,19 +1493,18 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   static const bool dense_always = getenv("PFP_DENSE_SA") != nullptr;      // tests: -s / -e through the dense path
   const int samode = (sa_mode == SA_SPARSE && dense_always && out.d_sa) ? SA_DENSE : sa_mode;
   const bool dense = samode == SA_DENSE;
-  DBuf<WordRec> wrec;
-  if (samode != SA_DENSE) wrec.alloc(c, d);      // the minority path of the hard groups and (sparse SA) the unit edges
+  DBuf<WordRec> wrec(c, d);      // per word: list start, occurrences, smallest / largest BWT(P) position, terminator
   hipLaunchKernelGGL(wistart_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, D.wocc.p, pb.ilist.p,
                      ix.wend.p, wistart.p, wrec.p);
-  DBuf<uint64_t> pp64;
+  const WordView wv = word_view(D, ix);
   DBuf<PosRec> prec;
-  DBuf<uint32_t> cnt, ist, sfirst, slast, ssl;
+  DBuf<uint32_t> cnt, sfirst, slast, ssl;
   // records already sit at their slots - unless most slots were re-ordered after the first round (a
   // dictionary of near-identical variants), where fetching each such record costs more than the gather
   const bool from_keys = !dense && so.paybits == 16 && so.skeys.p && so.n_refined * 5 < N;
-  // BWT only / sparse SA without records in the keys: ONE 16-byte gather per slot (slot_records_kernel)
-  const bool fused = !dense && !from_keys;
-  if (dense) { ist.alloc(c, N + 8); pp64.alloc(c, NP); }
+  // everything else: ONE 16-byte gather per slot (slot_records_kernel); full SA output included - its per-slot inverted-list
+  // start travels in the record's `first` field
+  const bool fused = !from_keys;
   if (!fused) { cnt.alloc(c, N + 8); PFP_HIP(hipMemsetAsync(cnt.p + N, 0, 4, c->stream)); }
   DBuf<uint8_t> pc(c, N + 8), hard(c, N);
   const uint64_t ntile = (N >> kOffTileLog) + 1;        // covers slot index N (one past the last)
@@ -1545,40 +1518,52 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   ovf.zero();
   PFP_HIP(hipMemsetAsync(tsum.p + ntile, 0, 8, c->stream));
   if (fused) {
-    prec.alloc(c, NP);
-    { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + 16));
-      hipLaunchKernelGGL(pprec16_kernel, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, D.bytes.p, NP, d, w, ix.pos_word.p, ix.slen.p,
-                         reinterpret_cast<const uint4 *>(wrec.p), prec.p); }
-    // per-slot copies of what the unit-edge / minority kernels ask about a slot's word (read coalesced there)
-    sfirst.alloc(c, ntile << kOffTileLog); slast.alloc(c, ntile << kOffTileLog);
-    if (samode == SA_SPARSE) ssl.alloc(c, ntile << kOffTileLog);
-    { KScope ks(c, "pfp::slot_gather_kernel", N * (2 * sizeof(I) + 16 + 4 + 1 + 8 + (ssl.p ? 4 : 0)));
-      hipLaunchKernelGGL(slot_records_kernel<I>, gdim((unsigned)ntile), gdim(256), 0, c->stream, N, so.sa.p, so.grp.p, prec.p, loc.p, pc.p,
-                         sfirst.p, slast.p, ssl.p, tsum.p, ovf.p, tile_full.p, first_full.p, hard.p); }
-    prec.release();
+    // 16 bytes per dictionary position - all at once while that stays below an eighth of the device, else in blocks of
+    // positions whose records the slots fetch block by block (a 30 GB dictionary on one rank of the multi-GPU chain:
+    // 480 GB of records otherwise; PFP_PREC_BLOCK = positions per block, for the tests)
+    uint64_t blk = cdiv64(NP, 256) * 256;
+    {
+      const uint64_t dev_bytes = c->pool.soft_limit ? c->pool.soft_limit / 7 * 10 : (64ull << 30);
+      const char *e = getenv("PFP_PREC_BLOCK");
+      const uint64_t cap = e ? strtoull(e, nullptr, 10) : dev_bytes / 8 / sizeof(PosRec);
+      if (blk > cap) blk = std::max<uint64_t>(cap / 256, 1) * 256;
+    }
+    const bool blocked = blk < NP;
+    prec.alloc(c, blk);
+    DBuf<PosRec> srec;
+    if (blocked) srec.alloc(c, std::max<uint64_t>(N, 1));
+    for (uint64_t p0 = 0; p0 < NP; p0 += blk) {
+      const uint64_t p1 = std::min<uint64_t>(p0 + blk, NP);
+      { KScope ks(c, "pfp::pprec_kernel", (p1 - p0) * (1 + 16) + (uint64_t)d * 40);
+        hipLaunchKernelGGL(pprec16_kernel, gdim(cdiv(p1 - p0, TB)), gdim(TB), 0, c->stream, wv, w, reinterpret_cast<const uint4 *>(wrec.p),
+                           dense ? 1 : 0, p0, p1, prec.p); }
+      if (blocked && N) {
+        KScope ks(c, "pfp::slot_gather_kernel", N * sizeof(I));
+        hipLaunchKernelGGL(slot_fetch_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, so.sa.p, p0, p1, prec.p, srec.p);
+      }
+    }
+    const PosRec *recs_p = blocked ? srec.p : prec.p;
+    // per-slot copies of what the unit-edge / minority kernels ask about a slot's word (read coalesced there); full SA:
+    // the list start of every slot's word and its suffix length
+    sfirst.alloc(c, ntile << kOffTileLog);
+    if (!dense) slast.alloc(c, ntile << kOffTileLog);
+    if (samode != SA_NONE) ssl.alloc(c, ntile << kOffTileLog);
+    { KScope ks(c, "pfp::slot_gather_kernel", N * (2 * sizeof(I) + 16 + 4 + 1 + 4 + (slast.p ? 4 : 0) + (ssl.p ? 4 : 0)));
+      hipLaunchKernelGGL(slot_records_kernel<I>, gdim((unsigned)ntile), gdim(256), 0, c->stream, N, so.sa.p, so.grp.p, recs_p, loc.p, pc.p,
+                         sfirst.p, slast.p, ssl.p, tsum.p, ovf.p, tile_full.p, first_full.p, hard.p, dense ? 1 : 0, blocked ? 1 : 0); }
+    prec.release(); srec.release();
   } else {
-  if (from_keys) {
-    KScope ks(c, "pfp::slot_gather_kernel", N * (8 + 1 + 5));
-    hipLaunchKernelGGL(slot_payload_kernel<I>, gdim(cdiv(cdiv64(N, 8), 256)), gdim(256), 0, c->stream, N, so.sa.p, so.skeys.p,
-                       so.refined.p, D.bytes.p, ix.pos_word.p, ix.slen.p, D.wocc.p, d, w, cnt.p, pc.p, tile_full.p, first_full.p);
-  } else {
-  { KScope ks(c, "pfp::pprec_kernel", NP * (1 + 4 + 4 + 8));
-    hipLaunchKernelGGL(pprec_kernel<uint64_t>, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, D.bytes.p, NP, d, w,
-                       ix.pos_word.p, ix.slen.p, D.wocc.p, pp64.p); }
-  { KScope ks(c, "pfp::slot_gather_kernel", N * (sizeof(I) + 5 + 12));
-    const dim3 grid = gdim(cdiv(cdiv64(N, 8), 256));
-    hipLaunchKernelGGL((slot_gather_kernel<uint64_t, I>), grid, gdim(256), 0, c->stream, N, so.sa.p, pp64.p,
-                       ix.pos_word.p, D.wocc.p, wistart.p, cnt.p, pc.p, ist.p, tile_full.p, first_full.p); }
-  }
-  pp64.release();
-  { KScope ks(c, "pfp::slot_loc_kernel", N * 8);
-    hipLaunchKernelGGL(slot_loc_kernel, gdim((unsigned)ntile), gdim(256), 0, c->stream, cnt.p, N, loc.p, tsum.p, ovf.p); }
-  { KScope ks(c, "pfp::group_flags_kernel", N * 5);
-    hipLaunchKernelGGL(group_flags_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, so.grp.p, pc.p, dense ? 1 : 0, hard.p); }
+    { KScope ks(c, "pfp::slot_gather_kernel", N * (8 + 1 + 5));
+      hipLaunchKernelGGL(slot_payload_kernel<I>, gdim(cdiv(cdiv64(N, 8), 256)), gdim(256), 0, c->stream, N, so.sa.p, so.skeys.p,
+                         so.refined.p, D.bytes.p, wv, D.wocc.p, d, w, cnt.p, pc.p, tile_full.p, first_full.p); }
+    { KScope ks(c, "pfp::slot_loc_kernel", N * 8);
+      hipLaunchKernelGGL(slot_loc_kernel, gdim((unsigned)ntile), gdim(256), 0, c->stream, cnt.p, N, loc.p, tsum.p, ovf.p); }
+    { KScope ks(c, "pfp::group_flags_kernel", N * 5);
+      hipLaunchKernelGGL(group_flags_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, so.grp.p, pc.p, 0, hard.p); }
   }
   exclusive_sum_u64(c, tsum.p, tbase.p, ntile + 1);
   exclusive_sum_u32(c, tile_full.p, fullbase.p, ntile + 1);
-  hipLaunchKernelGGL(full_base0_kernel<I>, dim3(1), dim3(1), 0, c->stream, first_full.p, so.sa.p, ix.pos_word.p, ix.lexrank.p, fullbase0.p);
+  hipLaunchKernelGGL(full_base0_kernel<I>, dim3(1), dim3(1), 0, c->stream, first_full.p, so.sa.p, wv, ix.lexrank.p, fullbase0.p);
   PFP_REQUIRE(read_scalar(c, ovf.p) == 0, PFP_ELIMIT, "2048 consecutive suffix-array slots emit 2^32 or more BWT positions");
   const uint64_t n_out = read_scalar(c, tbase.p + ntile);
   PFP_REQUIRE(expect_n_out == 0 || n_out == expect_n_out, PFP_EFORMAT,
@@ -1590,9 +1575,10 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   a.N = N; a.n_out = n_out; a.d = d; a.w = w; a.want_sa = samode;
   a.pos_base = pos_base; a.n_out_global = n_out_global ? n_out_global : n_out;
   { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
-  a.sa = so.sa.p; a.slen = ix.slen.p; a.grp = so.grp.p; a.ist = dense ? ist.p : nullptr;
-  a.pos_word = ix.pos_word.p; a.wistart = wistart.p; a.wrec = wrec.p;
-  a.sfirst = sfirst.p; a.slast = slast.p; a.ssl = ssl.p;
+  a.sa = so.sa.p; a.grp = so.grp.p; a.wv = wv;
+  a.ist = dense ? sfirst.p : nullptr;          // full SA: the record's `first` field held the list start
+  a.wistart = wistart.p; a.wrec = wrec.p;
+  a.sfirst = dense ? nullptr : sfirst.p; a.slast = slast.p; a.ssl = ssl.p;
   a.pc = pc.p; a.hard = hard.p; a.tbase = tbase.p; a.loc = loc.p;
   a.ilist = pb.ilist.p; a.bwlast = pb.bwlast.p; a.bwsai = pb.bwsai.p;
   a.istart_lex = istart_lex.p; a.fullbase = fullbase.p; a.fullbase0 = fullbase0.p;
@@ -1613,13 +1599,13 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   select_index<I>(c, hard.p, heads.p, nheads.p, N);
   // BWT only / sparse SA: majority fill + minority placement; groups it leaves (no dominating char) go to the LDS kernels
   DBuf<uint8_t> gmaj, fallback;
-  DBuf<unsigned long long> mstat(c, 1);
+  DBuf<unsigned long long> mstat(c, 2);      // chars and members of the hard groups the minority path takes
   mstat.zero();
   DBuf<HardGroupInfo> ginfo;
   DBuf<uint32_t> minor_cnt, mm_cnt;
   DBuf<uint64_t> minor_off, mm_off;
   DBuf<MinorMember> mm_list;
-  uint64_t n_mm = 0;
+  uint64_t n_mm = 0, sum_k = 0;
   DBuf<I> fb_heads;
   const I *hard_list = heads.p;             // what hard_groups_kernel works through
   const uint64_t *hard_list_n = nheads.p;
@@ -1636,10 +1622,11 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     exclusive_sum_u32_u64(c, minor_cnt.p, minor_off.p, n_heads + 1);
     exclusive_sum_u32_u64(c, mm_cnt.p, mm_off.p, n_heads + 1);
     n_mm = read_scalar(c, mm_off.p + n_heads);
+    sum_k = read_scalar(c, (const uint64_t *)mstat.p + 1);
     if (n_mm) {
       mm_list.alloc(c, n_mm);
       KScope ks(c, "pfp::hard_minor_fill_kernel", n_heads * 40 + n_mm * 16);
-      hipLaunchKernelGGL(hard_minor_fill_kernel<I>, gdim(cdiv(n_heads, 256)), gdim(256), 0, c->stream, a, ginfo.p, n_heads, mm_off.p,
+      hipLaunchKernelGGL(hard_minor_fill_kernel<I>, gdim(cdiv(n_heads * 8, 256)), gdim(256), 0, c->stream, a, ginfo.p, n_heads, mm_off.p,
                          minor_off.p, gmaj.p, mm_list.p);
     }
     n_fallback = count_flags(c, fallback.p, n_heads);
@@ -1678,8 +1665,14 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   if (n_mm) {
     if (sparse) recs.alloc(c, n_minor + 1);
     KScope ks(c, "pfp::hard_minor_kernel", n_minor * 64);
-    hipLaunchKernelGGL(hard_minor_kernel<I>, gdim((unsigned)std::min<uint64_t>(cdiv64(n_mm, 32), (uint64_t)c->n_cu * 64)), gdim(256), 0,
-                       c->stream, a, mm_list.p, n_mm, recs.p);
+    // lanes per minority member: eight, or the wave where the groups average more than 32 members
+    const uint64_t avg_k = sum_k / std::max<uint64_t>(n_heads - n_fallback, 1);
+    if (avg_k > 32)
+      hipLaunchKernelGGL((hard_minor_kernel<I, 64>), gdim((unsigned)std::min<uint64_t>(cdiv64(n_mm, 4), (uint64_t)c->n_cu * 64)), gdim(256), 0,
+                         c->stream, a, mm_list.p, n_mm, recs.p);
+    else
+      hipLaunchKernelGGL((hard_minor_kernel<I, 8>), gdim((unsigned)std::min<uint64_t>(cdiv64(n_mm, 32), (uint64_t)c->n_cu * 64)), gdim(256), 0,
+                         c->stream, a, mm_list.p, n_mm, recs.p);
   }
   PFP_HIP(hipGetLastError());
   int gpb = 64;      // groups per wave batch: down to 8 while that still leaves every wave of the launch a batch

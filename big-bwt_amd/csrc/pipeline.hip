@@ -217,13 +217,14 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
   {
     PhaseTimer t(c, &st.ms_sa_dict);
     // BWT only: the merge records ride in the spare bits of the first-round keys (SuffixOrder::paybits)
-    const SlotPayloadSrc pay{ch.ix.pos_word.p, ch.ix.slen.p, ch.D.wocc.p, (uint32_t)ch.D.d, w};
+    const WordView wv = word_view(ch.D, ch.ix);
+    const SlotPayloadSrc pay{wv, ch.D.wocc.p, w};
     ch.ord.wide = use_wide_index(c, ch.D.dsize);      // 32- or 64-bit dictionary positions (bigbwt:130-151)
     with_width(ch.ord.wide, [&](auto tag) {
       using I = decltype(tag);
       auto &so = ch.ord.get<I>();
       so.rep_hint = (double)ch.n_used / (double)std::max<uint64_t>(ch.D.dsize, 1);
-      sort_dict_suffixes<I>(c, ch.D.bytes.p, ch.D.dsize, ch.ix.slen.p, so, dense_sa ? nullptr : &pay);
+      sort_dict_suffixes<I>(c, ch.D.bytes.p, ch.D.dsize, wv, so, dense_sa ? nullptr : &pay);
       if (c->debug) validate_suffix_order<I>(c, ch.D.bytes.p, so, true, "dict SA");
       compute_lexrank<I>(c, ch.D, so, ch.ix);
       if (!c->debug) { so.rank.release(); so.tab.release(); }      // the merge reads sa / grp / skeys only
@@ -679,12 +680,12 @@ static void dictionary_from_host(pfp_ctx *c, const uint8_t *s, uint64_t n, Dicti
 // SA[i], where a separator (1) or the final 0 ends the count (gsa/README.md:76-104); DA[i] = index of the string
 // the suffix SA[i] starts in.  One thread per slot compares its two suffixes 8 bytes at a time.
 template <class I, class L>
-__global__ void lcp_da_kernel(const uint8_t *__restrict__ s, uint64_t n, const I *__restrict__ sa, const uint32_t *__restrict__ pos_word,
+__global__ void lcp_da_kernel(const uint8_t *__restrict__ s, uint64_t n, const I *__restrict__ sa, WordView wv,
                               L *__restrict__ lcp, L *__restrict__ da) {
   const uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const uint64_t b = sa[t];
-  if (da) da[t] = (L)pos_word[b];
+  if (da) da[t] = (L)word_of(wv, b);
   if (!lcp) return;
   if (t == 0) { lcp[0] = 0; return; }
   const uint64_t a = sa[t - 1];
@@ -710,11 +711,11 @@ static void gsacak_any(pfp_ctx *c, const uint8_t *s, OUT *SA, uint64_t n, L *LCP
   with_width(use_wide_index(c, n), [&](auto tag) {
     using I = decltype(tag);
     SuffixOrderT<I> so;
-    sort_dict_suffixes<I>(c, D.bytes.p, n, ix.slen.p, so);
+    sort_dict_suffixes<I>(c, D.bytes.p, n, word_view(D, ix), so);
     fetch_converted<I, OUT>(c, so.sa.p, n, SA);
     if (LCP || DA) {
       DBuf<L> dl(c, LCP ? n : 1), dd(c, DA ? n : 1);
-      hipLaunchKernelGGL((lcp_da_kernel<I, L>), gdim(cdiv(n, TB)), gdim(TB), 0, c->stream, D.bytes.p, n, so.sa.p, ix.pos_word.p,
+      hipLaunchKernelGGL((lcp_da_kernel<I, L>), gdim(cdiv(n, TB)), gdim(TB), 0, c->stream, D.bytes.p, n, so.sa.p, word_view(D, ix),
                          LCP ? dl.p : (L *)nullptr, DA ? dd.p : (L *)nullptr);
       PFP_HIP(hipGetLastError());
       if (LCP) d2h(c, LCP, dl.p, n);
@@ -824,12 +825,13 @@ int pfp_merge(pfp_ctx *c, const uint8_t *dict, uint64_t dict_size, const uint32_
   D.wocc.alloc(c, D.d);
   h2d(c, D.wocc.p, occ, D.d);
   if (c->debug) validate_index(c, D, ix);
-  const SlotPayloadSrc pay{ix.pos_word.p, ix.slen.p, D.wocc.p, (uint32_t)D.d, w};
+  const WordView wv = word_view(D, ix);
+  const SlotPayloadSrc pay{wv, D.wocc.p, w};
   ord.wide = use_wide_index(c, D.dsize);      // pfbwt[NT].x or pfbwt[NT]64.x (bigbwt:130-151)
   with_width(ord.wide, [&](auto tag) {
     using I = decltype(tag);
     auto &so = ord.get<I>();
-    sort_dict_suffixes<I>(c, D.bytes.p, D.dsize, ix.slen.p, so, (flags & PFP_FLAG_SA) ? nullptr : &pay);
+    sort_dict_suffixes<I>(c, D.bytes.p, D.dsize, wv, so, (flags & PFP_FLAG_SA) ? nullptr : &pay);
     if (c->debug) validate_suffix_order<I>(c, D.bytes.p, so, true, "dict SA");
     compute_lexrank<I>(c, D, so, ix);
   });
@@ -1232,7 +1234,8 @@ static void dist_sort_global(pfp_ctx *c, DistState *ds, uint32_t part, uint32_t 
   ds->ord = DictOrder();
   build_dict_index(c, ds->G, ds->ix);
   const uint32_t d = (uint32_t)ds->G.d;
-  const SlotPayloadSrc pay{ds->ix.pos_word.p, ds->ix.slen.p, ds->G.wocc.p, d, ds->w};
+  const WordView wv = word_view(ds->G, ds->ix);
+  const SlotPayloadSrc pay{wv, ds->G.wocc.p, ds->w};
   const SlotPayloadSrc *payp = (ds->flags & PFP_FLAG_SA) ? nullptr : &pay;      // full SA: the merge gathers wider records itself
   ds->ord.wide = use_wide_index(c, ds->G.dsize);
   // phrases per distinct word = text bytes per dictionary byte, near enough (the same on every rank: the keys-only
@@ -1250,15 +1253,15 @@ static void dist_sort_global(pfp_ctx *c, DistState *ds, uint32_t part, uint32_t 
     auto &so = ds->ord.get<I>();
     so.rep_hint = rep_hint;
     if (parts == 1) {
-      sort_dict_suffixes<I>(c, ds->G.bytes.p, ds->G.dsize, ds->ix.slen.p, so, payp);
+      sort_dict_suffixes<I>(c, ds->G.bytes.p, ds->G.dsize, wv, so, payp);
       if (c->debug) validate_suffix_order<I>(c, ds->G.bytes.p, so, true, "global dict SA");
       DBuf<I> slots(c, d);
       gather_ranks<I>(c, so, ds->G.woff.p, d, slots.p);
       hipLaunchKernelGGL(add_one_kernel<I>, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, slots.p, (uint64_t *)d_wslot_out);
       ds->local_total = 0;
     } else {
-      sort_dict_suffixes_range<I>(c, ds->G.bytes.p, ds->G.dsize, ds->ix.slen.p, part, parts, so, payp, &pay);
-      gather_slots_range<I>(c, so, ds->G.woff.p, d, (uint64_t *)d_wslot_out);
+      sort_dict_suffixes_range<I>(c, ds->G.bytes.p, ds->G.dsize, wv, part, parts, so, payp, &pay);
+      gather_slots_range<I>(c, so, wv, d, (uint64_t *)d_wslot_out);
       ds->local_total = so.complete ? so.range_emits : 0;
       if (c->debug && so.complete)
         PFP_REQUIRE(count_slot_outputs<I>(c, ds->G, ds->ix, so, ds->w) == ds->local_total, PFP_EHIP,

@@ -28,12 +28,12 @@ namespace pfp {
 enum : int { MODE_DICT = 0, MODE_PLAIN = 1 };
 
 struct SufGeom {
-  int mode; uint64_t N; const uint32_t *slen;   // slen[i] = distance from i to the terminator of i's word
+  int mode; uint64_t N; WordView wv;            // dictionary mode: where the word of a position ends
   const uint32_t *sym = nullptr;                // plain mode on an integer string (unique smallest last symbol): the string
 };
 // length of the suffix string starting at i, terminator included
 __device__ __forceinline__ uint64_t suf_len(const SufGeom &g, uint64_t i) {
-  if (g.mode == MODE_DICT) return (uint64_t)g.slen[i] + 1;
+  if (g.mode == MODE_DICT) return slen_of(g.wv, i) + 1;
   return g.N - i;
 }
 
@@ -190,9 +190,8 @@ __device__ __forceinline__ I rank_at(const RankViewT<I> &L, uint64_t j, bool &se
 
 // merge record of position i: low byte = preceding char (1 = whole word, pfbwt.cpp:153; 0 = emits
 // nothing, <= w long, pfbwt.cpp:151), high byte = occurrences of its word, 255 = "255 or more"
-__device__ __forceinline__ uint32_t slot_record(const uint8_t *__restrict__ b, uint64_t i, const SlotPayloadSrc &P) {
-  const uint32_t wd = P.pos_word[i];
-  if (!(wd < P.d && P.slen[i] > (uint32_t)P.w)) return 0u;
+__device__ __forceinline__ uint32_t slot_record(const uint8_t *__restrict__ b, uint64_t i, uint32_t wd, const SlotPayloadSrc &P) {
+  if (!(wd < P.wv.d && P.wv.wend[wd] - i > (uint64_t)P.w)) return 0u;
   const uint32_t pc = (i == 0) ? kEndOfWord : b[i - 1];
   const uint32_t occ = P.wocc[wd];
   return pc | ((occ < 255u ? occ : 255u) << 8);
@@ -203,11 +202,16 @@ __device__ __forceinline__ uint32_t slot_record(const uint8_t *__restrict__ b, u
 // terminator (endpos) and at 32 characters - exactly what packed_key_at assembles character by
 // character (checked against it under PFP_DEBUG).  224 positions per workgroup, 32 characters of overlap.
 constexpr int kKeyPos = 224;
-struct KeyStreamLds { uint32_t off[257]; uint32_t bs[200]; uint32_t wsum[4]; };
+struct KeyStreamLds { uint32_t off[257]; uint32_t bs[200]; uint32_t wsum[4]; unsigned long long tmask[4]; uint32_t wbase; };
 // workgroup-cooperative: returns the key (code bits << 1 | terminator flag) of position B0 + threadIdx.x
 // for threadIdx.x < kKeyPos and position < N; every thread of the workgroup must call it
+// Where a position's word ends is read off the block's own characters (the first byte <= 1 at or after it, looked for
+// over the 32 characters a key can cover): no per-position length array is read.
+// word_out (optional, needs wv): the word of position B0 + threadIdx.x - the word of the block's first position (one lookup
+// per block) plus the terminators the ballots count before the lane.
 __device__ __forceinline__ uint64_t block_stream_key(KeyStreamLds &L, const uint8_t *__restrict__ s, uint64_t N,
-                                                     const KeyCode &kp, const uint32_t *__restrict__ slen, uint64_t B0) {
+                                                     const KeyCode &kp, uint64_t B0, const WordView *view = nullptr,
+                                                     uint32_t *word_out = nullptr) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint64_t pos = B0 + t;
   if (t < 200) L.bs[t] = 0;
@@ -217,7 +221,15 @@ __device__ __forceinline__ uint64_t block_stream_key(KeyStreamLds &L, const uint
   uint32_t inc = l;
   for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
   if (lane == 63) L.wsum[wv] = inc;
+  const unsigned long long tmine = __ballot(c <= (uint32_t)kEndOfWord);      // terminators (0x01) and the final 0x00 / the padding behind it
+  if (lane == 0) L.tmask[wv] = tmine;
+  if (word_out && t == 0) L.wbase = B0 < N ? word_of(*view, B0) : 0u;
   __syncthreads();
+  if (word_out) {
+    uint32_t before = (uint32_t)__popcll(tmine & ((1ull << lane) - 1ull));
+    for (int q = 0; q < wv; q++) before += (uint32_t)__popcll(L.tmask[q]);
+    *word_out = L.wbase + before;
+  }
   uint32_t base = 0;
   for (int q = 0; q < wv; q++) base += L.wsum[q];
   const uint32_t p = base + inc - l;            // bit offset of this character's code
@@ -234,7 +246,14 @@ __device__ __forceinline__ uint64_t block_stream_key(KeyStreamLds &L, const uint
   }
   __syncthreads();
   if (t >= kKeyPos || pos >= N) return 0;
-  const uint32_t toterm = slen[pos] + 1;        // characters up to and including the terminator of this position's word
+  // characters up to and including the terminator of this position's word (33 = "more than a key can cover")
+  uint32_t toterm = 33u;
+  {
+    const unsigned long long m0 = tmine >> lane;
+    if (m0) toterm = (uint32_t)__builtin_ctzll(m0) + 1u;
+    else if (wv < 3) { const unsigned long long m1 = L.tmask[wv + 1]; if (m1) toterm = (uint32_t)(64 - lane) + (uint32_t)__builtin_ctzll(m1) + 1u; }
+    if (toterm > 33u) toterm = 33u;
+  }
   const uint32_t nch = toterm < 32u ? toterm : 32u;
   const uint32_t avail = L.off[t + nch] - p;
   const uint32_t kb = (uint32_t)kp.kbits;
@@ -250,16 +269,16 @@ __device__ __forceinline__ uint64_t block_stream_key(KeyStreamLds &L, const uint
 }
 template <class I>
 __global__ __launch_bounds__(256) void init_keys_packed_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
-                                                               const uint32_t *__restrict__ slen, SlotPayloadSrc P,
-                                                               int paybits, uint64_t *__restrict__ key,
+                                                               SlotPayloadSrc P, int paybits, uint64_t *__restrict__ key,
                                                                I *__restrict__ val, int idx_bits) {
   __shared__ KeyStreamLds L;
   const uint64_t B0 = (uint64_t)BID * kKeyPos;
-  uint64_t k = block_stream_key(L, s, N, kp, slen, B0);
+  uint32_t wd = 0;
+  uint64_t k = paybits ? block_stream_key(L, s, N, kp, B0, &P.wv, &wd) : block_stream_key(L, s, N, kp, B0);
   const uint64_t pos = B0 + threadIdx.x;
   if (threadIdx.x >= kKeyPos || pos >= N) return;
   if (idx_bits) { key[pos] = (k << idx_bits) | pos; return; }      // keys-only sort: the position rides in the low bits
-  if (paybits) k |= (uint64_t)slot_record(s, pos, P) << 48;
+  if (paybits) k |= (uint64_t)slot_record(s, pos, wd, P) << 48;
   key[pos] = k; val[pos] = (I)pos;
 }
 // sorted (key << idx_bits | position) words -> the sorted keys and the sorted positions
@@ -615,6 +634,11 @@ __global__ void scatter_settled_kernel(uint64_t N, const I *__restrict__ sa, con
 constexpr int kPivBits = 23;
 constexpr uint32_t kPivEq = 1u << 21;
 constexpr uint32_t kPivCapMax = 8192;
+// (Tried in round 3: eight lanes per member, 128 contiguous bytes of the member's string per load instruction, the pivot's
+//  bytes coalesced, ballot for the first differing chunk.  Same lines fetched, 3x fewer address-coalescer cycles - and 17 %
+//  SLOWER (c3 6.8 -> 7.9 ms, 12.6 GB 107 -> 120 ms): the kernel is bound by the rate at which HBM serves random lines
+//  (~54 G/s, tools/microbench/gather.hip; 112 M members x ~1.6 lines + their pivots' = 3.9 ms at that rate), not by
+//  its instruction stream, and eight times the waves only add ballots.  One thread per member stays.)
 template <class I>
 __global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t m, uint64_t from, uint32_t cap,
                                         const I *__restrict__ act_i, const I *__restrict__ act_grp,
@@ -721,7 +745,7 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
   // (a whole word is a singleton group: only a suffix alone in its group can be one; which positions start a word is
   // read from a bitmap of N bits - it stays cache resident where the dictionary bytes would not)
   if (wstart_bits) wr = !k && single && ((wstart_bits[i >> 5] >> (i & 31)) & 1u);
-  if (wr) rank[i] = newhead[a] | (k ? (I)0 : finbit);
+  if (wr && rank) rank[i] = newhead[a] | (k ? (I)0 : finbit);
   keep[a] = k ? 1 : 0;
 }
 
@@ -823,7 +847,7 @@ __global__ void finish_write_kernel(uint64_t m, const I *__restrict__ aslot, con
   const I i = act_i[a], slot = aslot[gs + lt[a] + eq[a]], head = aslot[gs + lt[a]];
   sa[slot] = i;
   grp[slot] = head;            // identical strings share their group's first slot
-  rank[i] = head | finbit;
+  if (rank) rank[i] = head | finbit;
 }
 
 // after the first round, pivot rounds are tried while the groups are families (average size up to
@@ -881,7 +905,11 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   };
   DBuf<uint8_t> hd(c, N + 1), keep(c, N);
   out.grp.alloc(c, N + 8);
-  out.rank.alloc(c, NP);
+  // a share of the suffix array (multi-GPU) never runs a doubling round - it stops where one would be needed - and finds
+  // its whole words by looking at its own slots (gather_slots_range): no rank per dictionary position is kept
+  const bool no_rank = range_mode;
+  out.rank.alloc(c, no_rank ? 1 : NP);
+  I *const rank_p = no_rank ? (I *)nullptr : out.rank.p;
   if (!lazy) {
     out.sa.alloc(c, N);
     alloc_lists(N);
@@ -896,7 +924,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     out.tab.alloc(c, out.T);
     hipLaunchKernelGGL(fill_kernel<I>, gdim(cdiv(out.T, TB)), gdim(TB), 0, c->stream, out.tab.p, (uint64_t)out.T,
                        (I)(IdxTraits<I>::kNone - (I)N));
-    PFP_HIP(hipMemsetAsync(out.rank.p, 0xff, NP * sizeof(I), c->stream));
+    if (!no_rank) PFP_HIP(hipMemsetAsync(out.rank.p, 0xff, NP * sizeof(I), c->stream));
   }
   const int nb = bits_for(N);           // key of a later round = (group head << nb) | (1 + rank of the continuation)
   const int keybits = 2 * nb;
@@ -1000,7 +1028,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     if (round0) {
       { KScope ks(c, "pfp::write_back_kernel", m * (4 + 4 + 1 + 8 + 4 + 1));
         hipLaunchKernelGGL(write_back0_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, valo.p, tile_scan.p, hd.p, keyo.p,
-                           out.rank.p, out.grp.p, keep.p, lazy_active ? 0 : 1); }
+                           rank_p, out.grp.p, keep.p, (lazy_active || no_rank) ? 0 : 1); }
       if (lazy_active) active_stale = true;
       // the sorted keys and the sorted positions stay with the result; later rounds sort the (smaller) active set elsewhere
       out.skeys = std::move(keyo);
@@ -1027,12 +1055,12 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       const I *prevgrp = (have_prev && seg_round) ? act_grp.p : (const I *)nullptr;
       if (dbl_round && kWide && !seg_round)
         hipLaunchKernelGGL((write_back_kernel<I, K>), gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p, hd.p,
-                           out.finbit, have_prev ? dkeyo.p : (const K *)nullptr, nb, prevgrp, vetop, lazyb, out.sa.p, out.rank.p,
+                           out.finbit, have_prev ? dkeyo.p : (const K *)nullptr, nb, prevgrp, vetop, lazyb, out.sa.p, rank_p,
                            out.grp.p, keep.p);
       else
         hipLaunchKernelGGL((write_back_kernel<I, uint64_t>), gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p,
                            hd.p, out.finbit, (have_prev && !seg_round) ? keyo.p : (const uint64_t *)nullptr, pivot_round ? kPivBits : nb,
-                           prevgrp, vetop, lazyb, out.sa.p, out.rank.p, out.grp.p, keep.p);
+                           prevgrp, vetop, lazyb, out.sa.p, rank_p, out.grp.p, keep.p);
       if (pivot_round && lazy_pivot_ranks) { ranks_stale = true; active_stale = true; }
     }
     uint64_t m2 = 0, ngrp = 0;
@@ -1115,7 +1143,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
                          fgs.p, fov.p);
       if (read_scalar(c, fov.p) == 0) {
         hipLaunchKernelGGL(finish_write_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, aslot.p, act_i.p, flt.p, feq.p, fgs.p,
-                           out.finbit, out.sa.p, out.grp.p, out.rank.p);
+                           out.finbit, out.sa.p, out.grp.p, rank_p);
         PFP_HIP(hipGetLastError());
         if (trace_rounds) fprintf(stderr, "[pfp] doubling N=%llu round=%llu: the last %llu suffixes ranked by comparison\n",
                                   (unsigned long long)N, (unsigned long long)out.rounds, (unsigned long long)m);
@@ -1222,7 +1250,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     out.rounds++;
   }
   // PFP_DEBUG validates the rank of every position: fill in what the pivot rounds left out
-  if (c->debug && out.complete) repair_ranks(0, nullptr);
+  if (c->debug && out.complete && !no_rank) repair_ranks(0, nullptr);
 }
 
 template <class I>
@@ -1268,11 +1296,11 @@ static int keysonly_bits(uint64_t N, double rep_hint, KeyCode &kc) {
 }
 
 template <class I>
-void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *slen, SuffixOrderT<I> &out,
+void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const WordView &wv, SuffixOrderT<I> &out,
                         const SlotPayloadSrc *pay) {
   PFP_REQUIRE(N >= 1 && (sizeof(I) == 8 ? N < (1ull << 40) : N < 0xFFFFFFF0ull), PFP_ELIMIT,
               sizeof(I) == 8 ? "dictionary of 2^40 bytes or more" : "dictionary too large for 32-bit suffix indices");
-  SufGeom g{MODE_DICT, N, slen};
+  SufGeom g{MODE_DICT, N, wv};
   KeyCode kc = dict_key_code(c, bytes, N, out.rep_hint);
   // Keys-only first round.  A dictionary of a repetitive collection (text / dictionary >= 2) is mostly families of
   // variants that no first-round key separates, whatever its width: the first round only has to bring the families
@@ -1287,7 +1315,7 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   out.paybits = (pay && !no_payload && !idx_bits && kc.kbits + 1 <= 48) ? 16 : 0;
   out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
   { KScope ks(c, "pfp::init_keys_packed_kernel", N * (9 + (idx_bits ? 0 : sizeof(I)) + (out.paybits ? 9 : 0)));
-    hipLaunchKernelGGL(init_keys_packed_kernel<I>, gdim((unsigned)cdiv64(N, kKeyPos)), gdim(256), 0, c->stream, bytes, N, kc, slen,
+    hipLaunchKernelGGL(init_keys_packed_kernel<I>, gdim((unsigned)cdiv64(N, kKeyPos)), gdim(256), 0, c->stream, bytes, N, kc,
                        pay ? *pay : SlotPayloadSrc{}, out.paybits, key.p, val.p, idx_bits); }
   if (c->debug) {
     DBuf<unsigned long long> bad(c, 1);
@@ -1303,8 +1331,8 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint
   out.bytes = bytes; out.kbits = kc.kbits;
   doubling<I>(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true, ~0ull, idx_bits);
 }
-template void sort_dict_suffixes<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, SuffixOrderT<uint32_t> &, const SlotPayloadSrc *);
-template void sort_dict_suffixes<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, SuffixOrderT<uint64_t> &, const SlotPayloadSrc *);
+template void sort_dict_suffixes<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, const WordView &, SuffixOrderT<uint32_t> &, const SlotPayloadSrc *);
+template void sort_dict_suffixes<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t, const WordView &, SuffixOrderT<uint64_t> &, const SlotPayloadSrc *);
 
 // ---- key-range sharded variant (multi-GPU)
 __global__ void sample_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t stride, uint32_t ns, KeyCode kp,
@@ -1322,25 +1350,23 @@ __global__ void sample_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, ui
 // Also sums, over the suffixes of the range, the occurrences of their words (count.pos_word != null): the
 // number of BWT positions this range will emit, known before anything is sorted.
 __global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
-                                                          const uint32_t *__restrict__ slen, uint64_t klo, uint64_t khi,
-                                                          int khi_open, SlotPayloadSrc count, uint8_t *__restrict__ flag,
+                                                          uint64_t klo, uint64_t khi,
+                                                          int khi_open, SlotPayloadSrc count, int want_count, uint8_t *__restrict__ flag,
                                                           unsigned long long *__restrict__ tile_below,
                                                           unsigned long long *__restrict__ tile_emits) {
   __shared__ KeyStreamLds L;
   __shared__ unsigned long long wsum[2][4];
   if ((uint64_t)BID * kKeyPos >= N) return;      // a workgroup of the padded last grid row
   const uint64_t B0 = (uint64_t)BID * kKeyPos;
-  const uint64_t k = block_stream_key(L, s, N, kp, slen, B0);
+  uint32_t wd = 0;
+  const uint64_t k = want_count ? block_stream_key(L, s, N, kp, B0, &count.wv, &wd) : block_stream_key(L, s, N, kp, B0);
   const uint64_t i = B0 + threadIdx.x;
   unsigned long long cnt = 0, emits = 0;
   if (threadIdx.x < kKeyPos && i < N) {
     cnt = k < klo ? 1ull : 0ull;
     const bool mine = k >= klo && (khi_open || k < khi);
     flag[i] = mine ? 1 : 0;
-    if (mine && count.pos_word) {
-      const uint32_t wd = count.pos_word[i];
-      if (wd < count.d && count.slen[i] > (uint32_t)count.w) emits = count.wocc[wd];
-    }
+    if (mine && want_count && wd < count.wv.d && count.wv.wend[wd] - i > (uint64_t)count.w) emits = count.wocc[wd];
   }
   for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o, 64); emits += __shfl_down(emits, o, 64); }
   if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = cnt; wsum[1][threadIdx.x >> 6] = emits; }
@@ -1365,7 +1391,7 @@ __global__ __launch_bounds__(256) void sum2_u64_kernel(const unsigned long long 
 }
 template <class I>
 __global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__restrict__ s, uint64_t n, KeyCode kp,
-                                                             SlotPayloadSrc P, int paybits, const I *__restrict__ idx,
+                                                             const I *__restrict__ idx,
                                                              uint64_t *__restrict__ key, I *__restrict__ val, int idx_bits) {
   __shared__ uint32_t lut[256];
   lut[threadIdx.x] = kp.lut[threadIdx.x];
@@ -1373,19 +1399,41 @@ __global__ __launch_bounds__(256) void init_keys_list_kernel(const uint8_t *__re
   uint64_t a = (uint64_t)BID * 256 + threadIdx.x;
   if (a >= n) return;
   const I i = idx[a];
-  uint64_t k = packed_key_at(s, i, kp.kbits, lut);
+  const uint64_t k = packed_key_at(s, i, kp.kbits, lut);
   if (idx_bits) { key[a] = (k << idx_bits) | (uint64_t)i; return; }      // keys-only sort (the list is in position order)
-  if (paybits) k |= (uint64_t)slot_record(s, i, P) << 48;
   key[a] = k; val[a] = i;
 }
 
+// the suffixes of a LIST of positions (ascending) sorted among themselves: first-round keys position by position, then the
+// rounds of doubling() in its range mode (no rank per dictionary position; out.complete == false where only a doubling
+// round - ranks of suffixes outside the list - could go on).  Releases idx.
 template <class I>
-void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const uint32_t *slen, uint32_t part,
+static void sort_suffix_list(pfp_ctx *c, const SufGeom &g, const KeyCode &kc, int idx_bits, DBuf<I> &idx, uint64_t n, SuffixOrderT<I> &out) {
+  DBuf<uint64_t> key(c, std::max<uint64_t>(n, 1));
+  DBuf<I> val;
+  if (!idx_bits) val.alloc(c, std::max<uint64_t>(n, 1));
+  out.paybits = 0;
+  out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
+  if (n) {
+    KScope ks(c, "pfp::init_keys_packed_kernel", (uint64_t)n * 17);
+    hipLaunchKernelGGL(init_keys_list_kernel<I>, gdim(cdiv(n, 256)), gdim(256), 0, c->stream, g.wv.bytes, (uint64_t)n, kc, idx.p, key.p, val.p,
+                       idx_bits);
+  }
+  idx.release();
+  out.lut.alloc(c, 256);
+  PFP_HIP(hipMemcpyAsync(out.lut.p, kc.lut, 1024, hipMemcpyHostToDevice, c->stream));
+  sync(c);      // kc may be a stack object of the caller
+  out.bytes = g.wv.bytes; out.kbits = kc.kbits;
+  doubling<I>(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true, (uint64_t)n, idx_bits);
+}
+
+template <class I>
+void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const WordView &wv, uint32_t part,
                               uint32_t parts, SuffixOrderT<I> &out, const SlotPayloadSrc *pay, const SlotPayloadSrc *count) {
   PFP_REQUIRE(N >= 1 && (sizeof(I) == 8 ? N < (1ull << 40) : N < 0xFFFFFFF0ull), PFP_ELIMIT,
               sizeof(I) == 8 ? "dictionary of 2^40 bytes or more" : "dictionary too large for 32-bit suffix indices");
   PFP_REQUIRE(parts >= 1 && part < parts, PFP_EINVAL, "bad key-range share");
-  SufGeom g{MODE_DICT, N, slen};
+  SufGeom g{MODE_DICT, N, wv};
   KeyCode kc = dict_key_code(c, bytes, N, out.rep_hint);
   const int idx_bits = keysonly_bits<I>(N, out.rep_hint, kc);      // (before the splitters: every rank cuts the same keys)
   // splitters: every stride-th suffix's key, sorted; the same on every rank
@@ -1410,8 +1458,8 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   {
     const uint64_t nblk = cdiv64(N, kKeyPos);
     DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
-    hipLaunchKernelGGL(range_flags_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, kc, slen, klo, khi, khi_open,
-                       count ? *count : SlotPayloadSrc{}, flag.p, tb.p, te.p);
+    hipLaunchKernelGGL(range_flags_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, kc, klo, khi, khi_open,
+                       count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
     hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, tb.p, te.p, nblk,
                        below.p);
   }
@@ -1425,55 +1473,255 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   const uint64_t slot_base = c->h_scalars[1];
   const uint64_t range_emits = c->h_scalars[2];
   flag.release();
-  DBuf<uint64_t> key(c, std::max<uint64_t>(n_mine, 1));
-  DBuf<I> val;
-  if (!idx_bits) val.alloc(c, std::max<uint64_t>(n_mine, 1));
-  static const bool no_payload = getenv("PFP_NO_PAYLOAD") != nullptr;
-  out.paybits = (pay && !no_payload && !idx_bits && kc.kbits + 1 <= 48) ? 16 : 0;
-  out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
-  if (n_mine) {
-    KScope ks(c, "pfp::init_keys_packed_kernel", (uint64_t)n_mine * 17);
-    hipLaunchKernelGGL(init_keys_list_kernel<I>, gdim(cdiv(n_mine, 256)), gdim(256), 0, c->stream, bytes, (uint64_t)n_mine, kc,
-                       pay ? *pay : SlotPayloadSrc{}, out.paybits, idx.p, key.p, val.p, idx_bits);
-  }
-  idx.release();
-  out.lut.alloc(c, 256);
-  PFP_HIP(hipMemcpyAsync(out.lut.p, kc.lut, 1024, hipMemcpyHostToDevice, c->stream));
-  sync(c);      // kc is a stack object
-  out.bytes = bytes; out.kbits = kc.kbits;
-  doubling<I>(c, g, key, val, (uint64_t)kc.hmin, out, kc.kbits + 1, true, (uint64_t)n_mine, idx_bits);
+  sort_suffix_list<I>(c, g, kc, idx_bits, idx, n_mine, out);
+  (void)pay;      // (no merge records in the keys of a share: its positions are a scattered list, every record would be a word lookup)
   out.slot_base = slot_base; out.klo = klo; out.khi = khi_open ? ~0ull : khi; out.range_emits = range_emits;
 }
-template void sort_dict_suffixes_range<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, uint32_t, uint32_t,
+template void sort_dict_suffixes_range<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, const WordView &, uint32_t, uint32_t,
                                                  SuffixOrderT<uint32_t> &, const SlotPayloadSrc *, const SlotPayloadSrc *);
-template void sort_dict_suffixes_range<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t, const uint32_t *, uint32_t, uint32_t,
+template void sort_dict_suffixes_range<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t, const WordView &, uint32_t, uint32_t,
                                                  SuffixOrderT<uint64_t> &, const SlotPayloadSrc *, const SlotPayloadSrc *);
 
+// range mode: out[word] = 1 + SA(D) slot of the word's whole-word suffix for the words whose suffix lies in this share (the others
+// stay 0).  A share keeps no rank per position: it looks at its own slots - the suffix of slot t is a whole word iff the
+// byte before it is a terminator - and asks the word lookup which word that is.
 template <class I>
-__global__ void gather_slots_range_kernel(RankViewT<I> L, uint64_t klo, uint64_t khi, uint64_t slot_base, uint64_t count,
-                                          const uint64_t *__restrict__ pos, uint64_t *__restrict__ out) {
-  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
-  if (a >= count) return;
-  const uint64_t j = pos[a];
-  const uint64_t k = packed_key_at(L.bytes, j, L.kbits, L.lut);
-  uint64_t r = 0;
-  if (k >= klo && (khi == ~0ull || k < khi)) { bool settled; r = slot_base + (uint64_t)rank_at(L, j, settled) + 1; }
-  out[a] = r;
+__global__ void word_slots_range_kernel(uint64_t N, const I *__restrict__ sa, WordView wv, uint64_t slot_base, uint64_t *__restrict__ out) {
+  const uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const uint64_t i = sa[t];
+  if (i != 0 && wv.bytes[i - 1] != kEndOfWord) return;
+  const uint32_t wd = word_of(wv, i);
+  if (wd < wv.d) out[wd] = slot_base + t + 1;
 }
 template <class I>
-void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, uint64_t count, uint64_t *d_out) {
+void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const WordView &wv, uint64_t count, uint64_t *d_out) {
   if (!count) return;
-  hipLaunchKernelGGL(gather_slots_range_kernel<I>, gdim(cdiv(count, 256)), gdim(256), 0, c->stream, rank_view(so), so.klo, so.khi,
-                     so.slot_base, count, d_pos, d_out);
+  PFP_HIP(hipMemsetAsync(d_out, 0, count * 8, c->stream));
+  if (so.N) hipLaunchKernelGGL(word_slots_range_kernel<I>, gdim(cdiv(so.N, 256)), gdim(256), 0, c->stream, so.N, so.sa.p, wv, so.slot_base, d_out);
   PFP_HIP(hipGetLastError());
 }
-template void gather_slots_range<uint32_t>(pfp_ctx *, const SuffixOrderT<uint32_t> &, const uint64_t *, uint64_t, uint64_t *);
-template void gather_slots_range<uint64_t>(pfp_ctx *, const SuffixOrderT<uint64_t> &, const uint64_t *, uint64_t, uint64_t *);
+template void gather_slots_range<uint32_t>(pfp_ctx *, const SuffixOrderT<uint32_t> &, const WordView &, uint64_t, uint64_t *);
+template void gather_slots_range<uint64_t>(pfp_ctx *, const SuffixOrderT<uint64_t> &, const WordView &, uint64_t, uint64_t *);
+
+// ---- dictionaries of repetitive collections: equal suffixes found without comparing them
+//
+// The dictionary of a collection of similar sequences is families of words - a phrase and its variants - and most of its
+// suffixes are duplicates: the variant's suffixes that start behind its last difference ARE the base word's (87 % of the
+// 129 M suffixes of the 64-copy workload tie in the first round, and the first pivot round reads ~90 bytes of each to find
+// most of them identical: a third of the dictionary sort).  Whether two suffixes are the same string can be read off the
+// WORDS instead: sort the d words by their REVERSED strings (d is small: 0.7 M words for 129 M suffixes) and keep the
+// longest common suffix lcs[r] of neighbours r - 1, r in that order.  The suffix of length L of the word at rank r is a
+// duplicate of its left neighbour's iff lcs[r] >= L; the words sharing it are the run r .. e - 1, e the next rank with
+// lcs[e] < L.  So only the suffixes with L > lcs[r] (one per distinct string; and only those longer than w, the others
+// emit nothing, pfbwt.cpp:151) are suffix-sorted - as a list, with the same first-round keys and pivot rounds - and every
+// sorted representative is then expanded into its run: the slots of a group, all at once.  The result is the same
+// (sa, grp) the merge takes from the full sort, without the slots that emit nothing; members of a group stand in
+// reverse-lexicographic word order (nothing downstream depends on their order inside a group).
+// (the reference finds equal suffixes from the LCP array of the full suffix array, pfbwt.cpp:204-209)
+
+// reversed words in the layout of the dictionary: word j's bytes back to front at the same offsets, same terminators
+__global__ __launch_bounds__(256) void reverse_words_kernel(WordView wv, const uint64_t *__restrict__ woff, uint8_t *__restrict__ out) {
+  __shared__ uint32_t wt[4];
+  const uint64_t i = (uint64_t)BID * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+  const uint32_t ch = i < wv.NP ? (uint32_t)wv.bytes[i] : 0u;
+  const unsigned long long tm = __ballot(ch == (uint32_t)kEndOfWord);
+  if (lane == 0) wt[wvi] = (uint32_t)__popcll(tm);
+  __syncthreads();
+  if (i >= wv.NP) return;
+  uint32_t wd = wv.blk_word[(uint64_t)BID * 4] + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
+  for (int q = 0; q < wvi; q++) wd += wt[q];
+  uint8_t o = (uint8_t)ch;                       // terminators and the final 0x00 stay where they are
+  if (wd < wv.d && ch != (uint32_t)kEndOfWord) o = wv.bytes[woff[wd] + (wv.wend[wd] - 1 - i)];
+  out[i] = o;
+}
+__global__ void word_starts_kernel(uint32_t d, const uint64_t *__restrict__ woff, uint32_t *__restrict__ idx32, uint64_t *__restrict__ idx64) {
+  const uint32_t j = BID * blockDim.x + threadIdx.x;
+  if (j >= d) return;
+  if (idx32) idx32[j] = (uint32_t)woff[j]; else idx64[j] = woff[j];
+}
+// rank r -> word, word -> rank, and the common prefix of the reversed words r - 1, r (= common suffix of the words)
+template <class I>
+__global__ void word_rev_kernel(uint32_t d, const I *__restrict__ order, WordView rev, uint32_t *__restrict__ revword, uint32_t *__restrict__ revrank,
+                                uint32_t *__restrict__ lcs) {
+  const uint32_t r = BID * blockDim.x + threadIdx.x;
+  if (r > d) return;
+  if (r == d) { lcs[d] = 0; return; }
+  const uint64_t b = order[r];
+  const uint32_t wd = word_of(rev, b);
+  revword[r] = wd; revrank[wd] = r;
+  uint32_t l = 0;
+  if (r > 0) {
+    const uint64_t a = order[r - 1];
+    for (;;) {
+      const uint64_t x = ld8u(rev.bytes + a + l), y = ld8u(rev.bytes + b + l);
+      const uint64_t end = (x - 0x0202020202020202ull) & ~x & 0x8080808080808080ull;      // bytes < 2 of x (lowest flag exact)
+      const uint64_t diff = x ^ y;
+      if (diff | end) {
+        const int fd = diff ? (__builtin_ctzll(diff) >> 3) : 8, fe = end ? (__builtin_ctzll(end) >> 3) : 8;
+        l += (uint32_t)(fd < fe ? fd : fe);
+        break;
+      }
+      l += 8;
+    }
+  }
+  lcs[r] = l;
+}
+// flag[i] = 1 where the suffix at i emits (longer than w) and is the first of its string in reverse-lexicographic word order;
+// tile_emit[block] = emitting positions of the block
+__global__ __launch_bounds__(256) void rep_flags_kernel(WordView wv, int w, const uint32_t *__restrict__ revrank, const uint32_t *__restrict__ lcs,
+                                                        uint8_t *__restrict__ flag, unsigned long long *__restrict__ tile_emit) {
+  __shared__ uint32_t wt[4], we[4];
+  const uint64_t i = (uint64_t)BID * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+  const uint32_t ch = i < wv.NP ? (uint32_t)wv.bytes[i] : 0u;
+  const unsigned long long tm = __ballot(ch == (uint32_t)kEndOfWord);
+  if (lane == 0) wt[wvi] = (uint32_t)__popcll(tm);
+  __syncthreads();
+  bool emit = false, rep = false;
+  if (i < wv.NP) {
+    uint32_t wd = wv.blk_word[(uint64_t)BID * 4] + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
+    for (int q = 0; q < wvi; q++) wd += wt[q];
+    if (wd < wv.d) {
+      const uint64_t L = wv.wend[wd] - i;
+      emit = L > (uint64_t)w;
+      rep = emit && L > (uint64_t)lcs[revrank[wd]];
+    }
+    flag[i] = rep ? 1 : 0;
+  }
+  const unsigned long long em = __ballot(emit);
+  if (lane == 0) we[wvi] = (uint32_t)__popcll(em);
+  __syncthreads();
+  if (threadIdx.x == 0) tile_emit[BID] = (unsigned long long)we[0] + we[1] + we[2] + we[3];
+}
+// sorted representative q: its run of words and the run's length
+template <class I>
+__global__ void rep_runs_kernel(uint64_t n, const I *__restrict__ sa, WordView wv, const uint32_t *__restrict__ revrank, const uint32_t *__restrict__ lcs,
+                                uint32_t *__restrict__ run_r, uint32_t *__restrict__ run_len, uint32_t *__restrict__ run_L) {
+  const uint64_t q = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const uint64_t i = sa[q];
+  const uint32_t wd = word_of(wv, i);
+  const uint32_t r = revrank[wd];
+  const uint64_t L64 = wv.wend[wd] - i;
+  const uint32_t L = L64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)L64;      // (a common suffix is shorter than 2^32 anyway)
+  uint32_t e = r + 1;
+  while (lcs[e] >= L) e++;                        // lcs[d] = 0 < L ends the walk
+  run_r[q] = r; run_len[q] = e - r; run_L[q] = L;
+}
+// eight lanes per representative: the slots of its group; whole words (groups of one) report their slot
+template <class I>
+__global__ __launch_bounds__(256) void rep_expand_kernel(uint64_t n, const I *__restrict__ rsa, const uint32_t *__restrict__ run_r,
+                                                         const uint32_t *__restrict__ run_len, const uint32_t *__restrict__ run_L,
+                                                         const I *__restrict__ off, const uint32_t *__restrict__ revword, WordView wv,
+                                                         I *__restrict__ sa, I *__restrict__ grp, uint64_t *__restrict__ wslot) {
+  const uint64_t tq = (uint64_t)BID * 256 + threadIdx.x;
+  const uint64_t q = tq >> 3;
+  const uint32_t l8 = (uint32_t)(tq & 7);
+  if (q >= n) return;
+  const uint32_t r = run_r[q], len = run_len[q], L = run_L[q];
+  const I o = off[q];
+  for (uint32_t j = l8; j < len; j += 8) {
+    sa[(uint64_t)o + j] = (I)(wv.wend[revword[r + j]] - L);
+    grp[(uint64_t)o + j] = o;
+  }
+  if (l8 == 0 && wslot) {
+    const uint64_t i = rsa[q];
+    if (i == 0 || wv.bytes[i - 1] == kEndOfWord) wslot[revword[r]] = (uint64_t)o + 1;
+  }
+}
+
+template <class I>
+bool sort_dict_suffixes_dedup(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, int w, double rep_hint, SuffixOrderT<I> &out,
+                              DBuf<uint64_t> &wslot) {
+  const uint64_t NP = D.dsize;
+  const uint32_t d = (uint32_t)D.d;
+  const int TB = 256;
+  if (sizeof(I) == 4 && NP >= 0xFFFFFFF0ull) return false;
+  const WordView wv = word_view(D, ix);
+  // ---- the words in reverse-lexicographic order, neighbours' common suffixes
+  DBuf<uint32_t> revword(c, d), revrank(c, d), lcs(c, (uint64_t)d + 1);
+  uint64_t rounds = 0;
+  {
+    DBuf<uint8_t> rev(c, NP + 64);
+    PFP_HIP(hipMemsetAsync(rev.p + NP, 0, 64, c->stream));
+    { KScope ks(c, "pfp::reverse_words_kernel", NP * 2);
+      hipLaunchKernelGGL(reverse_words_kernel, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, wv, D.woff.p, rev.p); }
+    const WordView rv{rev.p, ix.blk_word.p, ix.wend.p, d, NP};      // same word boundaries as the dictionary
+    DBuf<I> idx(c, d);
+    hipLaunchKernelGGL(word_starts_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, D.woff.p, sizeof(I) == 4 ? (uint32_t *)idx.p : nullptr,
+                       sizeof(I) == 8 ? (uint64_t *)idx.p : nullptr);
+    SufGeom g{MODE_DICT, NP, rv};
+    KeyCode kc = dict_key_code(c, rev.p, NP, 0);
+    SuffixOrderT<I> wo;
+    sort_suffix_list<I>(c, g, kc, 0, idx, d, wo);
+    if (!wo.complete) return false;            // two words share more than the widest pivot window: the full sort handles that
+    rounds = wo.rounds;
+    hipLaunchKernelGGL(word_rev_kernel<I>, gdim(cdiv((uint64_t)d + 1, TB)), gdim(TB), 0, c->stream, d, wo.sa.p, rv, revword.p, revrank.p, lcs.p);
+    PFP_HIP(hipGetLastError());
+  }
+  // ---- representatives: one position per distinct emitting suffix
+  const uint64_t nblk = cdiv64(NP, 256);
+  DBuf<uint8_t> flag(c, NP + 16);
+  PFP_HIP(hipMemsetAsync(flag.p + NP, 0, 16, c->stream));
+  uint64_t n_emit = 0;
+  {
+    DBuf<unsigned long long> te(c, nblk), tot(c, 2);
+    tot.zero();
+    KScope ks(c, "pfp::rep_flags_kernel", NP * 2 + nblk * 8);
+    hipLaunchKernelGGL(rep_flags_kernel, gdim((unsigned)nblk), gdim(TB), 0, c->stream, wv, w, revrank.p, lcs.p, flag.p, te.p);
+    hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, te.p, te.p, nblk, tot.p);
+    n_emit = read_scalar(c, (const uint64_t *)tot.p);
+  }
+  const uint64_t n_rep = count_flags(c, flag.p, NP);
+  if (sizeof(I) == 4 && n_emit >= 0xFFFFFFF0ull) return false;
+  if (n_rep == 0) return false;
+  DBuf<I> idx(c, n_rep);
+  { DBuf<uint64_t> cnt_d(c, 1);
+    select_index<I>(c, flag.p, idx.p, cnt_d.p, NP); }
+  flag.release();
+  SuffixOrderT<I> ro;
+  {
+    SufGeom g{MODE_DICT, NP, wv};
+    KeyCode kc = dict_key_code(c, D.bytes.p, NP, rep_hint);
+    const int idx_bits = keysonly_bits<I>(NP, rep_hint, kc);
+    sort_suffix_list<I>(c, g, kc, idx_bits, idx, n_rep, ro);
+  }
+  if (!ro.complete) return false;
+  // ---- every representative becomes its group's slots
+  DBuf<uint32_t> run_r(c, n_rep), run_len(c, n_rep + 1), run_L(c, n_rep);
+  DBuf<I> off(c, n_rep + 1);
+  PFP_HIP(hipMemsetAsync(run_len.p + n_rep, 0, 4, c->stream));
+  { KScope ks(c, "pfp::rep_expand_kernel", n_rep * (sizeof(I) + 64 + 12));
+    hipLaunchKernelGGL(rep_runs_kernel<I>, gdim(cdiv(n_rep, TB)), gdim(TB), 0, c->stream, n_rep, ro.sa.p, wv, revrank.p, lcs.p, run_r.p, run_len.p,
+                       run_L.p); }
+  exclusive_sum_u32_to<I>(c, run_len.p, off.p, n_rep + 1);
+  I total_i = 0;
+  PFP_HIP(hipMemcpyAsync(c->h_scalars, off.p + n_rep, sizeof(I), hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  memcpy(&total_i, c->h_scalars, sizeof(I));
+  PFP_REQUIRE((uint64_t)total_i == n_emit, PFP_EHIP, "suffix groups hold " + std::to_string((uint64_t)total_i) + " slots, the dictionary has " +
+                                                        std::to_string(n_emit) + " emitting suffixes");
+  out.N = n_emit; out.NP = NP; out.range = false; out.complete = true; out.rounds = rounds + ro.rounds + 1;
+  out.slot_base = 0; out.paybits = 0; out.n_refined = 0; out.finbit = 0;
+  out.sa.alloc(c, n_emit + 8); out.grp.alloc(c, n_emit + 8); out.rank.alloc(c, 1);
+  wslot.alloc(c, d);
+  wslot.zero();
+  { KScope ks(c, "pfp::rep_expand_kernel", n_rep * 24 + n_emit * (2 * sizeof(I) + 12));
+    hipLaunchKernelGGL(rep_expand_kernel<I>, gdim(cdiv(n_rep * 8, TB)), gdim(TB), 0, c->stream, n_rep, ro.sa.p, run_r.p, run_len.p, run_L.p, off.p,
+                       revword.p, wv, out.sa.p, out.grp.p, wslot.p); }
+  PFP_HIP(hipGetLastError());
+  sync(c);
+  return true;
+}
+template bool sort_dict_suffixes_dedup<uint32_t>(pfp_ctx *, const Dictionary &, const DictIndex &, int, double, SuffixOrderT<uint32_t> &, DBuf<uint64_t> &);
+template bool sort_dict_suffixes_dedup<uint64_t>(pfp_ctx *, const Dictionary &, const DictIndex &, int, double, SuffixOrderT<uint64_t> &, DBuf<uint64_t> &);
 
 template <class I>
 void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrderT<I> &out) {
   PFP_REQUIRE(N >= 1 && (sizeof(I) == 8 ? N < (1ull << 40) : N < 0xFFFFFFF0ull), PFP_ELIMIT, "text too large for the suffix index width");
-  SufGeom g{MODE_PLAIN, N, nullptr};
+  SufGeom g{MODE_PLAIN, N, WordView{}};
   DBuf<uint64_t> key(c, N);
   DBuf<I> val(c, N);
   hipLaunchKernelGGL(init_keys_bytes_kernel<I>, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, bytes, N, key.p, val.p);
@@ -1484,7 +1732,7 @@ template void sort_byte_suffixes<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t,
 
 void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym) {
   PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "parse too large for 32-bit suffix indices");
-  SufGeom g{MODE_PLAIN, N, nullptr};
+  SufGeom g{MODE_PLAIN, N, WordView{}};
   DBuf<uint64_t> key(c, N);
   DBuf<uint32_t> val(c, N);
   // the symbol width is measured, not taken on trust (max_sym is only an upper bound for the check)

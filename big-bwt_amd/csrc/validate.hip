@@ -45,15 +45,27 @@ void validate_dictionary(pfp_ctx *c, const Dictionary &D, int w) {
   for (int i = 0; i < 64; i++) if (b[D.dsize + i]) VFAIL("dict: pad not zero");
 }
 
+// every position asks the word lookup (wordview.hpp) for its word and its distance to the terminator
+__global__ void word_lookup_kernel(WordView wv, uint32_t *__restrict__ pw, uint64_t *__restrict__ sl) {
+  const uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (i >= wv.NP) return;
+  pw[i] = word_of(wv, i);
+  sl[i] = slen_of(wv, i);
+}
 void validate_index(pfp_ctx *c, const Dictionary &D, const DictIndex &ix) {
   auto b = fetch(c, D.bytes.p, D.dsize);
-  auto pw = fetch(c, ix.pos_word.p, D.dsize);
   auto we = fetch(c, ix.wend.p, D.d + 1);
-  auto sl = fetch(c, ix.slen.p, D.dsize);
-  for (uint64_t i = 0; i < D.dsize; i++) if (pw[i] > D.d || i + sl[i] != we[pw[i]]) VFAIL("index: slen wrong at " + std::to_string(i));
+  auto bw = fetch(c, ix.blk_word.p, (D.dsize + 63) / 64 + 1);
+  DBuf<uint32_t> d_pw(c, D.dsize);
+  DBuf<uint64_t> d_sl(c, D.dsize);
+  hipLaunchKernelGGL(word_lookup_kernel, gdim(cdiv(D.dsize, 256)), gdim(256), 0, c->stream, word_view(D, ix), d_pw.p, d_sl.p);
+  auto pw = fetch(c, d_pw.p, D.dsize);
+  auto sl = fetch(c, d_sl.p, D.dsize);
   uint32_t wd = 0;
   for (uint64_t i = 0; i < D.dsize; i++) {
-    if (pw[i] != wd) VFAIL("index: pos_word wrong at " + std::to_string(i));
+    if ((i & 63) == 0 && bw[i >> 6] != wd) VFAIL("index: blk_word wrong at line " + std::to_string(i >> 6));
+    if (pw[i] != wd) VFAIL("index: word lookup wrong at " + std::to_string(i));
+    if (pw[i] > D.d || i + sl[i] != we[pw[i]]) VFAIL("index: suffix length wrong at " + std::to_string(i));
     if (b[i] == kEndOfWord) { if (we[wd] != i) VFAIL("index: wend wrong"); wd++; }
   }
   if (wd != D.d || we[D.d] != D.dsize - 1) VFAIL("index: word count");

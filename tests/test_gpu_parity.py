@@ -187,6 +187,23 @@ def test_mid_size_against_oracle(O, pkg, wctx):
     assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
 
 
+@pytest.mark.parametrize("block", [256, 4096])
+def test_position_records_in_blocks(golden, O, pkg, wctx, monkeypatch, block):
+    """the merge's 16-byte position records done in blocks of positions (what a dictionary too large for one array of
+    them gets: the multi-GPU chain's ranks at |D| = 30 GB): same files, all three flag sets"""
+    monkeypatch.setenv("PFP_PREC_BLOCK", str(block))
+    for c in golden[:6]:
+        text = make_text(c["spec"], O)
+        for flags in (0, 1, 6):
+            r = c["runs"][str(flags)]
+            got = wctx.bigbwt(text, c["w"], c["p"], flags)
+            assert sha(got["bwt"]) == r["bwt_sha256"], (c["name"], flags, "bwt")
+            if flags & 1:
+                assert sha(got["sa"]) == r["sa_sha256"], (c["name"], "sa")
+            if flags & 2:
+                assert sha(got["ssa"]) == r["ssa_sha256"] and sha(got["esa"]) == r["esa_sha256"], (c["name"], "ssa/esa")
+
+
 @pytest.mark.parametrize("env", [{}, {"PFP_BIG_BUDGET": "6000"}, {"PFP_BIG_BY_RANK": "1"}])
 def test_large_hard_groups_without_a_dominating_char(O, pkg, wctx, monkeypatch, env):
     """1200 copies of a short random sequence, a few of them mutated, small window: suffixes of 5+ characters are shared

@@ -53,6 +53,9 @@ for it in range(2):
     torch.cuda.synchronize(); el = (time.perf_counter() - t0) * 1e3
 print('R=%d workload=%s dedup=%s flags=%d total wall (all ranks one after the other) %.1f ms' % (R, name, dedup, wl['flags'], el))
 print('last rank compute ms:', {k: round(v, 2) for k, v in acc.items()}, 'sum %.1f' % sum(acc.values()))
+ms_ = ctxs[R - 1].mem_stats()
+print('last rank device memory: peak in use %.2f GB (%.1f bytes per byte of its shard, %.1f per byte of the union dictionary)' % (
+    ms_['peak'] / 1e9, ms_['peak'] / texts[R - 1].numel(), ms_['peak'] / max(res[R - 1]['stats']['glob']['dict_bytes'], 1)))
 st = res[R - 1]['stats']
 print('stats', {k: st[k] for k in ('phrases_total', 'shard_bytes', 'sa_shares', 'dedup')}, st['glob'])
 kt = ctxs[R - 1].kernel_trace()
