@@ -351,7 +351,7 @@ def main():
                         launches_per_step=dom["launches_per_step"], algo_bytes_per_launch=dom["algo_bytes_per_launch"],
                         share_of_step=round(dom["ms_per_step"] / ms_per_step, 3))
         # HBM traffic of that kernel from the committed PMC passes of the same workload, per launch like `achieved`
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{wl_name}_pmc_traffic.json")))
                 if world == 1 and dom["kernel"] in pmc["kernels"]:

@@ -139,14 +139,6 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
 // range mode: out[j] = 1 + SA(D) slot of the whole-word suffix of word j if it belongs to this share, else 0 (count = d)
 template <class I>
 void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const WordView &wv, uint64_t count, uint64_t *d_out);
-// Dictionary of a repetitive collection: the emitting suffixes (longer than w) grouped by equal strings WITHOUT sorting the
-// duplicates - equal suffixes are read off the words' reverse-lexicographic order, one representative per distinct string is
-// suffix-sorted, the groups are laid out from the representatives (sufsort.hip).  out.N = emitting suffixes (< NP), out.sa /
-// out.grp as from the full sort minus the slots that emit nothing; wslot[j] = 1 + slot of word j's whole-word suffix.
-// false: not applicable (a comparison would need doubling rounds) - nothing usable in out, sort everything instead.
-template <class I>
-bool sort_dict_suffixes_dedup(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, int w, double rep_hint, SuffixOrderT<I> &out,
-                              DBuf<uint64_t> &wslot);
 // plain suffix array of an integer string with unique smallest last symbol (sacak_int)
 // max_sym: largest symbol value (spare key bits then describe runs of equal symbols)
 void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym = 0xFFFFFFFFu);

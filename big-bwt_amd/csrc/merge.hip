@@ -476,7 +476,7 @@ __global__ void wistart_kernel(uint32_t d, const uint32_t *__restrict__ lexrank,
 
 template <class I>
 struct MergeArgsT {
-  uint64_t N, n_out; uint32_t d; int w; int want_sa; int dbg_mode;
+  uint64_t N, n_out; uint32_t d; int w; int want_sa;
   uint64_t pos_base, n_out_global;   // global BWT position of local position 0; global n+1 (== n_out unless the slots are one rank's range)
   uint64_t out_lo, out_hi;   // this call emits BWT positions [out_lo,out_hi) only (multi-GPU slices); bwt/out_sa are indexed by global position
   const I *sa, *grp;
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, con
   }
   // fallback (the kernels that rank every occurrence): no dominating char, a long minority list (its occurrences
   // would be ranked one after the other), too many distinct chars
-  const bool fb = many || minor * 4 > E || mm_max > 1024 || a.dbg_mode != 0;
+  const bool fb = many || minor * 4 > E || mm_max > 1024;
   const bool in_slice = !(base + E <= a.out_lo || base >= a.out_hi);
   fallback[h] = (fb && in_slice) ? 1 : 0;
   gmaj[g] = fb ? 0 : (uint8_t)mc;
@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgsT<I> a, const
       const uint64_t Eg = slot_off(a, g + kk) - base;
       if (kk && !(base + Eg <= a.out_lo || base >= a.out_hi)) {      // inside this rank's slice
         my_chars += Eg; my_groups += 1;
-        const bool sorted_path = a.dbg_mode ? a.dbg_mode == 3 : Eg > (uint64_t)kHardSortMin;
+        const bool sorted_path = Eg > (uint64_t)kHardSortMin;
         if (Eg <= (uint64_t)kHardRank && kk <= (uint32_t)kHardMem && !sorted_path) { live = true; k = kk; E = (uint32_t)Eg; }
         else if (Eg <= (uint64_t)kHardLds && sorted_path) {      // one wave sorts it in LDS: hard_sort_kernel
           const unsigned long long idx = atomicAdd(&stats[3], 1ull);
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(256) void hard_groups_kernel(MergeArgsT<I> a, const
         const uint32_t pos = L.lpos[e];
         uint32_t lg = 1;
         while ((kg << lg) < Eg) lg++;
-        const bool by_search = a.dbg_mode ? a.dbg_mode == 2 : (uint64_t)kg * (lg + 1) * 3 < Eg;
+        const bool by_search = (uint64_t)kg * (lg + 1) * 3 < Eg;
         uint32_t r = 0;
         if (!by_search) {
           for (uint32_t x = s0; x < s1; x++) r += L.lpos[x] < pos;
@@ -1490,8 +1490,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   exclusive_sum_u32(c, occ_lex, istart_lex.p, d);
   // SA values: none, all (-S), or only where the sampled files can look (-s / -e): run boundaries of the BWT
   const int sa_mode = !flags ? SA_NONE : ((flags & PFP_FLAG_SA) ? SA_DENSE : SA_SPARSE);
-  static const bool dense_always = getenv("PFP_DENSE_SA") != nullptr;      // tests: -s / -e through the dense path
-  const int samode = (sa_mode == SA_SPARSE && dense_always && out.d_sa) ? SA_DENSE : sa_mode;
+  const int samode = sa_mode;
   const bool dense = samode == SA_DENSE;
   DBuf<WordRec> wrec(c, d);      // per word: list start, occurrences, smallest / largest BWT(P) position, terminator
   hipLaunchKernelGGL(wistart_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, ix.lexrank.p, istart_lex.p, D.wocc.p, pb.ilist.p,
@@ -1574,7 +1573,6 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   MergeArgsT<I> a{};
   a.N = N; a.n_out = n_out; a.d = d; a.w = w; a.want_sa = samode;
   a.pos_base = pos_base; a.n_out_global = n_out_global ? n_out_global : n_out;
-  { const char *e = getenv("PFP_HARD_MODE"); a.dbg_mode = e ? atoi(e) : 0; }
   a.sa = so.sa.p; a.grp = so.grp.p; a.wv = wv;
   a.ist = dense ? sfirst.p : nullptr;          // full SA: the record's `first` field held the list start
   a.wistart = wistart.p; a.wrec = wrec.p;
@@ -1589,8 +1587,8 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   hstats.zero();
   uint32_t big_cap = 1u << 20;
   DBuf<BigGroup> big(c, big_cap);
-  // such a group emits > kHardSortMin positions (PFP_HARD_MODE=3, tests: every group takes this path)
-  const uint32_t mid_cap = (uint32_t)std::min<uint64_t>(a.dbg_mode == 3 ? N / 2 + 2 : n_out / (kHardSortMin + 1) + 64, 0x7FFFFFFFull);
+  // such a group emits > kHardSortMin positions
+  const uint32_t mid_cap = (uint32_t)std::min<uint64_t>(n_out / (kHardSortMin + 1) + 64, 0x7FFFFFFFull);
   DBuf<BigGroup> mid(c, mid_cap);
   // hard[] marks exactly the heads of the hard groups (group_flags_kernel): count, then compact them once
   const uint64_t n_heads = count_flags(c, hard.p, N);
@@ -1703,7 +1701,6 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   std::vector<uint64_t> es(nbig + 1, 0);
   // (read per call: the tests switch them inside one process)
   const uint64_t big_budget = [] { const char *e = getenv("PFP_BIG_BUDGET"); return e ? strtoull(e, nullptr, 10) : (1ull << 27); }();
-  const bool big_by_rank = getenv("PFP_BIG_BY_RANK") != nullptr;      // the occurrence-by-occurrence kernel for every queued group
   if (nbig) {
     // occurrences of the queued groups, laid end to end
     std::vector<BigGroup> hb(nbig);
@@ -1726,7 +1723,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
       uint32_t q1 = q0 + 1;
       while (q1 < nbig && es[q1 + 1] - es[q0] <= big_budget) q1++;
       const uint64_t cnt = es[q1] - es[q0];
-      if (cnt > big_budget || big_by_rank) {
+      if (cnt > big_budget) {
         const int nb = (int)std::min<uint64_t>(cdiv64(cnt, 256), (uint64_t)c->n_cu * 32);
         KScope ks(c, "pfp::hard_big_kernel", cnt * (samode ? 21 : 5));
         hipLaunchKernelGGL(hard_big_kernel<I>, gdim(nb), gdim(256), 0, c->stream, a, big.p + q0, q1 - q0, estart.p + q0, cnt);

@@ -261,8 +261,7 @@ static void run_chain_dev(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, 
   {
     PhaseTimer t(c, &st.ms_merge);
     BwtOutputs &bo = ch.out;
-    static const bool dense_always = getenv("PFP_DENSE_SA") != nullptr;      // tests: -s / -e through the dense path
-    if (flags && !d_sa && ((flags & PFP_FLAG_SA) || dense_always)) { ch.sa_own.alloc(c, ch.n_used + 1); d_sa = ch.sa_own.p; }
+    if ((flags & PFP_FLAG_SA) && !d_sa) { ch.sa_own.alloc(c, ch.n_used + 1); d_sa = ch.sa_own.p; }
     bo.d_bwt = d_bwt; bo.d_sa = d_sa;
     with_width(ch.ord.wide, [&](auto tag) {
       using I = decltype(tag);

@@ -852,11 +852,11 @@ __global__ void finish_write_kernel(uint64_t m, const I *__restrict__ aslot, con
 
 // after the first round, pivot rounds are tried while the groups are families (average size up to
 // kPivotAvg) and each one at least halves the unresolved set; at most kPivotCap bytes per comparison
-static const uint32_t kPivotAvg = []() { const char *e = getenv("PFP_PIVOT_AVG"); return e ? (uint32_t)atoll(e) : 1024u; }();
+constexpr uint32_t kPivotAvg = 1024u;
 static const uint32_t kPivotCap = []() { const char *e = getenv("PFP_PIVOT_CAP"); uint32_t v = e ? (uint32_t)atoll(e) : 512u; return v > kPivCapMax ? kPivCapMax : v; }();
 
 // the first round leaves more than N/kLazyRatio suffixes unresolved -> scatter all ranks after all
-static const uint64_t kLazyRatio = []() { const char *e = getenv("PFP_LAZY_RATIO"); return e ? (uint64_t)atoll(e) : 8ull; }();
+constexpr uint64_t kLazyRatio = 8ull;
 
 template <class I>
 RankViewT<I> rank_view(const SuffixOrderT<I> &so) {
@@ -930,7 +930,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   const int keybits = 2 * nb;
   static const bool no_finflag = getenv("PFP_NO_FINFLAG") != nullptr;      // tests: force the length-gather path
   out.finbit = (g.mode == MODE_DICT && (kWide || N < (1ull << 31)) && !no_finflag) ? IdxTraits<I>::kTop : (I)0;
-  static const bool use_segsort = []() { const char *e = getenv("PFP_SEGSORT"); return !(e && e[0] == '0'); }();
+  constexpr bool use_segsort = true;
   DBuf<uint8_t> gs;
   DBuf<uint32_t> k32, k32o, segb, sege, nseg_d;
   DBuf<uint64_t> nsel_d;
@@ -941,7 +941,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   bool pivot_ok = true;
   bool lazy_pending = false;    // dictionary mode: rank[] of the suffixes settled by the first round not scattered (yet)
   DBuf<uint8_t> veto, keep0;
-  static const bool lazy_pivot_ranks = getenv("PFP_EAGER_PIVOT_RANKS") == nullptr;
+  constexpr bool lazy_pivot_ranks = true;
   bool ranks_stale = false;     // pivot rounds skipped rank[] of settled suffixes that are not whole words
   bool active_stale = false;    // ... and the first round / pivot rounds skipped rank[] of the suffixes that stay unresolved
   DBuf<uint32_t> wstart_bits;   // pivot rounds: which positions start a word (their ranks order the dictionary)
@@ -965,7 +965,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   // more than kSmallSeg members (nothing usable was written)
   // 32-bit index build: the groups of more than kSmallSeg members are passed through in place, flagged, and finished
   // by ONE library sort of just their elements (a few long families no longer send the whole round to the library)
-  static const bool big_side = getenv("PFP_NO_BIGSIDE") == nullptr;
+  constexpr bool big_side = true;
   DBuf<uint8_t> bigf;
   auto seg_small_sort = [&](uint64_t mm) -> bool {
     ovf_d.zero();
@@ -1167,7 +1167,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       // segmented sort of the 23-bit order key moves 16 B per suffix instead of 7 x 24 B
       bool seg = false, small = false;
       uint32_t ng = 0;
-      static const uint32_t seg_min_avg = []() { const char *e = getenv("PFP_SEG_MINAVG"); return e ? (uint32_t)atoi(e) : 24u; }();
+      constexpr uint32_t seg_min_avg = 24u;
       static const bool use_small = getenv("PFP_NO_SMALLSEG") == nullptr;
       // families of a handful of members: placed directly (after a group proved too long, only once the average is tiny)
       // (32-bit build: long families go to the side sort, so the average may be larger)
@@ -1311,8 +1311,7 @@ void sort_dict_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, const Word
   DBuf<uint64_t> key(c, N);
   DBuf<I> val;
   if (!idx_bits) val.alloc(c, N);
-  static const bool no_payload = getenv("PFP_NO_PAYLOAD") != nullptr;
-  out.paybits = (pay && !no_payload && !idx_bits && kc.kbits + 1 <= 48) ? 16 : 0;
+  out.paybits = (pay && !idx_bits && kc.kbits + 1 <= 48) ? 16 : 0;
   out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
   { KScope ks(c, "pfp::init_keys_packed_kernel", N * (9 + (idx_bits ? 0 : sizeof(I)) + (out.paybits ? 9 : 0)));
     hipLaunchKernelGGL(init_keys_packed_kernel<I>, gdim((unsigned)cdiv64(N, kKeyPos)), gdim(256), 0, c->stream, bytes, N, kc,
@@ -1504,219 +1503,16 @@ void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const WordView &w
 template void gather_slots_range<uint32_t>(pfp_ctx *, const SuffixOrderT<uint32_t> &, const WordView &, uint64_t, uint64_t *);
 template void gather_slots_range<uint64_t>(pfp_ctx *, const SuffixOrderT<uint64_t> &, const WordView &, uint64_t, uint64_t *);
 
-// ---- dictionaries of repetitive collections: equal suffixes found without comparing them
-//
-// The dictionary of a collection of similar sequences is families of words - a phrase and its variants - and most of its
-// suffixes are duplicates: the variant's suffixes that start behind its last difference ARE the base word's (87 % of the
-// 129 M suffixes of the 64-copy workload tie in the first round, and the first pivot round reads ~90 bytes of each to find
-// most of them identical: a third of the dictionary sort).  Whether two suffixes are the same string can be read off the
-// WORDS instead: sort the d words by their REVERSED strings (d is small: 0.7 M words for 129 M suffixes) and keep the
-// longest common suffix lcs[r] of neighbours r - 1, r in that order.  The suffix of length L of the word at rank r is a
-// duplicate of its left neighbour's iff lcs[r] >= L; the words sharing it are the run r .. e - 1, e the next rank with
-// lcs[e] < L.  So only the suffixes with L > lcs[r] (one per distinct string; and only those longer than w, the others
-// emit nothing, pfbwt.cpp:151) are suffix-sorted - as a list, with the same first-round keys and pivot rounds - and every
-// sorted representative is then expanded into its run: the slots of a group, all at once.  The result is the same
-// (sa, grp) the merge takes from the full sort, without the slots that emit nothing; members of a group stand in
-// reverse-lexicographic word order (nothing downstream depends on their order inside a group).
-// (the reference finds equal suffixes from the LCP array of the full suffix array, pfbwt.cpp:204-209)
-
-// reversed words in the layout of the dictionary: word j's bytes back to front at the same offsets, same terminators
-__global__ __launch_bounds__(256) void reverse_words_kernel(WordView wv, const uint64_t *__restrict__ woff, uint8_t *__restrict__ out) {
-  __shared__ uint32_t wt[4];
-  const uint64_t i = (uint64_t)BID * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
-  const uint32_t ch = i < wv.NP ? (uint32_t)wv.bytes[i] : 0u;
-  const unsigned long long tm = __ballot(ch == (uint32_t)kEndOfWord);
-  if (lane == 0) wt[wvi] = (uint32_t)__popcll(tm);
-  __syncthreads();
-  if (i >= wv.NP) return;
-  uint32_t wd = wv.blk_word[(uint64_t)BID * 4] + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
-  for (int q = 0; q < wvi; q++) wd += wt[q];
-  uint8_t o = (uint8_t)ch;                       // terminators and the final 0x00 stay where they are
-  if (wd < wv.d && ch != (uint32_t)kEndOfWord) o = wv.bytes[woff[wd] + (wv.wend[wd] - 1 - i)];
-  out[i] = o;
-}
-__global__ void word_starts_kernel(uint32_t d, const uint64_t *__restrict__ woff, uint32_t *__restrict__ idx32, uint64_t *__restrict__ idx64) {
-  const uint32_t j = BID * blockDim.x + threadIdx.x;
-  if (j >= d) return;
-  if (idx32) idx32[j] = (uint32_t)woff[j]; else idx64[j] = woff[j];
-}
-// rank r -> word, word -> rank, and the common prefix of the reversed words r - 1, r (= common suffix of the words)
-template <class I>
-__global__ void word_rev_kernel(uint32_t d, const I *__restrict__ order, WordView rev, uint32_t *__restrict__ revword, uint32_t *__restrict__ revrank,
-                                uint32_t *__restrict__ lcs) {
-  const uint32_t r = BID * blockDim.x + threadIdx.x;
-  if (r > d) return;
-  if (r == d) { lcs[d] = 0; return; }
-  const uint64_t b = order[r];
-  const uint32_t wd = word_of(rev, b);
-  revword[r] = wd; revrank[wd] = r;
-  uint32_t l = 0;
-  if (r > 0) {
-    const uint64_t a = order[r - 1];
-    for (;;) {
-      const uint64_t x = ld8u(rev.bytes + a + l), y = ld8u(rev.bytes + b + l);
-      const uint64_t end = (x - 0x0202020202020202ull) & ~x & 0x8080808080808080ull;      // bytes < 2 of x (lowest flag exact)
-      const uint64_t diff = x ^ y;
-      if (diff | end) {
-        const int fd = diff ? (__builtin_ctzll(diff) >> 3) : 8, fe = end ? (__builtin_ctzll(end) >> 3) : 8;
-        l += (uint32_t)(fd < fe ? fd : fe);
-        break;
-      }
-      l += 8;
-    }
-  }
-  lcs[r] = l;
-}
-// flag[i] = 1 where the suffix at i emits (longer than w) and is the first of its string in reverse-lexicographic word order;
-// tile_emit[block] = emitting positions of the block
-__global__ __launch_bounds__(256) void rep_flags_kernel(WordView wv, int w, const uint32_t *__restrict__ revrank, const uint32_t *__restrict__ lcs,
-                                                        uint8_t *__restrict__ flag, unsigned long long *__restrict__ tile_emit) {
-  __shared__ uint32_t wt[4], we[4];
-  const uint64_t i = (uint64_t)BID * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
-  const uint32_t ch = i < wv.NP ? (uint32_t)wv.bytes[i] : 0u;
-  const unsigned long long tm = __ballot(ch == (uint32_t)kEndOfWord);
-  if (lane == 0) wt[wvi] = (uint32_t)__popcll(tm);
-  __syncthreads();
-  bool emit = false, rep = false;
-  if (i < wv.NP) {
-    uint32_t wd = wv.blk_word[(uint64_t)BID * 4] + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
-    for (int q = 0; q < wvi; q++) wd += wt[q];
-    if (wd < wv.d) {
-      const uint64_t L = wv.wend[wd] - i;
-      emit = L > (uint64_t)w;
-      rep = emit && L > (uint64_t)lcs[revrank[wd]];
-    }
-    flag[i] = rep ? 1 : 0;
-  }
-  const unsigned long long em = __ballot(emit);
-  if (lane == 0) we[wvi] = (uint32_t)__popcll(em);
-  __syncthreads();
-  if (threadIdx.x == 0) tile_emit[BID] = (unsigned long long)we[0] + we[1] + we[2] + we[3];
-}
-// sorted representative q: its run of words and the run's length
-template <class I>
-__global__ void rep_runs_kernel(uint64_t n, const I *__restrict__ sa, WordView wv, const uint32_t *__restrict__ revrank, const uint32_t *__restrict__ lcs,
-                                uint32_t *__restrict__ run_r, uint32_t *__restrict__ run_len, uint32_t *__restrict__ run_L) {
-  const uint64_t q = (uint64_t)BID * blockDim.x + threadIdx.x;
-  if (q >= n) return;
-  const uint64_t i = sa[q];
-  const uint32_t wd = word_of(wv, i);
-  const uint32_t r = revrank[wd];
-  const uint64_t L64 = wv.wend[wd] - i;
-  const uint32_t L = L64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)L64;      // (a common suffix is shorter than 2^32 anyway)
-  uint32_t e = r + 1;
-  while (lcs[e] >= L) e++;                        // lcs[d] = 0 < L ends the walk
-  run_r[q] = r; run_len[q] = e - r; run_L[q] = L;
-}
-// eight lanes per representative: the slots of its group; whole words (groups of one) report their slot
-template <class I>
-__global__ __launch_bounds__(256) void rep_expand_kernel(uint64_t n, const I *__restrict__ rsa, const uint32_t *__restrict__ run_r,
-                                                         const uint32_t *__restrict__ run_len, const uint32_t *__restrict__ run_L,
-                                                         const I *__restrict__ off, const uint32_t *__restrict__ revword, WordView wv,
-                                                         I *__restrict__ sa, I *__restrict__ grp, uint64_t *__restrict__ wslot) {
-  const uint64_t tq = (uint64_t)BID * 256 + threadIdx.x;
-  const uint64_t q = tq >> 3;
-  const uint32_t l8 = (uint32_t)(tq & 7);
-  if (q >= n) return;
-  const uint32_t r = run_r[q], len = run_len[q], L = run_L[q];
-  const I o = off[q];
-  for (uint32_t j = l8; j < len; j += 8) {
-    sa[(uint64_t)o + j] = (I)(wv.wend[revword[r + j]] - L);
-    grp[(uint64_t)o + j] = o;
-  }
-  if (l8 == 0 && wslot) {
-    const uint64_t i = rsa[q];
-    if (i == 0 || wv.bytes[i - 1] == kEndOfWord) wslot[revword[r]] = (uint64_t)o + 1;
-  }
-}
-
-template <class I>
-bool sort_dict_suffixes_dedup(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, int w, double rep_hint, SuffixOrderT<I> &out,
-                              DBuf<uint64_t> &wslot) {
-  const uint64_t NP = D.dsize;
-  const uint32_t d = (uint32_t)D.d;
-  const int TB = 256;
-  if (sizeof(I) == 4 && NP >= 0xFFFFFFF0ull) return false;
-  const WordView wv = word_view(D, ix);
-  // ---- the words in reverse-lexicographic order, neighbours' common suffixes
-  DBuf<uint32_t> revword(c, d), revrank(c, d), lcs(c, (uint64_t)d + 1);
-  uint64_t rounds = 0;
-  {
-    DBuf<uint8_t> rev(c, NP + 64);
-    PFP_HIP(hipMemsetAsync(rev.p + NP, 0, 64, c->stream));
-    { KScope ks(c, "pfp::reverse_words_kernel", NP * 2);
-      hipLaunchKernelGGL(reverse_words_kernel, gdim(cdiv(NP, TB)), gdim(TB), 0, c->stream, wv, D.woff.p, rev.p); }
-    const WordView rv{rev.p, ix.blk_word.p, ix.wend.p, d, NP};      // same word boundaries as the dictionary
-    DBuf<I> idx(c, d);
-    hipLaunchKernelGGL(word_starts_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, D.woff.p, sizeof(I) == 4 ? (uint32_t *)idx.p : nullptr,
-                       sizeof(I) == 8 ? (uint64_t *)idx.p : nullptr);
-    SufGeom g{MODE_DICT, NP, rv};
-    KeyCode kc = dict_key_code(c, rev.p, NP, 0);
-    SuffixOrderT<I> wo;
-    sort_suffix_list<I>(c, g, kc, 0, idx, d, wo);
-    if (!wo.complete) return false;            // two words share more than the widest pivot window: the full sort handles that
-    rounds = wo.rounds;
-    hipLaunchKernelGGL(word_rev_kernel<I>, gdim(cdiv((uint64_t)d + 1, TB)), gdim(TB), 0, c->stream, d, wo.sa.p, rv, revword.p, revrank.p, lcs.p);
-    PFP_HIP(hipGetLastError());
-  }
-  // ---- representatives: one position per distinct emitting suffix
-  const uint64_t nblk = cdiv64(NP, 256);
-  DBuf<uint8_t> flag(c, NP + 16);
-  PFP_HIP(hipMemsetAsync(flag.p + NP, 0, 16, c->stream));
-  uint64_t n_emit = 0;
-  {
-    DBuf<unsigned long long> te(c, nblk), tot(c, 2);
-    tot.zero();
-    KScope ks(c, "pfp::rep_flags_kernel", NP * 2 + nblk * 8);
-    hipLaunchKernelGGL(rep_flags_kernel, gdim((unsigned)nblk), gdim(TB), 0, c->stream, wv, w, revrank.p, lcs.p, flag.p, te.p);
-    hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, te.p, te.p, nblk, tot.p);
-    n_emit = read_scalar(c, (const uint64_t *)tot.p);
-  }
-  const uint64_t n_rep = count_flags(c, flag.p, NP);
-  if (sizeof(I) == 4 && n_emit >= 0xFFFFFFF0ull) return false;
-  if (n_rep == 0) return false;
-  DBuf<I> idx(c, n_rep);
-  { DBuf<uint64_t> cnt_d(c, 1);
-    select_index<I>(c, flag.p, idx.p, cnt_d.p, NP); }
-  flag.release();
-  SuffixOrderT<I> ro;
-  {
-    SufGeom g{MODE_DICT, NP, wv};
-    KeyCode kc = dict_key_code(c, D.bytes.p, NP, rep_hint);
-    const int idx_bits = keysonly_bits<I>(NP, rep_hint, kc);
-    sort_suffix_list<I>(c, g, kc, idx_bits, idx, n_rep, ro);
-  }
-  if (!ro.complete) return false;
-  // ---- every representative becomes its group's slots
-  DBuf<uint32_t> run_r(c, n_rep), run_len(c, n_rep + 1), run_L(c, n_rep);
-  DBuf<I> off(c, n_rep + 1);
-  PFP_HIP(hipMemsetAsync(run_len.p + n_rep, 0, 4, c->stream));
-  { KScope ks(c, "pfp::rep_expand_kernel", n_rep * (sizeof(I) + 64 + 12));
-    hipLaunchKernelGGL(rep_runs_kernel<I>, gdim(cdiv(n_rep, TB)), gdim(TB), 0, c->stream, n_rep, ro.sa.p, wv, revrank.p, lcs.p, run_r.p, run_len.p,
-                       run_L.p); }
-  exclusive_sum_u32_to<I>(c, run_len.p, off.p, n_rep + 1);
-  I total_i = 0;
-  PFP_HIP(hipMemcpyAsync(c->h_scalars, off.p + n_rep, sizeof(I), hipMemcpyDeviceToHost, c->stream));
-  sync(c);
-  memcpy(&total_i, c->h_scalars, sizeof(I));
-  PFP_REQUIRE((uint64_t)total_i == n_emit, PFP_EHIP, "suffix groups hold " + std::to_string((uint64_t)total_i) + " slots, the dictionary has " +
-                                                        std::to_string(n_emit) + " emitting suffixes");
-  out.N = n_emit; out.NP = NP; out.range = false; out.complete = true; out.rounds = rounds + ro.rounds + 1;
-  out.slot_base = 0; out.paybits = 0; out.n_refined = 0; out.finbit = 0;
-  out.sa.alloc(c, n_emit + 8); out.grp.alloc(c, n_emit + 8); out.rank.alloc(c, 1);
-  wslot.alloc(c, d);
-  wslot.zero();
-  { KScope ks(c, "pfp::rep_expand_kernel", n_rep * 24 + n_emit * (2 * sizeof(I) + 12));
-    hipLaunchKernelGGL(rep_expand_kernel<I>, gdim(cdiv(n_rep * 8, TB)), gdim(TB), 0, c->stream, n_rep, ro.sa.p, run_r.p, run_len.p, run_L.p, off.p,
-                       revword.p, wv, out.sa.p, out.grp.p, wslot.p); }
-  PFP_HIP(hipGetLastError());
-  sync(c);
-  return true;
-}
-template bool sort_dict_suffixes_dedup<uint32_t>(pfp_ctx *, const Dictionary &, const DictIndex &, int, double, SuffixOrderT<uint32_t> &, DBuf<uint64_t> &);
-template bool sort_dict_suffixes_dedup<uint64_t>(pfp_ctx *, const Dictionary &, const DictIndex &, int, double, SuffixOrderT<uint64_t> &, DBuf<uint64_t> &);
+// (Tried in round 3 and removed: "grouped order without sorting duplicates".  Equal suffixes of a dictionary of variants can be
+//  read off the WORDS: sort the d words by their reversed strings, keep the longest common suffix lcs[r] of neighbours; the
+//  suffix of length L of the word at rank r duplicates its left neighbour's iff lcs[r] >= L, so only one representative per
+//  distinct string (71 M of 129 M suffixes on the 64-copy workload) is suffix-sorted - as a list - and every sorted
+//  representative is expanded into its run of words.  Bit-exact on all goldens, half the peak memory (12.6 GB input: 165 ->
+//  90 GB) - and slower: the dictionary sort went 20.0 -> 22.2 ms (64 copies) and 354 -> 434 ms (1024 copies).  The first
+//  round shrinks (radix 3.8 -> 2.2 ms, pivot 6.8 -> 4.9 ms), but with the identical strings gone every remaining tie is a real
+//  difference: 7 rounds instead of 5 (23 pivot launches instead of 7 on 1024 copies), and finding the runs and laying out
+//  the slots costs 4.5 ms / 87 ms.  It would pay if the MERGE worked on the 71 M groups instead of 129 M slots (sums over
+//  a run from prefix sums, "all chars equal" from a range minimum over lcs[]): DESIGN.md 7b.)
 
 template <class I>
 void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrderT<I> &out) {
@@ -1743,8 +1539,7 @@ void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder 
   PFP_REQUIRE(real_max <= max_sym, PFP_EFORMAT, "integer string holds a symbol above its alphabet size");
   const int sb = bits_for(real_max);
   g.sym = sym;
-  static const bool no_runkeys = getenv("PFP_NO_RUNKEYS") != nullptr;
-  if (64 - 2 * sb >= 6 && !no_runkeys) {
+  if (64 - 2 * sb >= 6) {
     DBuf<uint32_t> v(c, N), pm(c, N);
     hipLaunchKernelGGL(run_marks_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, (uint32_t)N, v.p);
     inclusive_max_u32(c, v.p, pm.p, N);

@@ -204,12 +204,12 @@ def test_position_records_in_blocks(golden, O, pkg, wctx, monkeypatch, block):
                 assert sha(got["ssa"]) == r["ssa_sha256"] and sha(got["esa"]) == r["esa_sha256"], (c["name"], "ssa/esa")
 
 
-@pytest.mark.parametrize("env", [{}, {"PFP_BIG_BUDGET": "6000"}, {"PFP_BIG_BY_RANK": "1"}])
+@pytest.mark.parametrize("env", [{}, {"PFP_BIG_BUDGET": "6000"}, {"PFP_BIG_BUDGET": "100"}])
 def test_large_hard_groups_without_a_dominating_char(O, pkg, wctx, monkeypatch, env):
     """1200 copies of a short random sequence, a few of them mutated, small window: suffixes of 5+ characters are shared
     by several words with ~1200 occurrences each and different preceding chars - hard groups of thousands of
     occurrences where no char dominates.  They are merged by one device-wide sort per chunk of groups (chunked by
-    PFP_BIG_BUDGET occurrences; a group beyond the budget, or PFP_BIG_BY_RANK, takes the per-occurrence ranking kernel)."""
+    PFP_BIG_BUDGET occurrences; a group beyond the budget - every group with PFP_BIG_BUDGET=100 - takes the per-occurrence ranking kernel)."""
     rng = np.random.default_rng(5)
     base = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=1500)]
     copies = np.tile(base, (1200, 1))

@@ -5,7 +5,7 @@ usage: pmc_to_json.py <fetch.csv> <write.csv> <workload> <out.json>
 Per kernel (bench.py's names): raw FETCH/WRITE bytes per chain execution and the corrected HBM bytes
 2*FETCH + WRITE (gfx950: FETCH_SIZE reports half of the bytes of wide coalesced streaming reads,
 MI355X_MICROARCH.md 'HBM'; exact for WRITE_SIZE).  A chain = one pfp_bigbwt_dev call; the number of
-chains in the profiled run is the number of pfp::dict_index_fill_kernel dispatches (one per chain in every mode)."""
+chains in the profiled run is the number of pfp::line_terms_kernel dispatches (the dictionary index: one per chain in every mode)."""
 import collections, csv, json, re, sys
 
 def bench_name(n):
@@ -15,7 +15,9 @@ def bench_name(n):
         k = {'heads0_kernel': 'heads_kernel', 'heads32_kernel': 'heads_kernel', 'write_back0_kernel': 'write_back_kernel',
              'scatter_settled_kernel': 'write_back_kernel', 'build_keys32_kernel': 'build_keys_kernel',
              'slot_payload_kernel': 'slot_gather_kernel', 'active_place_kernel': 'compact3_kernel', 'active_count_kernel': 'compact3_kernel',
-             'flag_place_kernel': 'select_flags_kernel', 'flag_count_kernel': 'select_flags_kernel'}.get(k, k)
+             'flag_place_kernel': 'select_flags_kernel', 'flag_count_kernel': 'select_flags_kernel',
+             'slot_records_kernel': 'slot_gather_kernel', 'slot_fetch_kernel': 'slot_gather_kernel', 'pprec16_kernel': 'pprec_kernel',
+             'line_terms_kernel': 'dict_index_fill_kernel', 'word_ends_kernel': 'dict_index_words_kernel'}.get(k, k)
         return 'pfp::' + k
     if 'onesweep' in n or 'radix_sort' in n or 'block_sort' in n:
         return 'rocprim::radix_sort_pairs<u64,u32>' if re.search(r'unsigned long, unsigned int|unsigned long,unsigned int', n) else 'rocprim::radix_sort_pairs<u32,u32>'
