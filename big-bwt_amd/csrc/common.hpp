@@ -66,11 +66,12 @@ inline int bits_for(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b)
 // released (after a stream sync) and the block goes back to the driver.  A damaged band is reported on
 // stderr with the allocation site and fails every later API call on the context (pfp_debug_check).
 struct pfp_pool {
-  struct Block { void *p; size_t bytes; void *base; const char *file; int line; };
+  struct Block { void *p; size_t bytes; void *base; const char *file; int line; size_t req; };      // req: bytes asked for by the current holder
   static constexpr size_t kBand = 1024;            // bytes of canary on either side (debug mode)
   static constexpr unsigned char kCanary = 0xA5, kPoison = 0xCD;
   std::vector<Block> free_list;
   std::vector<Block> all;
+  // total: held from the driver; live / peak: bytes the holders ASKED for (a recycled block may be larger than the request)
   size_t total_bytes = 0, peak_bytes = 0, live_bytes = 0;
   bool debug = false;
   hipStream_t stream = nullptr;
@@ -78,6 +79,25 @@ struct pfp_pool {
   uint64_t debug_blocks = 0;
   size_t soft_limit = 0;                           // bytes held from the driver beyond which any cached block that fits is reused
   uint64_t driver_allocs = 0, trims = 0;           // hipMalloc calls; times a failed one made the pool give its cache back
+  bool trace = false;                              // PFP_TRACE_POOL=1: remember what was live at the peak (printed by pfp_ctx_destroy)
+  std::vector<Block> peak_blocks;
+  void note_peak() {
+    if (live_bytes <= peak_bytes) return;
+    peak_bytes = live_bytes;
+    if (!trace) return;
+    peak_blocks.clear();
+    for (const auto &b : all) {
+      bool is_free = false;
+      for (const auto &f : free_list) if (f.p == b.p) { is_free = true; break; }
+      if (!is_free) peak_blocks.push_back(b);
+    }
+  }
+  void print_peak() const {
+    if (!trace) return;
+    fprintf(stderr, "[pfp] pool peak %.2f GB in %zu blocks:\n", peak_bytes / 1e9, peak_blocks.size());
+    for (const auto &b : peak_blocks)
+      if (b.bytes >= (64u << 20)) fprintf(stderr, "[pfp]   %10.3f GB asked (block of %.3f)  %s:%d\n", b.req / 1e9, b.bytes / 1e9, b.file, b.line);
+  }
   void *get(size_t bytes, hipError_t *err, const char *file = "", int line = 0) {
     *err = hipSuccess;
     if (debug) return get_debug(bytes, err, file, line);
@@ -96,8 +116,10 @@ struct pfp_pool {
     }
     if (bi != (size_t)-1) {
       void *p = free_list[bi].p;
-      live_bytes += free_list[bi].bytes; if (live_bytes > peak_bytes) peak_bytes = live_bytes;
+      live_bytes += bytes;
       free_list[bi] = free_list.back(); free_list.pop_back();
+      for (auto &b : all) if (b.p == p) { b.file = file; b.line = line; b.req = bytes; break; }
+      note_peak();
       return p;
     }
     void *p = nullptr;
@@ -110,14 +132,14 @@ struct pfp_pool {
       e = hipMalloc(&p, bytes);
     }
     if (e != hipSuccess) { *err = e; (void)hipGetLastError(); return nullptr; }
-    all.push_back({p, bytes, p, file, line}); total_bytes += bytes;
-    live_bytes += bytes; if (live_bytes > peak_bytes) peak_bytes = live_bytes;
+    all.push_back({p, bytes, p, file, line, bytes}); total_bytes += bytes;
+    live_bytes += bytes; note_peak();
     return p;
   }
   void put(void *p) {
     for (size_t i = 0; i < all.size(); i++)
       if (all[i].p == p) {
-        live_bytes -= all[i].bytes;
+        live_bytes -= all[i].req;
         if (debug) { put_debug(i); return; }
         free_list.push_back(all[i]);
         return;
@@ -131,7 +153,7 @@ struct pfp_pool {
     (void)hipMemsetAsync(b, kCanary, kBand, stream);
     (void)hipMemsetAsync(b + kBand, kPoison, bytes, stream);
     (void)hipMemsetAsync(b + kBand + bytes, kCanary, kBand, stream);
-    all.push_back({b + kBand, bytes, base, file, line});
+    all.push_back({b + kBand, bytes, base, file, line, bytes});
     total_bytes += bytes; live_bytes += bytes; if (live_bytes > peak_bytes) peak_bytes = live_bytes;
     debug_blocks++;
     return b + kBand;

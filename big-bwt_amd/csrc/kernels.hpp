@@ -89,7 +89,9 @@ struct SuffixOrderT {
   bool range = false, complete = true;   // range mode stops (complete = false) where it would need other ranks' ranks
   DBuf<I> sa;            // [N] suffix start positions in sorted order (ties: position order)
   DBuf<I> grp;           // [N] grp[t] = first sa slot of slot t's group (equal strings share it)
-  DBuf<I> rank;          // [NP] rank[i] = grp[slot of i]; kNone where the sorter never needed it (see RankView)
+  DBuf<I> rank;          // [NP] rank[i] = grp[slot of i]; kNone where the sorter never needed it (see RankView); not allocated
+                         // where no round ever read it (then: wordrank)
+  DBuf<I> wordrank;      // [d+1] rank of word j's whole-word suffix where a round after the first settled it, else kNone
   uint64_t rounds = 0;
   // Dictionary mode keeps the sorted first-round keys: the rank of a suffix that the first round
   // already settled is the lower bound of its packed key among them, found on demand instead of
@@ -119,6 +121,7 @@ template <class I>
 struct RankViewT {
   const I *rank; const uint64_t *skeys; const I *tab; const uint32_t *lut; const uint8_t *bytes;
   uint64_t N; int kbits, shift; uint32_t T; I finbit; uint64_t keymask;
+  const I *wordrank;      // gather_ranks over the word starts: see SuffixOrderT::wordrank
 };
 template <class I> RankViewT<I> rank_view(const SuffixOrderT<I> &so);
 // out[k] = rank of the suffix starting at pos[k]

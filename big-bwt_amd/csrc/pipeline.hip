@@ -417,6 +417,7 @@ int pfp_ctx_create(pfp_ctx **out, int device) {
     PFP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->pool.stream = c->stream;
     { const char *pd = getenv("PFP_POOL_DEBUG"); c->pool.debug = pd && pd[0] && pd[0] != '0'; }
+    c->pool.trace = getenv("PFP_TRACE_POOL") != nullptr;
     { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->pool.soft_limit = tot / 10 * 7; else (void)hipGetLastError(); }
     PFP_HIP(hipHostMalloc((void **)&c->h_scalars, 16 * sizeof(uint64_t), hipHostMallocDefault));
     const char *dbg = getenv("PFP_DEBUG");
@@ -445,6 +446,7 @@ void pfp_ctx_destroy(pfp_ctx *c) {
   delete reinterpret_cast<K1Scratch *>(c->k1scratch);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->kt.destroy();
+  c->pool.print_peak();
   c->pool.destroy();
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   for (int k = 0; k < 2; k++) {

@@ -174,7 +174,7 @@ __device__ __forceinline__ uint64_t packed_key_at(const uint8_t *__restrict__ s,
 // write_back retires groups without gathering the suffix length of every member every round.
 template <class I>
 __device__ __forceinline__ I rank_at(const RankViewT<I> &L, uint64_t j, bool &settled) {
-  const I r = L.rank[j];
+  const I r = L.rank ? L.rank[j] : IdxTraits<I>::kNone;
   if (L.skeys == nullptr || r != IdxTraits<I>::kNone) { settled = (r & L.finbit) != 0; return r & ~L.finbit; }
   settled = true;
   const uint64_t k = packed_key_at(L.bytes, j, L.kbits, L.lut);
@@ -720,7 +720,7 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
                                   const uint8_t *__restrict__ hd, I finbit, const K *__restrict__ prevkey,
                                   int prevshift, const I *__restrict__ prevgrp, const uint8_t *__restrict__ veto,
                                   const uint32_t *__restrict__ wstart_bits, I *__restrict__ sa,
-                                  I *__restrict__ rank, I *__restrict__ grp, uint8_t *__restrict__ keep) {
+                                  I *__restrict__ rank, I *__restrict__ wordrank, I *__restrict__ grp, uint8_t *__restrict__ keep) {
   uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const I iv = val[a], i = iv & ~finbit;
@@ -746,6 +746,7 @@ __global__ void write_back_kernel(SufGeom g, uint64_t m, uint64_t sorted_len, co
   // read from a bitmap of N bits - it stays cache resident where the dictionary bytes would not)
   if (wstart_bits) wr = !k && single && ((wstart_bits[i >> 5] >> (i & 31)) & 1u);
   if (wr && rank) rank[i] = newhead[a] | (k ? (I)0 : finbit);
+  else if (wr && wordrank && wstart_bits) wordrank[word_of(g.wv, i)] = newhead[a] | finbit;      // (a settled whole word: see `wr` above)
   keep[a] = k ? 1 : 0;
 }
 
@@ -838,9 +839,9 @@ __global__ void finish_rank_kernel(SufGeom g, const uint8_t *__restrict__ s, uin
   lt[a] = nlt; eq[a] = neq; gstart[a] = (uint32_t)gs;
 }
 template <class I>
-__global__ void finish_write_kernel(uint64_t m, const I *__restrict__ aslot, const I *__restrict__ act_i, const uint32_t *__restrict__ lt,
+__global__ void finish_write_kernel(SufGeom g, uint64_t m, const I *__restrict__ aslot, const I *__restrict__ act_i, const uint32_t *__restrict__ lt,
                                     const uint32_t *__restrict__ eq, const uint32_t *__restrict__ gstart, I finbit,
-                                    I *__restrict__ sa, I *__restrict__ grp, I *__restrict__ rank) {
+                                    I *__restrict__ sa, I *__restrict__ grp, I *__restrict__ rank, I *__restrict__ wordrank) {
   const uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const uint64_t gs = gstart[a];
@@ -848,6 +849,7 @@ __global__ void finish_write_kernel(uint64_t m, const I *__restrict__ aslot, con
   sa[slot] = i;
   grp[slot] = head;            // identical strings share their group's first slot
   if (rank) rank[i] = head | finbit;
+  else if (wordrank && ((uint64_t)i == 0 || g.wv.bytes[(uint64_t)i - 1] == kEndOfWord)) wordrank[word_of(g.wv, i)] = head | finbit;
 }
 
 // after the first round, pivot rounds are tried while the groups are families (average size up to
@@ -860,7 +862,7 @@ constexpr uint64_t kLazyRatio = 8ull;
 
 template <class I>
 RankViewT<I> rank_view(const SuffixOrderT<I> &so) {
-  return RankViewT<I>{so.rank.p, so.skeys.p, so.tab.p, so.lut.p, so.bytes, so.N, so.kbits, so.shift, so.T, so.finbit, so.keymask};
+  return RankViewT<I>{so.rank.p, so.skeys.p, so.tab.p, so.lut.p, so.bytes, so.N, so.kbits, so.shift, so.T, so.finbit, so.keymask, so.wordrank.p};
 }
 template RankViewT<uint32_t> rank_view(const SuffixOrderT<uint32_t> &);
 template RankViewT<uint64_t> rank_view(const SuffixOrderT<uint64_t> &);
@@ -895,6 +897,10 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     std::swap(key, keyo); std::swap(val, valo);
   }
   if (lazy) { key.release(); val.release(); }      // dictionary mode: later rounds sort the (much smaller) unresolved set
+  // (allocated only now: while the first sort holds its four buffers - 32 bytes per suffix in the wide build - nothing else
+  //  of that size is live: a 4.8 GB dictionary peaked at 206 GB with the group array next to them, 168 GB without)
+  DBuf<uint8_t> hd(c, N + 1), keep(c, N);
+  out.grp.alloc(c, N + 8);
   // active list (slot, suffix, group) of the unresolved suffixes and per-round scratch, `cap` elements each;
   // dictionary mode allocates them when the first round has told how many suffixes stay unresolved
   DBuf<I> aslot, aslot2, hv, newhead, act_i, act_grp;
@@ -903,13 +909,9 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     aslot.alloc(c, cap); aslot2.alloc(c, cap); hv.alloc(c, cap); newhead.alloc(c, cap); act_i.alloc(c, cap); act_grp.alloc(c, cap);
     list_cap = cap;
   };
-  DBuf<uint8_t> hd(c, N + 1), keep(c, N);
-  out.grp.alloc(c, N + 8);
   // a share of the suffix array (multi-GPU) never runs a doubling round - it stops where one would be needed - and finds
   // its whole words by looking at its own slots (gather_slots_range): no rank per dictionary position is kept
   const bool no_rank = range_mode;
-  out.rank.alloc(c, no_rank ? 1 : NP);
-  I *const rank_p = no_rank ? (I *)nullptr : out.rank.p;
   if (!lazy) {
     out.sa.alloc(c, N);
     alloc_lists(N);
@@ -924,7 +926,6 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     out.tab.alloc(c, out.T);
     hipLaunchKernelGGL(fill_kernel<I>, gdim(cdiv(out.T, TB)), gdim(TB), 0, c->stream, out.tab.p, (uint64_t)out.T,
                        (I)(IdxTraits<I>::kNone - (I)N));
-    if (!no_rank) PFP_HIP(hipMemsetAsync(out.rank.p, 0xff, NP * sizeof(I), c->stream));
   }
   const int nb = bits_for(N);           // key of a later round = (group head << nb) | (1 + rank of the continuation)
   const int keybits = 2 * nb;
@@ -947,6 +948,24 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   DBuf<uint32_t> wstart_bits;   // pivot rounds: which positions start a word (their ranks order the dictionary)
   // lazy ranks are possible when pivot rounds (which never read rank[]) can follow the first round
   const bool lazy_active = lazy && lazy_pivot_ranks && out.finbit && g.mode == MODE_DICT && kPivotCap >= 16 && (uint64_t)nb + kPivBits <= 64;
+  // rank[] (one entry per dictionary position: 4 / 8 bytes each, 38 GB for a 4.8 GB dictionary in the wide build) exists
+  // from the start only where a round may read it.  With lazy ranks nothing reads it before the first doubling round - and a
+  // dictionary of word families never gets there - so it is allocated when (if) that round comes (late_rank); until then the
+  // whole words, whose ranks order the dictionary, report to wordrank[d].  (PFP_DEBUG validates every rank: eager.)
+  const bool late_rank = !no_rank && lazy_active && !c->debug;
+  bool rank_alloc = false;
+  I *rank_p = nullptr;
+  auto alloc_rank = [&]() {
+    out.rank.alloc(c, NP);
+    if (lazy) PFP_HIP(hipMemsetAsync(out.rank.p, 0xff, NP * sizeof(I), c->stream));
+    rank_p = out.rank.p; rank_alloc = true;
+  };
+  if (!no_rank && !late_rank) alloc_rank();
+  if (late_rank) {
+    out.wordrank.alloc(c, (uint64_t)g.wv.d + 1);
+    PFP_HIP(hipMemsetAsync(out.wordrank.p, 0xff, ((uint64_t)g.wv.d + 1) * sizeof(I), c->stream));
+  }
+  I *const wordrank_p = late_rank ? out.wordrank.p : (I *)nullptr;
   auto repair_ranks = [&](uint64_t m_active, const I *aslot_list) {
     if (!ranks_stale) return;
     DBuf<uint8_t> act(c, N);
@@ -1056,11 +1075,11 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       if (dbl_round && kWide && !seg_round)
         hipLaunchKernelGGL((write_back_kernel<I, K>), gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p, hd.p,
                            out.finbit, have_prev ? dkeyo.p : (const K *)nullptr, nb, prevgrp, vetop, lazyb, out.sa.p, rank_p,
-                           out.grp.p, keep.p);
+                           wordrank_p, out.grp.p, keep.p);
       else
         hipLaunchKernelGGL((write_back_kernel<I, uint64_t>), gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, aslot.p, valo.p, newhead.p,
                            hd.p, out.finbit, (have_prev && !seg_round) ? keyo.p : (const uint64_t *)nullptr, pivot_round ? kPivBits : nb,
-                           prevgrp, vetop, lazyb, out.sa.p, rank_p, out.grp.p, keep.p);
+                           prevgrp, vetop, lazyb, out.sa.p, rank_p, wordrank_p, out.grp.p, keep.p);
       if (pivot_round && lazy_pivot_ranks) { ranks_stale = true; active_stale = true; }
     }
     uint64_t m2 = 0, ngrp = 0;
@@ -1142,8 +1161,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       hipLaunchKernelGGL(finish_rank_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, out.bytes, m, act_i.p, act_grp.p, flt.p, feq.p,
                          fgs.p, fov.p);
       if (read_scalar(c, fov.p) == 0) {
-        hipLaunchKernelGGL(finish_write_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, aslot.p, act_i.p, flt.p, feq.p, fgs.p,
-                           out.finbit, out.sa.p, out.grp.p, rank_p);
+        hipLaunchKernelGGL(finish_write_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, aslot.p, act_i.p, flt.p, feq.p, fgs.p,
+                           out.finbit, out.sa.p, out.grp.p, rank_p, wordrank_p);
         PFP_HIP(hipGetLastError());
         if (trace_rounds) fprintf(stderr, "[pfp] doubling N=%llu round=%llu: the last %llu suffixes ranked by comparison\n",
                                   (unsigned long long)N, (unsigned long long)out.rounds, (unsigned long long)m);
@@ -1194,6 +1213,10 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       continue;                 // the sorted prefix common to all groups is still h: no doubling of h
     }
     if (range_mode) { out.complete = false; break; }     // doubling would read ranks of suffixes other ranks hold
+    if (late_rank && !rank_alloc) {      // the first doubling round: rank[] is needed after all
+      alloc_rank();
+      ranks_stale = true;               // whatever pivot rounds settled (whole words included) is filled in from the slots
+    }
     if (lazy_pending) {
       lazy_pending = false;
       if (m * kLazyRatio > N) {      // most lookups would need the search: scatter the settled ranks once
@@ -1251,13 +1274,19 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   }
   // PFP_DEBUG validates the rank of every position: fill in what the pivot rounds left out
   if (c->debug && out.complete && !no_rank) repair_ranks(0, nullptr);
+  if (rank_alloc) out.wordrank.release();      // every rank is in rank[]
 }
 
 template <class I>
 __global__ void gather_ranks_kernel(RankViewT<I> L, uint64_t count, const uint64_t *__restrict__ pos, I *__restrict__ out) {
   uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
   bool settled;
-  if (a < count) out[a] = rank_at(L, pos[a], settled);
+  if (a >= count) return;
+  if (L.wordrank) {      // pos[] are the word starts, in word order: the whole words a later round settled reported here
+    const I r = L.wordrank[a];
+    if (r != IdxTraits<I>::kNone) { out[a] = r & ~L.finbit; return; }
+  }
+  out[a] = rank_at(L, pos[a], settled);
 }
 template <class I>
 void gather_ranks(pfp_ctx *c, const SuffixOrderT<I> &so, const uint64_t *d_pos, uint64_t count, I *d_out) {

@@ -57,7 +57,8 @@ void pfp_free(void *host_ptr);     /* frees host buffers returned by this librar
 int pfp_debug_check(pfp_ctx *ctx);
 /* returns the context's cached (currently unused) device blocks to the driver */
 void pfp_pool_trim(pfp_ctx *ctx);
-/* out = {bytes held from the driver, peak bytes in use, bytes in use now, blocks handed out in debug mode} */
+/* out = {bytes held from the driver, peak of the bytes in use, bytes in use now, blocks handed out in debug mode};
+ * "in use" counts what the holders asked for (a recycled block can be larger than the request: that shows in out[0]) */
 int pfp_get_mem_stats(const pfp_ctx *ctx, uint64_t out[4]);
 /* out = {allocations that reached the driver (hipMalloc) since the context was made, times a failed one made the
  * pool hand its cached blocks back}: a steady-state call adds nothing to either */

@@ -2,6 +2,7 @@
 real reference produced for the same texts in the build container (tests/golden/golden_full.json, made
 by tests/golden/make_golden_full.py), and SURVEY.md section 4's GEN(12e6,16,1e-3,42) digests."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -143,3 +144,25 @@ def test_pack_and_sample_exports_on_slices(O, pkg, ctx):
     with pytest.raises(pkg.PfpError):
         buf = torch.empty(64, dtype=torch.uint8, device=dev)
         ctx.sample_runs_dev(bwt.data_ptr(), sa.data_ptr(), n + 1, 0, -1, -1, False, buf.data_ptr(), 1)
+
+
+@pytest.mark.gpu
+def test_dictionary_over_4gib_takes_the_wide_build():
+    """a 4.33 GB non-repetitive text: dictionary of 4.78 GB, so positions and slots are 64 bits wide (the reference switches
+    to its -DM64 executables there, bigbwt:109-151).  Checked by size-independent properties (tools/check_wide.py: the BWT is
+    a permutation of text + EOS; a second parse with another window and modulus gives the same BWT byte for byte) - no
+    reference digests exist for this size (the reference needs > 64 GiB of host memory for it).  Needs most of the GPU."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < (245 << 30):
+        pytest.skip(f"needs ~235 GB of free device memory, {free >> 30} GB free")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_wide.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["all_ok"] and r["index_bits"] == 64 and r["dict_over_4GiB"] and r["second_parse"]["index_bits"] == 64, r
+    assert r["peak_device_bytes"] <= 215e9, r["peak_device_bytes"]          # round 2: 274 GB
+    assert r["warm_pool"]["MBps"] >= 2000, r["warm_pool"]
