@@ -38,8 +38,11 @@ def gen():
         m = rng.random(len(t)) < 0.1
         t = np.where(m & (t >= 65), t | 32, t).astype(np.uint8)
     return np.ascontiguousarray(t, dtype=np.uint8), int(kind)
+import time
+timing = os.environ.get("FUZZ_TIMING") is not None      # seconds per iteration (oracle / chain / distributed) on stdout
 bad = 0; compared = 0; dist_runs = 0; skipped = 0
 for it in range(ntr):
+    t_it = time.perf_counter()
     t, kind = gen()
     w = int(rng.choice([4, 5, 10, 17])); p = int(rng.choice([10, 11, 20, 100]))
     flags = int(rng.choice([0, 1, 6]))
@@ -49,10 +52,12 @@ for it in range(ntr):
     except Exception as ex:
         skipped += 1
         continue
+    t_or = time.perf_counter()
     ok = True; msg = ""
     try:
         ctx.set_max_phrase(int(rng.choice([0, 700, 32768])) if len(t) > 3000 else 0)
         got = ctx.bigbwt(t, w, p, flags)
+        if timing: print("it=%d kind=%d n=%d w=%d p=%d flags=%d: oracle %.2f s, chain %.2f s" % (it, kind, len(t), w, p, flags, t_or - t_it, time.perf_counter() - t_or), flush=True)
         compared += 1
         ok = np.array_equal(got["bwt"], want["bwt"])
         if flags & 1: ok = ok and np.array_equal(pkg.unpack5(got["sa"]), want["sa"])
