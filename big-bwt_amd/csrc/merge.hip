@@ -977,7 +977,9 @@ __global__ void count_unset_kernel(const uint64_t *__restrict__ v, uint64_t n, u
 struct HardGroupInfo { uint64_t g; uint64_t E; uint32_t k; uint32_t minor; };
 // member m (of k) of the hard group at head slot g does not carry the majority char; roff: index of its first occurrence among
 // all minority occurrences (where hard_minor_kernel keeps its record for the SA round - no counter to contend for)
-struct MinorMember { uint64_t g; uint32_t k, m; uint64_t roff; };
+// base / ist / occ / sl / ch: the group's first output position and the member's own inverted list, char and suffix length, looked up
+// once where the list is laid out (eight lanes per group) instead of at the head of every ranking wave's chain of dependent loads
+struct MinorMember { uint64_t g; uint32_t k, m; uint64_t roff; uint64_t base; uint32_t ist, occ; uint32_t sl; uint32_t ch; };
 // sparse SA: what the second pass needs of a placed minority occurrence - its output position, its BWT(P) position
 // and those of its neighbours in the merged order (flags bit 0 / 1: there is a predecessor / successor), suffix length
 struct MinorRec { uint64_t o; uint32_t pos, pred, succ, flags, sl, pad; };
@@ -1060,6 +1062,7 @@ __global__ __launch_bounds__(256) void hard_minor_fill_kernel(MergeArgsT<I> a, c
   const HardGroupInfo gi = info[h];
   const uint32_t maj = gmaj[gi.g];
   uint64_t r = minor_off[h];
+  const uint64_t gbase = slot_off(a, gi.g);
   for (uint32_t m0 = 0; m0 < gi.k; m0 += 8) {
     const uint32_t m = m0 + (uint32_t)l8;
     const bool is_minor = m < gi.k && (uint32_t)fix_char(a.pc[gi.g + m]) != maj;
@@ -1071,7 +1074,12 @@ __global__ __launch_bounds__(256) void hard_minor_fill_kernel(MergeArgsT<I> a, c
       const uint32_t vc = __shfl_up(cnt, d2, 8); const uint64_t vo = __shfl_up(oc, d2, 8);
       if (l8 >= d2) { cnt += vc; oc += vo; }
     }
-    if (is_minor) out[o + cnt - own_c] = MinorMember{gi.g, gi.k, m, r + oc - own_o};
+    if (is_minor) {
+      const uint64_t myi = a.sa[gi.g + m];
+      const WordRec wr = a.wrec[word_of(a.wv, myi)];
+      out[o + cnt - own_c] = MinorMember{gi.g, gi.k, m, r + oc - own_o, gbase, wr.ist, wr.occ, (uint32_t)(wr.wend - myi),
+                                         (uint32_t)fix_char(a.pc[gi.g + m])};
+    }
     o += __shfl(cnt, 7, 8); r += __shfl(oc, 7, 8);
   }
 }
@@ -1089,21 +1097,13 @@ __global__ __launch_bounds__(256) void hard_minor_kernel(MergeArgsT<I> a, const 
   for (uint64_t it = 0; it < rounds; it++) {
     const uint64_t q = (it * GDIM + BID) * PER + (threadIdx.x / LPM);
     const bool live = q < total;
-    MinorMember mmv{0, 0, 0, 0};
+    MinorMember mmv{0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (live) mmv = mem[q];
     const uint64_t g = mmv.g;
     const uint32_t k = mmv.k, me = mmv.m;
-    uint32_t my_occ = 0, my_ist = 0;
-    uint64_t base = 0, sl = 0;
-    uint8_t mych = 0;
-    if (live) {
-      base = slot_off(a, g);
-      const I myi = a.sa[g + me];
-      const WordRec wr = a.wrec[word_of(a.wv, myi)];
-      my_occ = wr.occ; my_ist = wr.ist;
-      mych = fix_char(a.pc[g + me]);
-      sl = wr.wend - (uint64_t)myi;          // (equal suffixes: the same for every member)
-    }
+    const uint32_t my_occ = mmv.occ, my_ist = mmv.ist;
+    const uint64_t base = mmv.base, sl = mmv.sl;          // (equal suffixes: the same length for every member)
+    const uint8_t mych = (uint8_t)mmv.ch;
     // longest occurrence count among the members of the wave decides the trip count (shuffles inside the loop)
     uint32_t trips = my_occ;
 #pragma unroll

@@ -68,52 +68,59 @@ __device__ __forceinline__ uint32_t bad_bytes(uint32_t x) {
   return (x - 0x03030303u) & ~x & 0x80808080u;
 }
 
+// trigger mask of the 16 positions pos0 .. pos0 + 15 (bit j: position pos0 + j ends a phrase); reports the first byte <= 2
+template <int W>
+__device__ __forceinline__ uint32_t kr_mask16(const uint8_t *__restrict__ tbase, uint64_t pos0, uint64_t n, const KRParams &kp,
+                                              unsigned long long *__restrict__ first_bad) {
+  static_assert(W >= 2 && W <= 17, "register path needs w-1 <= 16");
+  const uint4 pv = *reinterpret_cast<const uint4 *>(tbase + pos0 - 16);
+  const uint4 cv = *reinterpret_cast<const uint4 *>(tbase + pos0);
+  const uint32_t r[8] = {pv.x, pv.y, pv.z, pv.w, cv.x, cv.y, cv.z, cv.w};
+  // bytes <= 2 stop the parse (newscan.cpp:364): report the first one
+  uint32_t bad = bad_bytes(cv.x) | bad_bytes(cv.y) | bad_bytes(cv.z) | bad_bytes(cv.w);
+  if (bad) {
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      if (byte_of(r, 16 + k) <= 2 && pos0 + k < n) { atomicMin(first_bad, (unsigned long long)(pos0 + k)); break; }
+  }
+  // first window: bytes [16-(W-1) .. 16], Horner 3 bytes per step
+  uint32_t h = 0;
+  constexpr int first = 16 - (W - 1);
+  int k = first;
+#pragma unroll
+  for (int s = 0; s < W / 3; s++) {
+    uint64_t T = ((uint64_t)h << 24) | (byte_of(r, k) << 16) | (byte_of(r, k + 1) << 8) | byte_of(r, k + 2);
+    h = kr_reduce<23>(T);
+    k += 3;
+  }
+  if (W % 3 == 1) { h = kr_reduce<8>(((uint64_t)h << 8) | byte_of(r, k)); }
+  if (W % 3 == 2) { h = kr_reduce<15>(((uint64_t)h << 16) | (byte_of(r, k) << 8) | byte_of(r, k + 1)); }
+  uint32_t mask = kr_divides(h, kp) ? 1u : 0u;
+#pragma unroll
+  for (int j = 1; j < 16; j++) {
+    const uint32_t cin = byte_of(r, 16 + j), cout = byte_of(r, 16 + j - W);
+    const uint64_t T = (uint64_t)cout * kp.negpw + (((uint64_t)h << 8) | cin);  // < 2^40
+    h = kr_reduce40((uint32_t)T, (uint32_t)(T >> 32));
+    mask |= (kr_divides(h, kp) ? 1u : 0u) << j;
+  }
+  // positions before w-1 (words shorter than w+1 are never saved, newscan.cpp:248) and past the text end
+  const uint64_t lo_valid = (uint64_t)(W - 1);
+  uint32_t valid = 0xFFFFu;
+  if (pos0 < lo_valid) valid &= 0xFFFFu << (uint32_t)(lo_valid - pos0);
+  if (n - pos0 < 16) valid &= (1u << (uint32_t)(n - pos0)) - 1u;
+  return mask & valid;
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void kr_flag_kernel(const uint8_t *__restrict__ tbase, uint64_t n, KRParams kp,
                                                       uint16_t *__restrict__ flags16,
                                                       uint32_t *__restrict__ block_counts,
                                                       unsigned long long *__restrict__ first_bad) {
-  static_assert(W >= 2 && W <= 17, "register path needs w-1 <= 16");
   const uint64_t c = (uint64_t)BID * 256 + threadIdx.x;  // 16-byte chunk index
   const uint64_t pos0 = c * 16;
   uint32_t mask = 0;
   if (pos0 < n) {
-    const uint4 pv = *reinterpret_cast<const uint4 *>(tbase + pos0 - 16);
-    const uint4 cv = *reinterpret_cast<const uint4 *>(tbase + pos0);
-    const uint32_t r[8] = {pv.x, pv.y, pv.z, pv.w, cv.x, cv.y, cv.z, cv.w};
-    // bytes <= 2 stop the parse (newscan.cpp:364): report the first one
-    uint32_t bad = bad_bytes(cv.x) | bad_bytes(cv.y) | bad_bytes(cv.z) | bad_bytes(cv.w);
-    if (bad) {
-#pragma unroll
-      for (int k = 0; k < 16; k++)
-        if (byte_of(r, 16 + k) <= 2 && pos0 + k < n) { atomicMin(first_bad, (unsigned long long)(pos0 + k)); break; }
-    }
-    // first window: bytes [16-(W-1) .. 16], Horner 3 bytes per step
-    uint32_t h = 0;
-    constexpr int first = 16 - (W - 1);
-    int k = first;
-#pragma unroll
-    for (int s = 0; s < W / 3; s++) {
-      uint64_t T = ((uint64_t)h << 24) | (byte_of(r, k) << 16) | (byte_of(r, k + 1) << 8) | byte_of(r, k + 2);
-      h = kr_reduce<23>(T);
-      k += 3;
-    }
-    if (W % 3 == 1) { h = kr_reduce<8>(((uint64_t)h << 8) | byte_of(r, k)); }
-    if (W % 3 == 2) { h = kr_reduce<15>(((uint64_t)h << 16) | (byte_of(r, k) << 8) | byte_of(r, k + 1)); }
-    mask = kr_divides(h, kp) ? 1u : 0u;
-#pragma unroll
-    for (int j = 1; j < 16; j++) {
-      const uint32_t cin = byte_of(r, 16 + j), cout = byte_of(r, 16 + j - W);
-      const uint64_t T = (uint64_t)cout * kp.negpw + (((uint64_t)h << 8) | cin);  // < 2^40
-      h = kr_reduce40((uint32_t)T, (uint32_t)(T >> 32));
-      mask |= (kr_divides(h, kp) ? 1u : 0u) << j;
-    }
-    // positions before w-1 (words shorter than w+1 are never saved, newscan.cpp:248) and past the text end
-    const uint64_t lo_valid = (uint64_t)(W - 1);
-    uint32_t valid = 0xFFFFu;
-    if (pos0 < lo_valid) valid &= 0xFFFFu << (uint32_t)(lo_valid - pos0);
-    if (n - pos0 < 16) valid &= (1u << (uint32_t)(n - pos0)) - 1u;
-    mask &= valid;
+    mask = kr_mask16<W>(tbase, pos0, n, kp, first_bad);
     flags16[c] = (uint16_t)mask;
   }
   // block count of triggers
@@ -124,6 +131,91 @@ __global__ __launch_bounds__(256) void kr_flag_kernel(const uint8_t *__restrict_
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0 && (uint64_t)BID * 4096 < n) block_counts[BID] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// K1 + K2 in one pass (round 3): the trigger masks never reach HBM.  A workgroup takes the next tile of 4096 positions from a
+// ticket counter (tiles are started in order, so the tiles before a running one are running or done), computes its masks,
+// publishes its trigger count, and finds the number of phrase ends before its tile by a decoupled look-back over the tiles
+// before it (Merrill & Garland's single-pass scan: every tile's state word holds "aggregate" or "inclusive prefix" with a
+// 2-bit tag; value and tag travel in ONE 64-bit word, so relaxed device-scope atomics suffice - a release / acquire pair costs an
+// L2 write-back / invalidate per tile on this multi-L2 part: 14 ms instead of 0.4); then every lane writes its ends at their final places.  ends[] has room for `cap` entries: what lies beyond is
+// counted, not written (the caller repeats with the true size - a text whose windows trigger four times as often as 1 / p).
+constexpr unsigned long long kTagShift = 62, kTagAgg = 1ull << 62, kTagPre = 2ull << 62, kTagMask = 3ull << 62;
+constexpr int kScanChunks = 16;                      // 4096-position chunks per tile: one look-back per 64 KB of text
+template <int W>
+__global__ __launch_bounds__(256) void kr_scan_kernel(const uint8_t *__restrict__ tbase, uint64_t n, KRParams kp, uint64_t ntiles,
+                                                      unsigned int *__restrict__ ticket, unsigned long long *__restrict__ state,
+                                                      uint64_t *__restrict__ ends, uint64_t cap,
+                                                      unsigned long long *__restrict__ first_bad) {
+  __shared__ uint32_t wsum[kScanChunks][4];
+  __shared__ unsigned int s_tile;
+  __shared__ unsigned long long s_excl;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const uint64_t tile = s_tile;
+  if (tile >= ntiles) return;      // (a workgroup of the padded last grid row)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t mask[kScanChunks], incl[kScanChunks];
+#pragma unroll 1
+  for (int j = 0; j < kScanChunks; j++) {
+    const uint64_t pos0 = ((tile * kScanChunks + j) * 256 + threadIdx.x) * 16;
+    mask[j] = pos0 < n ? kr_mask16<W>(tbase, pos0, n, kp, first_bad) : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < kScanChunks; j++) {
+    uint32_t v = __popc(mask[j]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t u = __shfl_up(v, off, 64); if (lane >= off) v += u; }
+    incl[j] = v;
+    if (lane == 63) wsum[j][wv] = v;
+  }
+  __syncthreads();
+  if (wv == 0) {
+    // the first wave looks back 64 tiles at a time: every lane waits for its tile's state, the lanes up to the nearest
+    // tile that already knows its inclusive prefix contribute
+    unsigned long long agg = 0;
+#pragma unroll
+    for (int j = 0; j < kScanChunks; j++) agg += (unsigned long long)wsum[j][0] + wsum[j][1] + wsum[j][2] + wsum[j][3];
+    unsigned long long excl = 0;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(&state[0], kTagPre | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(&state[tile], kTagAgg | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (long long base = (long long)tile - 1;; base -= 64) {
+        const long long idx = base - lane;
+        unsigned long long v = kTagPre;                      // before the first tile: prefix 0
+        if (idx >= 0)
+          while (((v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kTagMask) == 0) __builtin_amdgcn_s_sleep(1);
+        const unsigned long long pre = __ballot((v & kTagMask) == kTagPre);
+        const int first = pre ? __ffsll((long long)pre) - 1 : 64;      // nearest tile with an inclusive prefix
+        unsigned long long part = lane <= first ? (v & ~kTagMask) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        excl += part;
+        if (pre) break;
+      }
+      if (lane == 0) __hip_atomic_store(&state[tile], kTagPre | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_excl = excl;
+  }
+  __syncthreads();
+  uint64_t chunk_base = s_excl;
+#pragma unroll
+  for (int j = 0; j < kScanChunks; j++) {
+    uint32_t m = mask[j];
+    if (m) {
+      uint64_t o = chunk_base + (incl[j] - __popc(m));
+      for (int q = 0; q < wv; q++) o += wsum[j][q];
+      const uint64_t pos0 = ((tile * kScanChunks + j) * 256 + threadIdx.x) * 16;
+      while (m) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1;
+        if (o < cap) ends[o] = pos0 + (uint64_t)b;
+        o++;
+      }
+    }
+    chunk_base += (uint64_t)wsum[j][0] + wsum[j][1] + wsum[j][2] + wsum[j][3];
+  }
 }
 
 // generic window size (w > 17): same arithmetic, bytes fetched from memory
@@ -241,6 +333,12 @@ void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p,
   PFP_HIP(hipGetLastError());
 }
 
+template <int W>
+static void launch_scan(pfp_ctx *c, uint64_t ntiles, const uint8_t *tbase, uint64_t n, const KRParams &kp, unsigned int *ticket,
+                        unsigned long long *state, uint64_t *ends, uint64_t cap, unsigned long long *fb) {
+  hipLaunchKernelGGL(kr_scan_kernel<W>, gdim(ntiles), gdim(256), 0, c->stream, tbase, n, kp, ntiles, ticket, state, ends, cap, fb);
+}
+
 // Full stage 1a on a staged text.  Returns the number of trigger ends; d_ends receives them.
 // If a byte <= 2 is found before n, *n_used is set to its position and the scan is redone on
 // the prefix (the reference stops reading there: newscan.cpp:364).
@@ -248,15 +346,50 @@ uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t
                    uint64_t *n_used, const KRParams *kp_override) {
   PFP_REQUIRE(w >= 1 && w <= 4096, PFP_EINVAL, "window size out of range");
   uint64_t cur_n = n;
-  for (int attempt = 0; attempt < 2; attempt++) {
+  uint64_t cap_hint = 0;      // a pass that found more ends than it had room for tells the next one how many
+  for (int attempt = 0; attempt < 4; attempt++) {
     uint64_t nchunks = cdiv64(cur_n, 16);
     int nblocks = (int)cdiv64(nchunks, 256);
     *n_used = cur_n;
     if (nblocks == 0) { d_ends.alloc(c, 1); return 0; }
-    DBuf<uint16_t> flags16(c, nchunks);
-    DBuf<uint32_t> bcnt(c, (size_t)nblocks + 1), boff(c, (size_t)nblocks + 1);
     DBuf<unsigned long long> fbad(c, 1);
     PFP_HIP(hipMemsetAsync(fbad.p, 0xff, 8, c->stream));
+    if (w >= 4 && w <= 17) {
+      // one pass: masks, counts, look-back and placement in one kernel (kr_scan_kernel)
+      const KRParams kp = kp_override ? *kp_override : make_kr_params(w, p);
+      const uint64_t ntiles = cdiv64((uint64_t)nblocks, kScanChunks);
+      const uint64_t expect = cur_n / (p ? p : 1);
+      const uint64_t cap = cap_hint ? cap_hint : std::min<uint64_t>(cur_n, expect * 4 + 65536);
+      d_ends.alloc(c, cap + 1);
+      DBuf<unsigned long long> state(c, ntiles);
+      DBuf<unsigned int> ticket(c, 1);
+      state.zero(); ticket.zero();
+      {
+        KScope ks(c, "pfp::kr_scan_kernel", cur_n + 8 * std::min<uint64_t>(cap, expect));
+        switch (w) {
+#define CASE(W) case W: launch_scan<W>(c, ntiles, tx.tbase(), cur_n, kp, ticket.p, state.p, d_ends.p, cap, fbad.p); break;
+          CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17)
+#undef CASE
+        }
+        PFP_HIP(hipGetLastError());
+      }
+      PFP_HIP(hipMemcpyAsync(c->h_scalars, state.p + (ntiles - 1), 8, hipMemcpyDeviceToHost, c->stream));
+      PFP_HIP(hipMemcpyAsync(c->h_scalars + 1, fbad.p, 8, hipMemcpyDeviceToHost, c->stream));
+      sync(c);
+      const uint64_t total = c->h_scalars[0] & ~kTagMask;
+      const uint64_t fb = c->h_scalars[1];
+      if (fb < cur_n) {
+        PFP_REQUIRE(cur_n == n, PFP_EHIP, "scan: special byte after truncation");
+        cur_n = fb;
+        tx.restage_tail(c, cur_n, w);
+        cap_hint = 0;
+        continue;
+      }
+      if (total > cap) { cap_hint = total; continue; }      // more triggers than room: once more with the true size
+      return total;
+    }
+    DBuf<uint16_t> flags16(c, nchunks);
+    DBuf<uint32_t> bcnt(c, (size_t)nblocks + 1), boff(c, (size_t)nblocks + 1);
     PFP_HIP(hipMemsetAsync(bcnt.p + nblocks, 0, 4, c->stream));
     scan_flags(c, tx.tbase(), cur_n, w, p, flags16.p, bcnt.p, fbad.p, kp_override);
     exclusive_sum_u32(c, bcnt.p, boff.p, (size_t)nblocks + 1);
@@ -268,7 +401,7 @@ uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t
     uint64_t fb = c->h_scalars[1];
     if (fb < cur_n) {
       // truncate at the first special byte and rescan the prefix with Dollar padding re-staged
-      PFP_REQUIRE(attempt == 0, PFP_EHIP, "scan: special byte after truncation");
+      PFP_REQUIRE(cur_n == n, PFP_EHIP, "scan: special byte after truncation");
       cur_n = fb;
       tx.restage_tail(c, cur_n, w);
       continue;
@@ -280,6 +413,7 @@ uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t
     PFP_HIP(hipGetLastError());
     return total;
   }
+  PFP_REQUIRE(false, PFP_EHIP, "scan did not settle");
   return 0;
 }
 

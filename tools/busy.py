@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU busy fraction of the last chain in a rocprofv3 kernel trace: python tools/busy.py <*_kernel_trace.csv>
 
-The last chain = from the last pfp::kr_flag_kernel dispatch to the last kernel of the trace that belongs to the
+The last chain = from the last pfp::kr_scan_kernel (or kr_flag_kernel) dispatch to the last kernel of the trace that belongs to the
 library or to rocPRIM before the next non-library kernel burst.  Prints span, summed kernel time, union of the busy
 intervals and the number of dispatches - the gap between span and union is launch latency and host round trips."""
 import csv
@@ -9,9 +9,9 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda x: x[0])
-starts = [k for k, e in enumerate(ev) if "kr_flag_kernel" in e[2]]
+starts = [k for k, e in enumerate(ev) if "kr_scan_kernel" in e[2] or "kr_flag_kernel" in e[2]]
 if not starts:
-    sys.exit("no pfp::kr_flag_kernel in the trace")
+    sys.exit("no pfp::kr_scan_kernel or kr_flag_kernel in the trace")
 first = starts[-1]
 chain = ev[first:]
 # cut at the first torch kernel after the chain (the bench's checks)
