@@ -15,6 +15,9 @@
  * reference compares against the raw file, bigbwt:183-184, which can never match).
  * --parsing and --compress write the overlap-free dictionary (.dicz) as the reference does
  * (bigbwt:81); --compress then shells out to tar/xz exactly as bigbwt:98 does.
+ * -G N (--gpus N) builds ONE BWT on N GPUs: the driver - before it has touched a GPU itself - starts N ranks
+ * of ../dist_main.py as a child (`python3 -m torch.distributed.run`, one process per GPU, RCCL), each of which reads its
+ * byte range of the text and writes its ranges of the output files; --sum and -c then run here as for one GPU.
  */
 #define _GNU_SOURCE
 #include <errno.h>
@@ -24,8 +27,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <arpa/inet.h>
+#include <netinet/in.h>
 #include <sys/mman.h>
+#include <sys/socket.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
 #include "pfpgpu.h"
@@ -59,9 +66,69 @@ static void print_digest(const char *label, const char *base, const char *ext) {
   printf("%s sha256sum: %s\n", label, line);
 }
 
+/* a TCP port nobody listens on right now (the rendezvous of the ranks, on 127.0.0.1) */
+static int free_port(void) {
+  int fd = socket(AF_INET, SOCK_STREAM, 0);
+  if (fd < 0) return 29500;
+  struct sockaddr_in a;
+  memset(&a, 0, sizeof a);
+  a.sin_family = AF_INET;
+  a.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+  socklen_t len = sizeof a;
+  int port = 29500;
+  if (bind(fd, (struct sockaddr *)&a, sizeof a) == 0 && getsockname(fd, (struct sockaddr *)&a, &len) == 0) port = ntohs(a.sin_port);
+  close(fd);
+  return port;
+}
+
+/* -G N: N ranks of dist_main.py (next to this executable) under torch.distributed.run, as a child process; this
+ * process has not initialised the GPU yet.  Returns the launcher's exit code (non-zero if any rank failed). */
+static int run_ranks(int gpus, const char *textfile, const char *base, int w, unsigned long long p, int flags,
+                     unsigned long long halo, int verbose) {
+  char exe[4096], script[4200], nproc[64], port[32], ws[32], ps[32], fs[32], hs[32];
+  ssize_t len = readlink("/proc/self/exe", exe, sizeof exe - 1);
+  if (len <= 0) { perror("/proc/self/exe"); return 127; }
+  exe[len] = 0;
+  char *slash = strrchr(exe, '/');
+  if (slash) *slash = 0;
+  snprintf(script, sizeof script, "%s/dist_main.py", exe);
+  if (access(script, R_OK) != 0) { perror(script); return 127; }
+  const char *py = getenv("PFP_PYTHON");
+  if (!py || !*py) py = "python3";
+  snprintf(nproc, sizeof nproc, "--nproc-per-node=%d", gpus);
+  snprintf(port, sizeof port, "%d", free_port());
+  snprintf(ws, sizeof ws, "%d", w);
+  snprintf(ps, sizeof ps, "%llu", p);
+  snprintf(fs, sizeof fs, "%d", flags);
+  snprintf(hs, sizeof hs, "%llu", halo);
+  const char *args[32];
+  int k = 0;
+  args[k++] = py; args[k++] = "-m"; args[k++] = "torch.distributed.run"; args[k++] = "--nnodes=1"; args[k++] = nproc;
+  args[k++] = "--master-addr"; args[k++] = "127.0.0.1"; args[k++] = "--master-port"; args[k++] = port;
+  args[k++] = script; args[k++] = "--text"; args[k++] = textfile; args[k++] = "--base"; args[k++] = base;
+  args[k++] = "-w"; args[k++] = ws; args[k++] = "-p"; args[k++] = ps; args[k++] = "--flags"; args[k++] = fs;
+  args[k++] = "--halo"; args[k++] = hs;
+  if (verbose) args[k++] = "-v";
+  args[k] = NULL;
+  fflush(NULL);
+  pid_t pid = fork();
+  if (pid < 0) { perror("fork"); return 127; }
+  if (pid == 0) {
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);   /* dmabuf IPC: what RCCL needs between processes on this driver */
+    setenv("OMP_NUM_THREADS", "4", 0);
+    execvp(py, (char *const *)args);
+    perror(py);
+    _exit(127);
+  }
+  int st = 0;
+  while (waitpid(pid, &st, 0) < 0)
+    if (errno != EINTR) { perror("waitpid"); return 127; }
+  return WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st);
+}
+
 static void usage(const char *argv0) {
   printf("usage: %s [-h] [-w WSIZE] [-p MOD] [-t T] [-s] [-e] [-S] [-k] [-v] [-c] [-f] [--sum]\n"
-         "              [--parsing] [--compress] [--probing] input\n\n"
+         "              [--parsing] [--compress] [--probing] [-G N] input\n\n"
          "MI355X build of the prefix-free-parsing BWT tool (drop-in for alshai/Big-BWT's bigbwt).\n\n"
          "  input            input file name\n"
          "  -w, --wsize W    sliding window size (def. 10)\n"
@@ -77,21 +144,24 @@ static void usage(const char *argv0) {
          "  --sum            compute output files sha256sum\n"
          "  --parsing        stop after the parsing phase (debug only)\n"
          "  --compress       compress output of the parsing phase (.parse.txz of .parse and .dicz)\n"
-         "  -P, --probing    accepted for compatibility (deduplication here is exact)\n",
+         "  -P, --probing    accepted for compatibility (deduplication here is exact)\n"
+         "  -G, --gpus N     one BWT on N GPUs (one process per GPU over RCCL; not with -k / --parsing / --compress)\n"
+         "      --halo H     -G: bytes of each byte range its right neighbour also reads (def. 1048576; must cover a phrase)\n",
          argv0);
 }
 
 int main(int argc, char **argv) {
   int w = 10, th = 0, s = 0, e = 0, S = 0, keep = 0, verbose = 0, check = 0, fasta = 0, sum = 0, parsing = 0,
-      compress = 0, device = 0;
-  unsigned long long p = 100;
+      compress = 0, device = 0, gpus = 1;
+  unsigned long long p = 100, halo = 1ull << 20;
   static struct option lo[] = {{"wsize", required_argument, 0, 'w'}, {"mod", required_argument, 0, 'p'},
                                {"sum", no_argument, 0, 1000},        {"parsing", no_argument, 0, 1001},
                                {"compress", no_argument, 0, 1002},   {"probing", no_argument, 0, 'P'},
                                {"device", required_argument, 0, 1003}, {"help", no_argument, 0, 'h'},
+                               {"gpus", required_argument, 0, 'G'},  {"halo", required_argument, 0, 1004},
                                {0, 0, 0, 0}};
   int c;
-  while ((c = getopt_long(argc, argv, "w:p:t:seSkvcfPh", lo, NULL)) != -1) {
+  while ((c = getopt_long(argc, argv, "w:p:t:seSkvcfPhG:", lo, NULL)) != -1) {
     switch (c) {
       case 'w': w = atoi(optarg); break;
       case 'p': p = strtoull(optarg, NULL, 10); break;
@@ -108,6 +178,8 @@ int main(int argc, char **argv) {
       case 1001: parsing = 1; break;
       case 1002: compress = 1; break;
       case 1003: device = atoi(optarg); break;
+      case 1004: halo = strtoull(optarg, NULL, 10); break;
+      case 'G': gpus = atoi(optarg); break;
       case 'h': usage(argv[0]); return 0;
       default: usage(argv[0]); return 2;
     }
@@ -118,6 +190,10 @@ int main(int argc, char **argv) {
   if (S && (s || e)) {   /* bigbwt:59-61 */
     printf("You can either compute the full SA or a sample of it, not both. Exiting...\n");
     return 0;
+  }
+  if (gpus < 1 || (gpus > 1 && (keep || parsing || compress))) {
+    printf("-G N needs N >= 1 and writes no temporary files: not with -k, --parsing or --compress. Exiting...\n");
+    return 2;
   }
   char logname[4096];
   snprintf(logname, sizeof logname, "%s.log", input);
@@ -145,6 +221,34 @@ int main(int argc, char **argv) {
     if (text == MAP_FAILED) { perror("mmap"); return 1; }
   }
 
+  int flags = (S ? PFP_FLAG_SA : 0) | (s ? PFP_FLAG_SSA : 0) | (e ? PFP_FLAG_ESA : 0);
+  double start0 = now_s(), start = start0;
+  int status = 0;
+  fprintf(logf, "==== %s\n==== input %s (%llu bytes) -w %d -p %llu%s%s%s\n", pfp_version(), input,
+          (unsigned long long)n, w, p, s ? " -s" : "", e ? " -e" : "", S ? " -S" : "");
+  if (gpus > 1) {
+    /* the ranks come first: a process that has initialised the GPU must not start other programs on it */
+    const char *textfile = input;
+    char seqname[4096 + 16];
+    if (fasta) {   /* the ranks read byte ranges of the filtered text */
+      snprintf(seqname, sizeof seqname, "%s.seq", input);
+      if (write_file(input, "seq", text, n)) return 1;
+      textfile = seqname;
+    }
+    fflush(logf);
+    printf("==== Parsing, BWT of parsing, final BWT on %d GPUs. Command: dist_main.py x %d (%s, -w %d -p %llu%s%s%s)\n", gpus,
+           gpus, input, w, p, s ? " -s" : "", e ? " -e" : "", S ? " -S" : "");
+    int code = run_ranks(gpus, textfile, input, w, p, flags, halo, verbose);
+    if (fasta) unlink(seqname);
+    if (code) {
+      printf("Error executing command line:\n\t%d ranks of dist_main.py: exit code %d\nCheck log file: %s\n", gpus, code, logname);
+      fprintf(logf, "error: %d ranks of dist_main.py ended with exit code %d\n", gpus, code);
+      fclose(logf);
+      return 1;
+    }
+    printf("Elapsed time: %.4f\n", now_s() - start);
+  }
+
   pfp_ctx *ctx = NULL;
   int rc = pfp_ctx_create(&ctx, device);
   if (rc) {
@@ -152,13 +256,10 @@ int main(int argc, char **argv) {
     return 1;
   }
   pfp_set_profiling(ctx, verbose);
-  fprintf(logf, "==== %s\n==== input %s (%llu bytes) -w %d -p %llu%s%s%s\n", pfp_version(), input,
-          (unsigned long long)n, w, p, s ? " -s" : "", e ? " -e" : "", S ? " -S" : "");
-  int flags = (S ? PFP_FLAG_SA : 0) | (s ? PFP_FLAG_SSA : 0) | (e ? PFP_FLAG_ESA : 0);
-  double start0 = now_s(), start = start0;
-  int status = 0;
 
-  if (keep || parsing || compress) {
+  if (gpus > 1) {
+    /* done above, by the ranks */
+  } else if (keep || parsing || compress) {
     /* staged run: materialise the reference's temp files (bigbwt -k / --parsing) */
     pfp_parse_result pr;
     printf("==== Parsing. Command: pfp_parse(%s, -w %d -p %llu%s)\n", input, w, p, flags ? " -s" : "");

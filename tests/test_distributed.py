@@ -379,3 +379,94 @@ def test_distributed_run_over_rccl():
     assert np.array_equal(np.concatenate([o[3] for o in out]), want["bwt"])
     assert out[0][5] == 0 and out[1][5] == len(out[0][4])
     assert np.array_equal(pkg.unpack5(np.concatenate([o[4] for o in out])).reshape(-1, 2), want["ssa"])
+
+
+# ----------------------------------------------------------------------------- the C driver's -G N mode
+EXE = os.path.join(ROOT, "big-bwt_amd", "bigbwt")
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_c_driver_multi_gpu_mode_fails_loudly_without_a_gpu(tmp_path):
+    """bigbwt -G 2 starts its ranks as a child process; without a GPU every rank says so and the driver reports the failure
+    (exit code 1, no output files): no CPU path behind the multi-GPU mode either."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    f = tmp_path / "t.txt"
+    f.write_bytes(b"ACGT" * 1000)
+    out = subprocess.run([EXE, "-G", "2", str(f)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 1
+    assert "on 2 GPUs" in out.stdout and "2 ranks of dist_main.py: exit code" in out.stdout
+    assert "no GPU" in out.stderr and not os.path.exists(str(f) + ".bwt")
+    bad = subprocess.run([EXE, "-G", "2", "-k", str(f)], capture_output=True, text=True)
+    assert bad.returncode == 2 and "not with -k" in bad.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,G,opts,run", [("gen_small", 2, ["-s", "-e"], "6"), ("gen_nblock", 3, ["-S"], "1"), ("gen_1e6x4", 2, [], "0")])
+def test_c_driver_multi_gpu_mode(golden, O, tmp_path, name, G, opts, run):
+    """`bigbwt -G N`: N processes (here all on cuda:0, gloo instead of RCCL) each read a byte range of the file and write
+    their ranges of the outputs; the files must be the reference's (golden digests), --sum and -c work as for one GPU."""
+    import subprocess
+    from textgen import make_text
+    c = {x["name"]: x for x in golden}[name]
+    f = tmp_path / "t.fa"
+    f.write_bytes(make_text(c["spec"], O).tobytes())
+    for ext in (".bwt", ".sa", ".ssa", ".esa"):          # stale, longer files from "an earlier run"
+        (tmp_path / ("t.fa" + ext)).write_bytes(b"x" * 5_000_000)
+    env = dict(os.environ, PFP_DIST_BACKEND="gloo", PFP_DIST_ONE_GPU="1")
+    cmd = [EXE, "-G", str(G), "-w", str(c["w"]), "-p", str(c["p"]), "--halo", "65536", "--sum", "-c", "-v"] + opts + [str(f)]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want = c["runs"][run]
+    assert "BWTs match" in out.stdout and want["bwt_sha256"] in out.stdout and f"{G} ranks (gloo)" in out.stdout
+    for ext in ["bwt"] + [{"-s": "ssa", "-e": "esa", "-S": "sa"}[o] for o in opts]:
+        assert _sha(np.fromfile(str(f) + "." + ext, dtype=np.uint8)) == want[ext + "_sha256"], ext
+    log = open(str(f) + ".log").read()
+    assert f"Ranks: {G}" in log and "distinct words" in log
+
+
+@pytest.mark.gpu
+def test_c_driver_multi_gpu_fasta_and_failure(tmp_path):
+    """-f with -G: the ranks read byte ranges of the filtered sequences; a text the chain refuses (a byte <= 2) ends every
+    rank and the driver with an error instead of a hang or a partial file set"""
+    import json
+    import subprocess
+    with open(os.path.join(ROOT, "tests", "golden", "golden_fasta.json")) as fh:
+        cases = json.load(fh)["cases"]
+    c = max(cases, key=lambda x: len(x["raw_hex"]))
+    f = tmp_path / "in.fa"
+    f.write_bytes(bytes.fromhex(c["raw_hex"]))
+    env = dict(os.environ, PFP_DIST_BACKEND="gloo", PFP_DIST_ONE_GPU="1")
+    out = subprocess.run([EXE, "-f", "-G", "2", "-w", str(c["w"]), "-p", str(c["p"]), "-c", str(f)], capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "BWTs match" in out.stdout and not os.path.exists(str(f) + ".seq")
+    assert _sha(np.fromfile(str(f) + ".bwt", dtype=np.uint8)) == c["bwt_sha256"]
+    g = tmp_path / "bad.txt"
+    g.write_bytes(b"ACGTTGCA" * 5000 + b"\x01" + b"ACGTTGCA" * 5000)
+    out = subprocess.run([EXE, "-G", "2", str(g)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 1 and "exit code" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` with no launcher around it: bench starts its two ranks itself (here both on cuda:0 over gloo,
+    the one-GPU rehearsal of what the round-end driver runs on an 8-GPU node) and rank 0 prints ONE JSON line for the job"""
+    import json
+    import subprocess
+    env = dict(os.environ, PFP_BENCH_BACKEND="gloo", PFP_BENCH_ONE_GPU="1")
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "small"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and j["steps"] == 1
+    assert j["verified"]["bwt_is_permutation_of_text_plus_eos"] is True
+    assert j["rccl"]["ranks"] == 2 and j["rccl"]["backend"] == "gloo"
