@@ -62,6 +62,7 @@ void build_dictionary_shard(pfp_ctx *c, const StagedText &tx, uint64_t n, int w,
 void build_dictionary_words(pfp_ctx *c, const uint8_t *bytes, const uint64_t *wstart, const uint32_t *wlen, uint64_t U,
                             const uint32_t *weight, uint64_t total_bytes, Dictionary &D);
 // identity hash of every word of a list (same function the dedup sorts by)
+void reorder_dictionary_by_occ(pfp_ctx *c, Dictionary &D, DBuf<uint32_t> &perm);      // words by descending occurrence; perm[old] = new
 void hash_word_list(pfp_ctx *c, const uint8_t *bytes, const uint64_t *wstart, const uint32_t *wlen, uint64_t U, uint64_t seed,
                     uint64_t *d_hash);
 

@@ -377,4 +377,51 @@ void build_dictionary_words(pfp_ctx *c, const uint8_t *bytes, const uint64_t *ws
   build_dictionary_core(c, bytes, g, U, weight, total_bytes, false, false, 0, D);
 }
 
+// Words of a (duplicate-free) dictionary re-ordered by descending occurrence count, ties in their old order.
+// The multi-GPU chain assembles its global dictionary owner by owner (hash classes), so the lowest position of a
+// family of near-identical words - the pivot of the suffix sorter's pivot rounds - is a random variant; a variant's
+// own difference splits the family in two each round (15 rounds on 8 x 64 copies).  After this pass the lowest
+// position is the family's most frequent word, in a collection of variants the one the others deviate from: every
+// member then differs from the pivot at its OWN difference and is placed in one round, as the single-GPU chain's
+// first-occurrence order has it by construction.  perm[old index] = new index.
+__global__ void occ_sort_keys_kernel(uint32_t d, const uint32_t *__restrict__ occ, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+  uint32_t j = BID * blockDim.x + threadIdx.x;
+  if (j < d) { key[j] = ~occ[j]; val[j] = j; }
+}
+__global__ void occ_order_apply_kernel(uint32_t d, const uint32_t *__restrict__ order, const uint64_t *__restrict__ woff,
+                                       const uint32_t *__restrict__ wlen, const uint32_t *__restrict__ occ, uint64_t *__restrict__ wsrc,
+                                       uint32_t *__restrict__ nlen, uint32_t *__restrict__ len1, uint32_t *__restrict__ nocc,
+                                       uint32_t *__restrict__ perm) {
+  uint32_t r = BID * blockDim.x + threadIdx.x;
+  if (r == 0) len1[d] = 0;
+  if (r >= d) return;
+  const uint32_t j = order[r];
+  wsrc[r] = woff[j]; nlen[r] = wlen[j]; len1[r] = wlen[j] + 1; nocc[r] = occ[j]; perm[j] = r;
+}
+void reorder_dictionary_by_occ(pfp_ctx *c, Dictionary &D, DBuf<uint32_t> &perm) {
+  const uint32_t d = (uint32_t)D.d;
+  const int TB = 256;
+  perm.alloc(c, std::max<uint32_t>(d, 1));
+  if (d < 2) { if (d) perm.zero(); return; }
+  KScope ks(c, "pfp::dict_reorder_kernels", 2 * D.dsize + 40ull * d);
+  DBuf<uint32_t> key(c, d), keyo(c, d), val(c, d), order(c, d), nlen(c, d), len1(c, (size_t)d + 1), nocc(c, d), long_list(c, d), cnt(c, 1);
+  DBuf<uint64_t> wsrc(c, d), nwoff(c, (size_t)d + 1);
+  hipLaunchKernelGGL(occ_sort_keys_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, D.wocc.p, key.p, val.p);
+  sort_pairs_u32_u32(c, key.p, keyo.p, val.p, order.p, d, 0, 32);      // stable: equal counts keep their order
+  hipLaunchKernelGGL(occ_order_apply_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, order.p, D.woff.p, D.wlen.p, D.wocc.p, wsrc.p,
+                     nlen.p, len1.p, nocc.p, perm.p);
+  exclusive_sum_u32_u64(c, len1.p, nwoff.p, (size_t)d + 1);
+  DBuf<uint8_t> nb(c, D.dsize + 64);
+  PFP_HIP(hipMemsetAsync(nb.p + (D.dsize - 1), 0, 65, c->stream));
+  cnt.zero();
+  hipLaunchKernelGGL(dict_copy_kernel, gdim(cdiv((uint64_t)d * 8, TB)), gdim(TB), 0, c->stream, D.bytes.p, d, wsrc.p, nlen.p, nwoff.p, nb.p,
+                     long_list.p, cnt.p);
+  const uint32_t nlong = read_scalar(c, cnt.p);
+  if (nlong)
+    hipLaunchKernelGGL(dict_copy_long_kernel, gdim(c->n_cu * 4), gdim(TB), 0, c->stream, D.bytes.p, wsrc.p, nlen.p, nwoff.p, nb.p, long_list.p,
+                       nlong);
+  PFP_HIP(hipGetLastError());
+  D.bytes = std::move(nb); D.woff = std::move(nwoff); D.wlen = std::move(nlen); D.wocc = std::move(nocc);
+}
+
 }  // namespace pfp

@@ -1405,8 +1405,17 @@ int pfp_dist_global_sort_distinct(pfp_ctx *c, const void *d_dict, uint64_t dict_
   PFP_HIP(hipMemcpyAsync(ds->G.wocc.p, d_occ, n_words * 4, hipMemcpyDeviceToDevice, c->stream));
   const uint32_t dl = (uint32_t)ds->L.d;
   ds->gid_local.alloc(c, dl);
-  hipLaunchKernelGGL(scatter_u32_kernel, gdim(cdiv(dl, TB)), gdim(TB), 0, c->stream, dl, ds->part_order.p, (const uint32_t *)d_gid_sent,
-                     ds->gid_local.p);
+  static const bool by_occ = getenv("PFP_DIST_NO_OCC_ORDER") == nullptr;      // (diagnostic: the owners' order as it arrived)
+  if (by_occ) {
+    // most frequent words first: the pivots of the suffix sorter's pivot rounds become the words the variants deviate from
+    DBuf<uint32_t> perm, gid(c, std::max<uint32_t>(dl, 1));
+    { PhaseTimer t(c, &c->stats.ms_phrases); reorder_dictionary_by_occ(c, ds->G, perm); }
+    hipLaunchKernelGGL(gather_u32_kernel, gdim(cdiv(dl, TB)), gdim(TB), 0, c->stream, dl, (const uint32_t *)d_gid_sent, perm.p, gid.p);
+    hipLaunchKernelGGL(scatter_u32_kernel, gdim(cdiv(dl, TB)), gdim(TB), 0, c->stream, dl, ds->part_order.p, gid.p, ds->gid_local.p);
+    sync(c);      // perm and gid are released on return
+  } else
+    hipLaunchKernelGGL(scatter_u32_kernel, gdim(cdiv(dl, TB)), gdim(TB), 0, c->stream, dl, ds->part_order.p, (const uint32_t *)d_gid_sent,
+                       ds->gid_local.p);
   ds->have_gid = true;
   dist_sort_global(c, ds, part, parts, d_wslot_out, out_info);
   return PFP_OK;

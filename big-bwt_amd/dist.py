@@ -440,8 +440,8 @@ def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=Tru
                 reqs[r] = payload
             except StopIteration as fin:
                 results[r] = fin.value
-            if trim:          # many virtual ranks on one card: a rank's cached device blocks must not starve the next one
-                ctxs[r].pool_trim()
+            if trim is True or (trim and r in trim):   # many virtual ranks on one card: a rank's cached device blocks must
+                ctxs[r].pool_trim()                    # not starve the next one (trim = True, or the set of ranks to trim)
         live = set(reqs)
         if live:
             assert len(live) == size and len(kinds) == 1, "ranks fell out of step"
