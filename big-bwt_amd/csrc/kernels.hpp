@@ -39,7 +39,7 @@ uint64_t scan_text_adaptive(pfp_ctx *c, const StagedText &tx, uint64_t n, int w,
                             DBuf<uint64_t> &d_ends, uint64_t *n_used, uint32_t *n_extra);
 
 // ---------------------------------------------------------------- stage 1b (phrase.hip)
-// Distinct phrases (the dictionary) in first-occurrence order plus the parse as word ids.
+// Distinct phrases (the dictionary), most frequent first (ties: first occurrence), plus the parse as word ids.
 struct Dictionary {
   uint64_t P = 0;          // # phrases
   uint64_t d = 0;          // # distinct words

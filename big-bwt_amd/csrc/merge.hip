@@ -302,7 +302,7 @@ constexpr uint32_t kSlCap = 0xFFFFFFu;
 // 64), the words of the others follow from the terminators before them in the block (ballots); consecutive positions
 // share their word's record.  dense_ist: full SA output wants the start of the word's inverted list where the sparse
 // modes want its smallest position (field `first`).
-// Positions [pos0, pos1) only (pos0 a multiple of 256), out[i - pos0]: a dictionary whose records would not fit is done in blocks.
+// Positions [pos0, pos1), out[i - pos0] (pos0 a multiple of 256).
 __global__ __launch_bounds__(256) void pprec16_kernel(WordView wv, int w, const uint4 *__restrict__ wrec /* WordRec as two uint4 */,
                                                       int dense_ist, uint64_t pos0, uint64_t pos1, PosRec *__restrict__ out) {
   __shared__ uint32_t wt[4];
@@ -326,14 +326,18 @@ __global__ __launch_bounds__(256) void pprec16_kernel(WordView wv, int w, const 
   }
   *reinterpret_cast<uint4 *>(out + (i - pos0)) = make_uint4(r.occ, r.first, r.last, r.pcsl);
 }
-// blocked records: the slots whose suffix starts in [pos0, pos1) fetch theirs
-template <class I>
-__global__ void slot_fetch_kernel(uint64_t N, const I *__restrict__ sa, uint64_t pos0, uint64_t pos1, const PosRec *__restrict__ blk,
-                                  PosRec *__restrict__ srec) {
-  const uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
-  if (t >= N) return;
-  const uint64_t i = sa[t];
-  if (i >= pos0 && i < pos1) *reinterpret_cast<uint4 *>(srec + t) = *reinterpret_cast<const uint4 *>(blk + (i - pos0));
+// the same record for ONE position, computed where it is wanted: the position's 64-byte line of the dictionary (word
+// lookup + preceding char) and its word's 32-byte record - two random sectors instead of one, and no 16 bytes per
+// dictionary position.  A share of the suffix array (multi-GPU: N slots of NP positions, N << NP) and a dictionary whose
+// records would not fit take this form.
+__device__ __forceinline__ uint4 posrec_at(const WordView &wv, int w, const uint4 *__restrict__ wrec, int dense_ist, uint64_t i) {
+  const uint32_t wd = word_of(wv, i);
+  if (wd >= wv.d) return make_uint4(0u, 0u, 0u, 0u);
+  const uint4 wr = wrec[2 * (uint64_t)wd], we = wrec[2 * (uint64_t)wd + 1];      // {ist, occ, first, last} {terminator position, -}
+  const uint64_t sl = ((uint64_t)we.x | ((uint64_t)we.y << 32)) - i;
+  if (sl <= (uint64_t)w) return make_uint4(0u, 0u, 0u, 0u);
+  const uint32_t pc = (i == 0) ? (uint32_t)kEndOfWord : (uint32_t)wv.bytes[i - 1];
+  return make_uint4(wr.y, dense_ist ? wr.x : wr.z, wr.w, pc | ((sl < kSlCap ? (uint32_t)sl : kSlCap) << 8));
 }
 
 // Per tile of 2048 slots (256 threads x 8 consecutive slots): gather the records, exclusive scan of the counts inside
@@ -348,8 +352,9 @@ __global__ __launch_bounds__(256) void slot_records_kernel(uint64_t N, const I *
                                                            uint32_t *__restrict__ slast, uint32_t *__restrict__ ssl,
                                                            uint64_t *__restrict__ tsum, uint32_t *__restrict__ overflow,
                                                            uint32_t *__restrict__ tile_full, unsigned long long *__restrict__ first_full,
-                                                           uint8_t *__restrict__ hard, int any_multi_is_hard, int per_slot) {
-  // per_slot: prec[] already holds one record per SLOT (blocked records, slot_fetch_kernel) - read, not gathered
+                                                           uint8_t *__restrict__ hard, int any_multi_is_hard, WordView view, int w,
+                                                           const uint4 *__restrict__ wrec, int dense_ist) {
+  // prec == null: no per-position records - every slot computes its own (posrec_at)
   __shared__ uint64_t ws[4];
   __shared__ uint32_t lpc[256];
   __shared__ I lgrp[256];
@@ -366,14 +371,19 @@ __global__ __launch_bounds__(256) void slot_records_kernel(uint64_t N, const I *
   }
   uint4 r8[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) r8[k] = k < nk ? *reinterpret_cast<const uint4 *>(prec + (per_slot ? t0 + k : (uint64_t)idx[k])) : make_uint4(0u, 0u, 0u, 0u);
+  for (int k = 0; k < 8; k++)
+    r8[k] = k >= nk ? make_uint4(0u, 0u, 0u, 0u)
+                    : (prec ? *reinterpret_cast<const uint4 *>(prec + (uint64_t)idx[k]) : posrec_at(view, w, wrec, dense_ist, (uint64_t)idx[k]));
   // the slot before this thread's first one: the previous thread's last slot, or (first thread) the last slot of the tile before
   uint32_t p8[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) p8[k] = r8[k].w & 0xffu;
   lpc[threadIdx.x] = p8[7]; lgrp[threadIdx.x] = g8[7];
   uint32_t prev_pc = 0; I prev_g = IdxTraits<I>::kNone;
-  if (threadIdx.x == 0 && t0 > 0 && nk) { prev_pc = prec[per_slot ? t0 - 1 : (uint64_t)sa[t0 - 1]].pcsl & 0xffu; prev_g = grp[t0 - 1]; }
+  if (threadIdx.x == 0 && t0 > 0 && nk) {
+    prev_pc = (prec ? prec[(uint64_t)sa[t0 - 1]].pcsl : posrec_at(view, w, wrec, dense_ist, (uint64_t)sa[t0 - 1]).w) & 0xffu;
+    prev_g = grp[t0 - 1];
+  }
   // counts: exclusive scan inside the tile
   uint64_t own = 0;
 #pragma unroll
@@ -1517,40 +1527,35 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   ovf.zero();
   PFP_HIP(hipMemsetAsync(tsum.p + ntile, 0, 8, c->stream));
   if (fused) {
-    // 16 bytes per dictionary position - all at once while that stays below an eighth of the device, else in blocks of
-    // positions whose records the slots fetch block by block (a 30 GB dictionary on one rank of the multi-GPU chain:
-    // 480 GB of records otherwise; PFP_PREC_BLOCK = positions per block, for the tests)
-    uint64_t blk = cdiv64(NP, 256) * 256;
+    // 16 bytes per dictionary position, written by one streaming pass and gathered once per slot - unless the slots are a
+    // small share of the positions (a rank's range of the multi-GPU chain: the pass over all NP positions is replicated
+    // work, 14 GB of records for a 0.9 GB dictionary) or the records would take more than an eighth of the device
+    // (a 30 GB dictionary: 480 GB): then every slot computes its record itself from the dictionary line and its word's
+    // entry (posrec_at: two random sectors per slot instead of one).  PFP_PREC_DIRECT=1/0 forces the choice (tests).
+    bool direct = N * 4 <= NP;
     {
       const uint64_t dev_bytes = c->pool.soft_limit ? c->pool.soft_limit / 7 * 10 : (64ull << 30);
-      const char *e = getenv("PFP_PREC_BLOCK");
-      const uint64_t cap = e ? strtoull(e, nullptr, 10) : dev_bytes / 8 / sizeof(PosRec);
-      if (blk > cap) blk = std::max<uint64_t>(cap / 256, 1) * 256;
+      if (NP * sizeof(PosRec) > dev_bytes / 8) direct = true;
+      const char *e = getenv("PFP_PREC_DIRECT");
+      if (e) direct = atoi(e) != 0;
     }
-    const bool blocked = blk < NP;
-    prec.alloc(c, blk);
-    DBuf<PosRec> srec;
-    if (blocked) srec.alloc(c, std::max<uint64_t>(N, 1));
-    for (uint64_t p0 = 0; p0 < NP; p0 += blk) {
-      const uint64_t p1 = std::min<uint64_t>(p0 + blk, NP);
-      { KScope ks(c, "pfp::pprec_kernel", (p1 - p0) * (1 + 16) + (uint64_t)d * 40);
-        hipLaunchKernelGGL(pprec16_kernel, gdim(cdiv(p1 - p0, TB)), gdim(TB), 0, c->stream, wv, w, reinterpret_cast<const uint4 *>(wrec.p),
-                           dense ? 1 : 0, p0, p1, prec.p); }
-      if (blocked && N) {
-        KScope ks(c, "pfp::slot_gather_kernel", N * sizeof(I));
-        hipLaunchKernelGGL(slot_fetch_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, so.sa.p, p0, p1, prec.p, srec.p);
-      }
+    if (!direct) {
+      const uint64_t np256 = cdiv64(NP, 256) * 256;
+      prec.alloc(c, np256);
+      KScope ks(c, "pfp::pprec_kernel", NP * (1 + 16) + (uint64_t)d * 40);
+      hipLaunchKernelGGL(pprec16_kernel, gdim(cdiv(np256, TB)), gdim(TB), 0, c->stream, wv, w, reinterpret_cast<const uint4 *>(wrec.p),
+                         dense ? 1 : 0, (uint64_t)0, NP, prec.p);
     }
-    const PosRec *recs_p = blocked ? srec.p : prec.p;
     // per-slot copies of what the unit-edge / minority kernels ask about a slot's word (read coalesced there); full SA:
     // the list start of every slot's word and its suffix length
     sfirst.alloc(c, ntile << kOffTileLog);
     if (!dense) slast.alloc(c, ntile << kOffTileLog);
     if (samode != SA_NONE) ssl.alloc(c, ntile << kOffTileLog);
-    { KScope ks(c, "pfp::slot_gather_kernel", N * (2 * sizeof(I) + 16 + 4 + 1 + 4 + (slast.p ? 4 : 0) + (ssl.p ? 4 : 0)));
-      hipLaunchKernelGGL(slot_records_kernel<I>, gdim((unsigned)ntile), gdim(256), 0, c->stream, N, so.sa.p, so.grp.p, recs_p, loc.p, pc.p,
-                         sfirst.p, slast.p, ssl.p, tsum.p, ovf.p, tile_full.p, first_full.p, hard.p, dense ? 1 : 0, blocked ? 1 : 0); }
-    prec.release(); srec.release();
+    { KScope ks(c, "pfp::slot_gather_kernel", N * (2 * sizeof(I) + (direct ? 64 + 32 : 16) + 4 + 1 + 4 + (slast.p ? 4 : 0) + (ssl.p ? 4 : 0)));
+      hipLaunchKernelGGL(slot_records_kernel<I>, gdim((unsigned)ntile), gdim(256), 0, c->stream, N, so.sa.p, so.grp.p,
+                         direct ? (const PosRec *)nullptr : prec.p, loc.p, pc.p, sfirst.p, slast.p, ssl.p, tsum.p, ovf.p, tile_full.p,
+                         first_full.p, hard.p, dense ? 1 : 0, wv, w, reinterpret_cast<const uint4 *>(wrec.p), dense ? 1 : 0); }
+    prec.release();
   } else {
     { KScope ks(c, "pfp::slot_gather_kernel", N * (8 + 1 + 5));
       hipLaunchKernelGGL(slot_payload_kernel<I>, gdim(cdiv(cdiv64(N, 8), 256)), gdim(256), 0, c->stream, N, so.sa.p, so.skeys.p,

@@ -11,7 +11,7 @@
 //   * dedup = radix sort of (hash, phrase#) + adjacent compare.  Every occurrence is verified
 //     byte-for-byte against its predecessor (the reference compares strings on every hit,
 //     newscan.cpp:282); a mismatch reseeds the hash and retries, so the result is exact.
-//   * words are numbered in first-occurrence order; the lexicographic ranks the reference
+//   * words are numbered by descending occurrence count (ties: first occurrence); the lexicographic ranks the reference
 //     assigns with std::sort (newscan.cpp:622-636) fall out of the dictionary suffix sort.
 #include "kernels.hpp"
 #include "prims.hpp"
@@ -162,7 +162,16 @@ __global__ void weighted_occ_kernel(uint64_t P, const uint32_t *__restrict__ hsc
   if (i < P) atomicAdd(&hocc[hscan[i] - 1], weight[vs[i]]);
 }
 
-__global__ void finish_words_kernel(PhraseGeom g, uint32_t d, const uint32_t *__restrict__ rep_sorted,
+// order of the words in the device dictionary: most frequent first, ties by first occurrence (key = ~occ : first phrase)
+__global__ void word_order_keys_kernel(uint32_t d, const uint32_t *__restrict__ hrep, const uint32_t *__restrict__ hpos,
+                                       const uint32_t *__restrict__ hocc, uint64_t *__restrict__ key) {
+  uint32_t hw = BID * blockDim.x + threadIdx.x;
+  if (hw >= d) return;
+  const uint32_t occ = hocc ? hocc[hw] : hpos[hw + 1] - hpos[hw];
+  key[hw] = ((uint64_t)(~occ) << 32) | hrep[hw];
+}
+
+__global__ void finish_words_kernel(PhraseGeom g, uint32_t d, const uint64_t *__restrict__ rep_sorted,
                                     const uint32_t *__restrict__ hw_sorted, const uint32_t *__restrict__ hpos,
                                     const uint32_t *__restrict__ hocc,
                                     uint32_t *__restrict__ fo_of_hw, uint32_t *__restrict__ wlen,
@@ -173,7 +182,7 @@ __global__ void finish_words_kernel(PhraseGeom g, uint32_t d, const uint32_t *__
   if (j >= d) return;
   uint32_t hw = hw_sorted[j];
   fo_of_hw[hw] = j;
-  uint64_t k = rep_sorted[j];
+  uint64_t k = rep_sorted[j] & 0xFFFFFFFFull;
   uint64_t s = ph_start(g, k), len = ph_end(g, k) - s + 1;
   if (len >= 0xFFFFFFF0ull) { atomicOr(toolong, 1u); len = 0xFFFFFFF0ull; }
   wlen[j] = (uint32_t)len;
@@ -312,8 +321,12 @@ static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, u
     D.reseeds++;
   }
   D.d = d;
-  // words in first-occurrence order
-  DBuf<uint32_t> hrep(c, d), hpos(c, (size_t)d + 1), hwi(c, d), rep_sorted(c, d), hw_sorted(c, d), fo_of_hw(c, d);
+  // words by descending occurrence count, ties in first-occurrence order.  (The order inside the device dictionary is free -
+  // the outputs depend on the words' lexicographic ranks only - and this one makes the lowest position of a family of
+  // near-identical words its most frequent member: the pivot of the suffix sorter's pivot rounds is then the word the variants
+  // deviate from, and every variant is placed by its own difference in one round.)
+  DBuf<uint32_t> hrep(c, d), hpos(c, (size_t)d + 1), hwi(c, d), hw_sorted(c, d), fo_of_hw(c, d);
+  DBuf<uint64_t> okey(c, d), rep_sorted(c, d);
   DBuf<uint32_t> hocc;
   if (weight) {
     hocc.alloc(c, d);
@@ -323,7 +336,9 @@ static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, u
   hipLaunchKernelGGL(collect_words_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, P, head.p, hscan.p, vs.p, hrep.p,
                      hpos.p, d);
   hipLaunchKernelGGL(iota_u32_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, hwi.p, (uint64_t)d);
-  sort_pairs_u32_u32(c, hrep.p, rep_sorted.p, hwi.p, hw_sorted.p, d, 0, bits_for(P));
+  hipLaunchKernelGGL(word_order_keys_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, hrep.p, hpos.p,
+                     weight ? hocc.p : (const uint32_t *)nullptr, okey.p);
+  sort_pairs_u64_u32(c, okey.p, rep_sorted.p, hwi.p, hw_sorted.p, d, 0, 64);
   D.wlen.alloc(c, d); D.wocc.alloc(c, d); D.woff.alloc(c, (size_t)d + 1); D.pid.alloc(c, P);
   DBuf<uint32_t> wlen1(c, (size_t)d + 1);
   DBuf<uint64_t> wsrc(c, d);

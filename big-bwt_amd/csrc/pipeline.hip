@@ -679,30 +679,100 @@ static void dictionary_from_host(pfp_ctx *c, const uint8_t *s, uint64_t n, Dicti
 
 // gsacak's optional outputs (gsa/gsacak.h:78-105): LCP[i] = length of the common prefix of the suffixes SA[i-1] and
 // SA[i], where a separator (1) or the final 0 ends the count (gsa/README.md:76-104); DA[i] = index of the string
-// the suffix SA[i] starts in.  One thread per slot compares its two suffixes 8 bytes at a time.
+// the suffix SA[i] starts in.
+// Pass 1: one thread per slot compares its two suffixes 8 bytes at a time, for at most kLcpCap bytes; a pair still equal
+// there is flagged.  Pass 2 (only if something was flagged - long exact repeats: an 18 Mb run of N inside one string has
+// 18 M pairs with a mean common prefix of 9 MB, which one thread per pair would never finish): the flagged slots in TEXT
+// order, 1024 of them per wave.  Neighbours in text order inherit (Kasai et al.: lcp(phi(b+1), b+1) >= lcp(phi(b), b) - 1;
+// separators rank as distinct smallest symbols, gsacak.c:2493, so the lemma holds for a collection), the compare itself
+// is the whole wave's: 64 lanes x 16 bytes per step, a ballot finds the first difference or end.
+constexpr uint32_t kLcpCap = 2048;
+constexpr uint32_t kLcpChunk = 1024;
 template <class I, class L>
 __global__ void lcp_da_kernel(const uint8_t *__restrict__ s, uint64_t n, const I *__restrict__ sa, WordView wv,
-                              L *__restrict__ lcp, L *__restrict__ da) {
+                              L *__restrict__ lcp, L *__restrict__ da, uint8_t *__restrict__ longf) {
   const uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const uint64_t b = sa[t];
   if (da) da[t] = (L)word_of(wv, b);
   if (!lcp) return;
+  longf[t] = 0;
   if (t == 0) { lcp[0] = 0; return; }
   const uint64_t a = sa[t - 1];
   uint64_t l = 0;
-  for (;;) {
+  for (; l < kLcpCap; l += 8) {
     const uint64_t x = ld8u(s + a + l), y = ld8u(s + b + l);
     const uint64_t end = (x - 0x0202020202020202ull) & ~x & 0x8080808080808080ull;      // bytes < 2 of x (lowest flag exact)
     const uint64_t diff = x ^ y;
     if (diff | end) {
       const int fd = diff ? (__builtin_ctzll(diff) >> 3) : 8, fe = end ? (__builtin_ctzll(end) >> 3) : 8;
-      l += fd < fe ? fd : fe;
-      break;
+      lcp[t] = (L)(l + (fd < fe ? fd : fe));
+      return;
     }
-    l += 8;
   }
-  lcp[t] = (L)l;
+  longf[t] = 1;      // equal for kLcpCap bytes: pass 2
+}
+template <class I>
+__global__ void lcp_long_pos_kernel(uint64_t m, const uint64_t *__restrict__ slot, const I *__restrict__ sa, uint64_t *__restrict__ pos) {
+  const uint64_t j = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (j < m) pos[j] = sa[slot[j]];
+}
+// one wave per kLcpChunk flagged pairs (sorted by text position b; slot[j] = their suffix-array slot)
+template <class I, class L>
+__global__ __launch_bounds__(64) void lcp_long_kernel(const uint8_t *__restrict__ s, uint64_t n, const I *__restrict__ sa, uint64_t m,
+                                                      const uint64_t *__restrict__ pos, const uint64_t *__restrict__ slot, L *__restrict__ lcp) {
+  const uint64_t j0 = (uint64_t)BID * kLcpChunk;
+  if (j0 >= m) return;
+  const uint64_t j1 = j0 + kLcpChunk < m ? j0 + kLcpChunk : m;
+  const int lane = threadIdx.x;
+  uint64_t prev_b = ~0ull, prev_l = 0;
+  for (uint64_t j = j0; j < j1; j++) {
+    const uint64_t b = pos[j], t = slot[j], a = sa[t - 1];      // (slot 0 is never flagged)
+    uint64_t l = kLcpCap;
+    if (prev_b + 1 == b && prev_l > (uint64_t)kLcpCap + 1) l = prev_l - 1;
+    for (;;) {
+      const uint64_t off = l + (uint64_t)lane * 16;
+      // (the buffer is padded with 64 zero bytes past n: a lane that would read beyond them sees an end instead)
+      const bool in = a + off + 16 <= n + 64 && b + off + 16 <= n + 64;
+      uint4 x = make_uint4(0u, 0u, 0u, 0u), y = x;
+      if (in) { x = ld16u(s + a + off); y = ld16u(s + b + off); }
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+      int ev = 16;
+#pragma unroll
+      for (int q = 3; q >= 0; q--) {
+        const uint32_t end = (xs[q] - 0x02020202u) & ~xs[q] & 0x80808080u, diff = xs[q] ^ ys[q];
+        if (diff | end) {
+          const int fd = diff ? (__builtin_ctz(diff) >> 3) : 4, fe = end ? (__builtin_ctz(end) >> 3) : 4;
+          ev = 4 * q + (fd < fe ? fd : fe);
+        }
+      }
+      const unsigned long long hit = __ballot(ev < 16);
+      if (hit) {
+        const int first = __ffsll((long long)hit) - 1;
+        l += (uint64_t)first * 16 + (uint64_t)__shfl(ev, first, 64);
+        break;
+      }
+      l += 1024;
+    }
+    if (lane == 0) lcp[t] = (L)l;
+    prev_b = b; prev_l = l;
+  }
+}
+template <class I, class L>
+static void lcp_da_device(pfp_ctx *c, const uint8_t *bytes, uint64_t n, const I *sa, const WordView &wv, L *d_lcp, L *d_da) {
+  DBuf<uint8_t> longf(c, d_lcp ? n + 16 : 16);
+  if (d_lcp) PFP_HIP(hipMemsetAsync(longf.p + n, 0, 16, c->stream));
+  hipLaunchKernelGGL((lcp_da_kernel<I, L>), gdim(cdiv(n, TB)), gdim(TB), 0, c->stream, bytes, n, sa, wv, d_lcp, d_da, longf.p);
+  PFP_HIP(hipGetLastError());
+  if (!d_lcp) return;
+  const uint64_t m = count_flags(c, longf.p, n);
+  if (!m) return;
+  DBuf<uint64_t> slot(c, m), slot2(c, m), pos(c, m), pos2(c, m), cnt(c, 1);
+  select_index<uint64_t>(c, longf.p, slot.p, cnt.p, n);
+  hipLaunchKernelGGL(lcp_long_pos_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, slot.p, sa, pos.p);
+  sort_pairs_db(c, pos, pos2, slot, slot2, m, 0, bits_for(n));
+  hipLaunchKernelGGL((lcp_long_kernel<I, L>), gdim((unsigned)cdiv64(m, kLcpChunk)), gdim(64), 0, c->stream, bytes, n, sa, m, pos.p, slot.p, d_lcp);
+  PFP_HIP(hipGetLastError());
 }
 template <class OUT, class L>
 static void gsacak_any(pfp_ctx *c, const uint8_t *s, OUT *SA, uint64_t n, L *LCP = nullptr, L *DA = nullptr) {
@@ -716,9 +786,7 @@ static void gsacak_any(pfp_ctx *c, const uint8_t *s, OUT *SA, uint64_t n, L *LCP
     fetch_converted<I, OUT>(c, so.sa.p, n, SA);
     if (LCP || DA) {
       DBuf<L> dl(c, LCP ? n : 1), dd(c, DA ? n : 1);
-      hipLaunchKernelGGL((lcp_da_kernel<I, L>), gdim(cdiv(n, TB)), gdim(TB), 0, c->stream, D.bytes.p, n, so.sa.p, word_view(D, ix),
-                         LCP ? dl.p : (L *)nullptr, DA ? dd.p : (L *)nullptr);
-      PFP_HIP(hipGetLastError());
+      lcp_da_device<I, L>(c, D.bytes.p, n, so.sa.p, word_view(D, ix), LCP ? dl.p : (L *)nullptr, DA ? dd.p : (L *)nullptr);
       if (LCP) d2h(c, LCP, dl.p, n);
       if (DA) d2h(c, DA, dd.p, n);
       sync(c);

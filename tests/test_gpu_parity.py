@@ -139,6 +139,22 @@ def test_suffix_sorters_match_oracle(O, wctx):
     assert elcp.tolist() == O.gsacak(ex, want_lcp=True)[1].tolist()
 
 
+def test_lcp_of_long_repeats(O, wctx):
+    """gsacak's LCP output on a collection full of long exact repeats - a 150 K run of one letter (149 999 ... 1 between
+    neighbouring suffixes), the same 30 K string twice plus a prefix of it, a 80 K periodic string: nearly every pair shares
+    more than the 2 KB one thread compares, and goes through the text-order pass (pipeline.hip lcp_long_kernel)"""
+    rng = np.random.default_rng(5)
+    r = rng.integers(65, 70, size=30000).astype(np.uint8)
+    coll = np.concatenate([np.full(150000, ord("N"), np.uint8), [1], r, [1], np.tile(np.frombuffer(b"ACGT", np.uint8), 20000), [1], r, [1],
+                           r[:20000], [1, 0]]).astype(np.uint8)
+    osa, olcp = O.gsacak(coll, want_lcp=True)
+    assert (olcp >= 2048).sum() > 250000 and olcp.max() == 149999
+    for wide in (False, True):
+        gsa, glcp, gda = wctx.gsacak_lcp_da(coll, wide)
+        assert np.array_equal(gsa.astype(np.uint32), osa)
+        assert np.array_equal(glcp.astype(np.int64), olcp.astype(np.int64))
+
+
 def test_error_behaviour(pkg, ctx, O):
     text = O.gen_fasta(5000, 1, 0, 3)
     for kw, code in [(dict(w=3), -1), (dict(p=9), -1), (dict(flags=pkg.FLAG_SA | pkg.FLAG_SSA), -1)]:
@@ -187,12 +203,12 @@ def test_mid_size_against_oracle(O, pkg, wctx):
     assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
 
 
-@pytest.mark.parametrize("block", [256, 4096])
-def test_position_records_in_blocks(golden, O, pkg, wctx, monkeypatch, block):
-    """the merge's 16-byte position records done in blocks of positions (what a dictionary too large for one array of
-    them gets: the multi-GPU chain's ranks at |D| = 30 GB): same files, all three flag sets"""
-    monkeypatch.setenv("PFP_PREC_BLOCK", str(block))
-    for c in golden[:6]:
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_position_records_per_slot_or_per_position(golden, O, pkg, wctx, monkeypatch, direct):
+    """the merge's 16-byte records computed by every slot itself (what a rank's share of the multi-GPU chain and a dictionary
+    too large for one record per position get) or written per position and gathered: same files, all three flag sets"""
+    monkeypatch.setenv("PFP_PREC_DIRECT", direct)
+    for c in golden[:8]:
         text = make_text(c["spec"], O)
         for flags in (0, 1, 6):
             r = c["runs"][str(flags)]
