@@ -638,7 +638,9 @@ constexpr uint32_t kPivCapMax = 8192;
 //  bytes coalesced, ballot for the first differing chunk.  Same lines fetched, 3x fewer address-coalescer cycles - and 17 %
 //  SLOWER (c3 6.8 -> 7.9 ms, 12.6 GB 107 -> 120 ms): the kernel is bound by the rate at which HBM serves random lines
 //  (~54 G/s, tools/microbench/gather.hip; 112 M members x ~1.6 lines + their pivots' = 3.9 ms at that rate), not by
-//  its instruction stream, and eight times the waves only add ballots.  One thread per member stays.)
+//  its instruction stream, and eight times the waves only add ballots.  One thread per member stays.
+//  Also tried: 64 bytes per step instead of 32, the second half's loads in flight with the first's - c3 6.5 -> 7.1 ms,
+//  12.6 GB 101 -> 102.5 ms: members that differ or end inside the first 32 bytes pay for a second line they do not need.)
 template <class I>
 __global__ void build_keys_pivot_kernel(const uint8_t *__restrict__ s, uint64_t m, uint64_t from, uint32_t cap,
                                         const I *__restrict__ act_i, const I *__restrict__ act_grp,
