@@ -1184,6 +1184,10 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     pivot_round = pivot_ok && g.mode == MODE_DICT && out.finbit && kPivotCap >= 16 && ngrp && m / ngrp <= kPivotAvg &&
                   (uint64_t)nb + kPivBits <= 64;
     if (pivot_round) {
+      // few suffixes left: the widest window at once.  (A compare reads only as far as the strings agree; the window bounds
+      // the worst case, m x window bytes.  What is left after two rounds are mostly members of phrases longer than the
+      // 512-byte window: without this they cost one round that settles nothing and quadruples the window, then another.)
+      if (piv_cap >= 16 && piv_cap < kPivCapMax - 16 && out.rounds >= 2 && m * (uint64_t)(kPivCapMax - 16) < N * 128) piv_cap = kPivCapMax - 16;
       // large families (a collection of hundreds of copies): the members are already grouped, a
       // segmented sort of the 23-bit order key moves 16 B per suffix instead of 7 x 24 B
       bool seg = false, small = false;
