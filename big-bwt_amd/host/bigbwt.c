@@ -15,9 +15,10 @@
  * reference compares against the raw file, bigbwt:183-184, which can never match).
  * --parsing and --compress write the overlap-free dictionary (.dicz) as the reference does
  * (bigbwt:81); --compress then shells out to tar/xz exactly as bigbwt:98 does.
- * -G N (--gpus N) builds ONE BWT on N GPUs: the driver - before it has touched a GPU itself - starts N ranks
- * of ../dist_main.py as a child (`python3 -m torch.distributed.run`, one process per GPU, RCCL), each of which reads its
- * byte range of the text and writes its ranges of the output files; --sum and -c then run here as for one GPU.
+ * -G N (--gpus N) builds ONE BWT on N GPUs of the node: one call, pfp_bigbwt_files_multi - a host thread and a context
+ * per GPU inside the library, RCCL collectives between them, every rank reads its byte range of the text and pwrites its
+ * ranges of the output files (the reference's -t N threads do the same on the CPU); --sum and -c then run as for one GPU.
+ * PFP_MULTI_PYTHON=1 starts N processes of ../dist_main.py under torch.distributed instead (the driver the bench uses).
  */
 #define _GNU_SOURCE
 #include <errno.h>
@@ -145,7 +146,7 @@ static void usage(const char *argv0) {
          "  --parsing        stop after the parsing phase (debug only)\n"
          "  --compress       compress output of the parsing phase (.parse.txz of .parse and .dicz)\n"
          "  -P, --probing    accepted for compatibility (deduplication here is exact)\n"
-         "  -G, --gpus N     one BWT on N GPUs (one process per GPU over RCCL; not with -k / --parsing / --compress)\n"
+         "  -G, --gpus N     one BWT on N GPUs of this node, devices --device .. --device + N - 1 (RCCL; not with -k / --parsing / --compress)\n"
          "      --halo H     -G: bytes of each byte range its right neighbour also reads (def. 1048576; must cover a phrase)\n",
          argv0);
 }
@@ -226,7 +227,7 @@ int main(int argc, char **argv) {
   int status = 0;
   fprintf(logf, "==== %s\n==== input %s (%llu bytes) -w %d -p %llu%s%s%s\n", pfp_version(), input,
           (unsigned long long)n, w, p, s ? " -s" : "", e ? " -e" : "", S ? " -S" : "");
-  if (gpus > 1) {
+  if (gpus > 1 && getenv("PFP_MULTI_PYTHON") && atoi(getenv("PFP_MULTI_PYTHON"))) {
     /* the ranks come first: a process that has initialised the GPU must not start other programs on it */
     const char *textfile = input;
     char seqname[4096 + 16];
@@ -246,6 +247,29 @@ int main(int argc, char **argv) {
       fclose(logf);
       return 1;
     }
+    printf("Elapsed time: %.4f\n", now_s() - start);
+  } else if (gpus > 1) {
+    /* one thread and one context per GPU inside the library, RCCL between them */
+    int devs[64];
+    if (gpus > 64) { printf("-G: at most 64 GPUs\n"); return 2; }
+    for (int g = 0; g < gpus; g++) devs[g] = device + g;
+    pfp_multi_stats ms;
+    char err[1024] = "";
+    printf("==== Parsing, BWT of parsing, final BWT on %d GPUs. Command: pfp_bigbwt_files_multi(%s, -w %d -p %llu%s%s%s)\n", gpus,
+           input, w, p, s ? " -s" : "", e ? " -e" : "", S ? " -S" : "");
+    int code = pfp_bigbwt_files_multi(gpus, devs, text, n, w, p, flags, halo, input, &ms, err, sizeof err);
+    if (code) {
+      printf("Error executing command line:\n\t%s: %s\nCheck log file: %s\n", pfp_strerror(code), err, logname);
+      fprintf(logf, "error %d: %s\n", code, err);
+      fclose(logf);
+      return 1;
+    }
+    fprintf(logf, "Ranks: %llu\nFound %llu distinct words\nTotal number of words: %llu\nDictionary size: %llu\nIndex width: %llu bits\n",
+            (unsigned long long)ms.ranks, (unsigned long long)ms.n_words, (unsigned long long)ms.n_phrases,
+            (unsigned long long)ms.dict_size, (unsigned long long)ms.index_bits);
+    if (verbose)
+      printf("  %llu ranks: chain %.1f ms, with files %.1f ms; suffix array of the dictionary in %llu share(s)\n", (unsigned long long)ms.ranks,
+             ms.ms_chain, ms.ms_total, (unsigned long long)ms.sa_shares);
     printf("Elapsed time: %.4f\n", now_s() - start);
   }
 

@@ -32,7 +32,7 @@ SYMBOLS = ["pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror"
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_files", "pfp_bigbwt_dev", "pfp_bigbwt_formats_dev", "pfp_dev_free", "pfp_memcpy_d2h", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
            "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
            "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_partition_words", "pfp_dist_export_partition",
-           "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_sample_runs", "pfp_dist_release"]
+           "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_sample_runs", "pfp_dist_release", "pfp_bigbwt_files_multi"]
 
 
 class PfpError(RuntimeError):
@@ -494,3 +494,22 @@ class Context:
 
     def scan_k1_enqueue(self, p=100):
         self._check(self.lib.pfp_scan_k1_enqueue(self._h, C.c_uint64(p)))
+
+
+def bigbwt_files_multi(text, base, devices, w=10, p=100, flags=0, halo=0):
+    """pfp_bigbwt_files_multi: one BWT on len(devices) GPUs from this process (csrc/multi.hip); returns its statistics"""
+    lib = load_library()
+
+    class MultiStats(C.Structure):
+        _fields_ = [(k, C.c_uint64) for k in ("n", "n_words", "n_phrases", "dict_size", "index_bits", "ranks", "sa_shares")] + \
+                   [("ms_chain", C.c_double), ("ms_total", C.c_double)]
+    text = _arr(text, np.uint8)
+    st = MultiStats()
+    err = C.create_string_buffer(1024)
+    devs = (C.c_int * len(devices))(*devices)
+    lib.pfp_bigbwt_files_multi.restype = C.c_int
+    rc = lib.pfp_bigbwt_files_multi(C.c_int(len(devices)), devs, _ptr(text, C.c_uint8), C.c_uint64(len(text)), C.c_int(w), C.c_uint64(p),
+                                    C.c_int(flags), C.c_uint64(halo), str(base).encode(), C.byref(st), err, C.c_uint64(len(err)))
+    if rc != 0:
+        raise PfpError(rc, err.value.decode(errors="replace"))
+    return {k: getattr(st, k) for k, _ in MultiStats._fields_}

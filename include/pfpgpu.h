@@ -319,6 +319,25 @@ int pfp_dist_merge(pfp_ctx *ctx, const void *d_sym, uint64_t P, const void *d_la
 int pfp_dist_sample_runs(pfp_ctx *ctx, int run_end, int drop_edge, void *d_out10, uint64_t cap_pairs, uint64_t *n_pairs);
 void pfp_dist_release(pfp_ctx *ctx);
 
+/* ------------------------------------------------------------------------------------
+ * One BWT on n_dev GPUs of one node, from one process (csrc/multi.hip): a host thread and a context per device run
+ * the chain above and meet in RCCL collectives over xGMI (grouped ncclSend / ncclRecv of the ranks' pieces; librccl is
+ * loaded on the first call).  The reference's analogue is its threaded build, `bigbwt -t N`: pscan.cpp / pscan.hpp:114-165
+ * (byte ranges of the input, hash-sharded dictionary) and pfthreads.hpp:171-176, 369-376, 456-493 (the suffix array sharded
+ * by range, output ranges written with pwrite).  text = the whole input in host memory (rank r reads bytes
+ * [n r / n_dev, n (r+1) / n_dev)); halo = bytes of a range its right neighbour also reads, must cover the longest phrase
+ * (0 = 1 MiB); outputs out_base.bwt / .sa / .ssa / .esa as pfp_bigbwt_files writes them.  A failure on any rank ends all
+ * ranks; its text goes to errbuf.  Bytes <= 2 in the text are an error here (PFP_EFORMAT), not the end of the input.
+ * PFP_MULTI_LOOPBACK=1 (tests on a one-GPU box): the ranks share the devices given, modulo the visible ones, and exchange
+ * through device copies instead of RCCL. */
+typedef struct {
+  uint64_t n, n_words, n_phrases, dict_size, index_bits;
+  uint64_t ranks, sa_shares;      /* sa_shares = 1: a key range could not finish alone, every rank sorted the whole dictionary */
+  double ms_chain, ms_total;      /* rank 0: upload to finished device outputs; + files */
+} pfp_multi_stats;
+int pfp_bigbwt_files_multi(int n_dev, const int *devices, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags,
+                           uint64_t halo, const char *out_base, pfp_multi_stats *stats, char *errbuf, uint64_t errbuf_len);
+
 /* ---- micro entry points used by bench.py's roofline leg and by the parity tests ---- */
 /* copy a device-resident text into the ctx's padded staging buffer (T' = Dollar.T.Dollar^w) */
 int pfp_stage_text_dev(pfp_ctx *ctx, const void *d_text, uint64_t n, int w);

@@ -391,8 +391,8 @@ def _sha(a):
 
 
 def test_c_driver_multi_gpu_mode_fails_loudly_without_a_gpu(tmp_path):
-    """bigbwt -G 2 starts its ranks as a child process; without a GPU every rank says so and the driver reports the failure
-    (exit code 1, no output files): no CPU path behind the multi-GPU mode either."""
+    """bigbwt -G 2 without a GPU: the library call says so (native ranks) / every rank process says so (PFP_MULTI_PYTHON=1) and
+    the driver reports the failure (exit code 1, no output files): no CPU path behind the multi-GPU mode either."""
     import subprocess
     if torch.cuda.is_available():
         pytest.skip("GPU present")
@@ -400,17 +400,26 @@ def test_c_driver_multi_gpu_mode_fails_loudly_without_a_gpu(tmp_path):
     f.write_bytes(b"ACGT" * 1000)
     out = subprocess.run([EXE, "-G", "2", str(f)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 1
+    assert "on 2 GPUs" in out.stdout and "pfp_bigbwt_files_multi" in out.stdout and "no usable HIP device" in out.stdout
+    assert not os.path.exists(str(f) + ".bwt")
+    out = subprocess.run([EXE, "-G", "2", str(f)], capture_output=True, text=True, timeout=300, env=dict(os.environ, PFP_MULTI_PYTHON="1"))
+    assert out.returncode == 1
     assert "on 2 GPUs" in out.stdout and "2 ranks of dist_main.py: exit code" in out.stdout
     assert "no GPU" in out.stderr and not os.path.exists(str(f) + ".bwt")
     bad = subprocess.run([EXE, "-G", "2", "-k", str(f)], capture_output=True, text=True)
     assert bad.returncode == 2 and "not with -k" in bad.stdout
 
 
+MULTI_CASES = [("gen_small", 2, ["-s", "-e"], "6"), ("gen_nblock", 3, ["-S"], "1"), ("gen_1e6x4", 2, [], "0"), ("gen_1e6x4", 5, ["-s"], "6"),
+               ("gen_p101_w12", 4, ["-e"], "6"), ("n_run", 3, ["-S"], "1"), ("kat1", 2, ["-s", "-e"], "6")]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,G,opts,run", [("gen_small", 2, ["-s", "-e"], "6"), ("gen_nblock", 3, ["-S"], "1"), ("gen_1e6x4", 2, [], "0")])
+@pytest.mark.parametrize("name,G,opts,run", MULTI_CASES)
 def test_c_driver_multi_gpu_mode(golden, O, tmp_path, name, G, opts, run):
-    """`bigbwt -G N`: N processes (here all on cuda:0, gloo instead of RCCL) each read a byte range of the file and write
-    their ranges of the outputs; the files must be the reference's (golden digests), --sum and -c work as for one GPU."""
+    """`bigbwt -G N`: N rank threads inside the library (pfp_bigbwt_files_multi; here all on cuda:0, exchanging through device
+    copies instead of RCCL: PFP_MULTI_LOOPBACK=1) each read a byte range of the file and write their ranges of the outputs; the
+    files must be the reference's (golden digests), --sum and -c work as for one GPU."""
     import subprocess
     from textgen import make_text
     c = {x["name"]: x for x in golden}[name]
@@ -418,12 +427,17 @@ def test_c_driver_multi_gpu_mode(golden, O, tmp_path, name, G, opts, run):
     f.write_bytes(make_text(c["spec"], O).tobytes())
     for ext in (".bwt", ".sa", ".ssa", ".esa"):          # stale, longer files from "an earlier run"
         (tmp_path / ("t.fa" + ext)).write_bytes(b"x" * 5_000_000)
-    env = dict(os.environ, PFP_DIST_BACKEND="gloo", PFP_DIST_ONE_GPU="1")
+    env = dict(os.environ, PFP_MULTI_LOOPBACK="1")
     cmd = [EXE, "-G", str(G), "-w", str(c["w"]), "-p", str(c["p"]), "--halo", "65536", "--sum", "-c", "-v"] + opts + [str(f)]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    if len(make_text(c["spec"], O)) < 64 * G:          # a text too short to give every rank a phrase: refused, not wrong
+        assert out.returncode in (0, 1), out.stdout + out.stderr
+        if out.returncode == 1:
+            assert "Error executing command line" in out.stdout
+            return
     assert out.returncode == 0, out.stdout + out.stderr
     want = c["runs"][run]
-    assert "BWTs match" in out.stdout and want["bwt_sha256"] in out.stdout and f"{G} ranks (gloo)" in out.stdout
+    assert "BWTs match" in out.stdout and want["bwt_sha256"] in out.stdout and f"{G} ranks: chain" in out.stdout
     for ext in ["bwt"] + [{"-s": "ssa", "-e": "esa", "-S": "sa"}[o] for o in opts]:
         assert _sha(np.fromfile(str(f) + "." + ext, dtype=np.uint8)) == want[ext + "_sha256"], ext
     log = open(str(f) + ".log").read()
@@ -431,9 +445,47 @@ def test_c_driver_multi_gpu_mode(golden, O, tmp_path, name, G, opts, run):
 
 
 @pytest.mark.gpu
+def test_c_driver_multi_gpu_over_rccl(golden, O, tmp_path):
+    """the same over RCCL, one rank per GPU; needs two GPUs, skips itself on a one-GPU box"""
+    import subprocess
+    from textgen import make_text
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the driver's 8-GPU node runs it)")
+    G = min(torch.cuda.device_count(), 8)
+    c = {x["name"]: x for x in golden}["gen_1e6x4"]
+    f = tmp_path / "t.fa"
+    f.write_bytes(make_text(c["spec"], O).tobytes())
+    for opts, run in ((["-s", "-e"], "6"), (["-S"], "1")):
+        out = subprocess.run([EXE, "-G", str(G), "-w", str(c["w"]), "-p", str(c["p"]), "--halo", "65536", "-c", "-v"] + opts + [str(f)],
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "BWTs match" in out.stdout
+        for ext in ["bwt"] + [{"-s": "ssa", "-e": "esa", "-S": "sa"}[o] for o in opts]:
+            assert _sha(np.fromfile(str(f) + "." + ext, dtype=np.uint8)) == c["runs"][run][ext + "_sha256"], ext
+
+
+@pytest.mark.gpu
+def test_c_driver_python_ranks(golden, O, tmp_path):
+    """PFP_MULTI_PYTHON=1: the same through N processes of dist_main.py under torch.distributed (gloo, one GPU)"""
+    import subprocess
+    from textgen import make_text
+    c = {x["name"]: x for x in golden}["gen_small"]
+    f = tmp_path / "t.fa"
+    f.write_bytes(make_text(c["spec"], O).tobytes())
+    env = dict(os.environ, PFP_MULTI_PYTHON="1", PFP_DIST_BACKEND="gloo", PFP_DIST_ONE_GPU="1")
+    out = subprocess.run([EXE, "-G", "2", "-w", str(c["w"]), "-p", str(c["p"]), "--halo", "65536", "--sum", "-c", "-v", "-s", "-e", str(f)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want = c["runs"]["6"]
+    assert "BWTs match" in out.stdout and want["bwt_sha256"] in out.stdout and "2 ranks (gloo)" in out.stdout
+    for ext in ("bwt", "ssa", "esa"):
+        assert _sha(np.fromfile(str(f) + "." + ext, dtype=np.uint8)) == want[ext + "_sha256"], ext
+
+
+@pytest.mark.gpu
 def test_c_driver_multi_gpu_fasta_and_failure(tmp_path):
-    """-f with -G: the ranks read byte ranges of the filtered sequences; a text the chain refuses (a byte <= 2) ends every
-    rank and the driver with an error instead of a hang or a partial file set"""
+    """-f with -G: the ranks read byte ranges of the filtered sequences; a text the chain refuses (a byte <= 2) or a halo that
+    does not reach the last phrase boundary ends every rank and the driver with an error instead of a hang or a partial file set"""
     import json
     import subprocess
     with open(os.path.join(ROOT, "tests", "golden", "golden_fasta.json")) as fh:
@@ -441,16 +493,49 @@ def test_c_driver_multi_gpu_fasta_and_failure(tmp_path):
     c = max(cases, key=lambda x: len(x["raw_hex"]))
     f = tmp_path / "in.fa"
     f.write_bytes(bytes.fromhex(c["raw_hex"]))
-    env = dict(os.environ, PFP_DIST_BACKEND="gloo", PFP_DIST_ONE_GPU="1")
+    env = dict(os.environ, PFP_MULTI_LOOPBACK="1")
     out = subprocess.run([EXE, "-f", "-G", "2", "-w", str(c["w"]), "-p", str(c["p"]), "-c", str(f)], capture_output=True, text=True, env=env,
                          timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "BWTs match" in out.stdout and not os.path.exists(str(f) + ".seq")
+    assert "BWTs match" in out.stdout
     assert _sha(np.fromfile(str(f) + ".bwt", dtype=np.uint8)) == c["bwt_sha256"]
     g = tmp_path / "bad.txt"
     g.write_bytes(b"ACGTTGCA" * 5000 + b"\x01" + b"ACGTTGCA" * 5000)
     out = subprocess.run([EXE, "-G", "2", str(g)], capture_output=True, text=True, env=env, timeout=600)
-    assert out.returncode == 1 and "exit code" in out.stdout, out.stdout + out.stderr
+    assert out.returncode == 1 and "local parse" in out.stdout, out.stdout + out.stderr
+    rng = np.random.default_rng(3)
+    h = tmp_path / "halo.txt"
+    h.write_bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=400000)].tobytes())
+    out = subprocess.run([EXE, "-G", "2", "--halo", "12", str(h)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 1 and "halo" in out.stdout, out.stdout + out.stderr
+    same = subprocess.run([EXE, "-G", "2", str(h)], capture_output=True, text=True, timeout=600)     # RCCL wants one rank per GPU
+    if torch.cuda.device_count() < 2:
+        assert same.returncode == 1 and "does not exist" in same.stdout, same.stdout + same.stderr
+
+
+@pytest.mark.gpu
+def test_multi_gpu_entry_point_from_python(golden, O, pkg, tmp_path, monkeypatch):
+    """pfp_bigbwt_files_multi called directly (ctypes): 8 rank threads on one device, every flag set"""
+    from textgen import make_text
+    import importlib
+    monkeypatch.setenv("PFP_MULTI_LOOPBACK", "1")
+    pfpmod = importlib.import_module("bigbwt_amd.pfp")
+    c = {x["name"]: x for x in golden}["gen_1e6x4"]
+    text = make_text(c["spec"], O)
+    for flags in (0, 1, 6):
+        base = str(tmp_path / ("m%d" % flags))
+        st = pfpmod.bigbwt_files_multi(text, base, [0] * 8, c["w"], c["p"], flags, halo=1 << 16)
+        assert st["ranks"] == 8 and st["n"] == len(text) and st["n_words"] > 0
+        want = c["runs"][str(flags)]
+        assert _sha(np.fromfile(base + ".bwt", dtype=np.uint8)) == want["bwt_sha256"]
+        if flags & 1:
+            assert _sha(np.fromfile(base + ".sa", dtype=np.uint8)) == want["sa_sha256"]
+        if flags & 2:
+            assert _sha(np.fromfile(base + ".ssa", dtype=np.uint8)) == want["ssa_sha256"]
+            assert _sha(np.fromfile(base + ".esa", dtype=np.uint8)) == want["esa_sha256"]
+    with pytest.raises(pkg.PfpError) as ei:
+        pfpmod.bigbwt_files_multi(text, str(tmp_path / "bad"), [0, 0], c["w"], c["p"], 3)
+    assert ei.value.code == -1
 
 
 @pytest.mark.gpu
