@@ -86,6 +86,36 @@ def test_benchmark_workloads_match_reference_digests(pkg, ctx, synth, golden_ful
         check(got, g)
 
 
+@pytest.mark.parametrize("name,ranks", [("c4s", 4), ("c5s", 3), ("c3", 2)])
+def test_benchmark_workloads_on_several_ranks(pkg, synth, golden_full, tmp_path, monkeypatch, name, ranks):
+    """pfp_bigbwt_files_multi (the host of `bigbwt -G N`): BASELINE configs[3] / configs[4] flag sets on their 0.2 GB stand-ins and
+    configs[2] at full size, split over rank threads that share this card (device copies in place of RCCL): the FILES against the
+    reference's digests"""
+    import importlib
+    if name not in golden_full:
+        pytest.skip("no reference digest committed for this workload")
+    monkeypatch.setenv("PFP_MULTI_LOOPBACK", "1")
+    pfpmod = importlib.import_module("bigbwt_amd.pfp")
+    g = golden_full[name]
+    text = synth.workload_text_np(name)
+    assert len(text) == g["n"]
+    base = "/dev/shm/pfp_multi_%s_%d" % (name, os.getpid())
+    try:
+        st = pfpmod.bigbwt_files_multi(text, base, [0] * ranks, g["w"], g["p"], g["flags"])
+        assert st["ranks"] == ranks and st["n"] == g["n"] and st["sa_shares"] == ranks
+        for key, ext, bit in (("bwt", ".bwt", 0), ("sa", ".sa", 1), ("ssa", ".ssa", 2), ("esa", ".esa", 4)):
+            if bit == 0 or g["flags"] & bit:
+                h = hashlib.sha256()
+                with open(base + ext, "rb") as fh:
+                    for blk in iter(lambda: fh.read(1 << 24), b""):
+                        h.update(blk)
+                assert os.path.getsize(base + ext) == g[key + "_bytes"] and h.hexdigest() == g[key + "_sha256"], (name, ext)
+    finally:
+        for ext in (".bwt", ".sa", ".ssa", ".esa"):
+            if os.path.exists(base + ext):
+                os.unlink(base + ext)
+
+
 def test_north_star_12_6_gb_with_sampled_sa(pkg, ctx, synth, golden_full):
     """The north star's workload on one GPU: 1024 mutated copies, 12.6 GB, -w 10 -p 100 -s.  The reference took 42
     minutes for it in the build container (tests/golden/make_golden_huge.py); its .bwt and .ssa digests against
