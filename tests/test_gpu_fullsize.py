@@ -116,6 +116,43 @@ def test_benchmark_workloads_on_several_ranks(pkg, synth, golden_full, tmp_path,
                 os.unlink(base + ext)
 
 
+def test_north_star_workload_on_8_ranks(pkg, ctx, synth, golden_full, monkeypatch):
+    """The 12.6 GB workload (-s) through the multi-GPU chain: 8 rank threads of pfp_bigbwt_files_multi sharing this card (device
+    copies in place of RCCL) - byte-range scan with halos, hash-partitioned dedup, the suffix array of the 1.7 GB union dictionary
+    in 8 key ranges, 8 output ranges written with pwrite.  The files against the digests of the reference's 42-minute run."""
+    import importlib
+    import torch
+    if "huge_s" not in golden_full:
+        pytest.skip("no reference digest committed for this workload")
+    g = golden_full["huge_s"]
+    dev = torch.device("cuda", 0)
+    free, _total = torch.cuda.mem_get_info(dev)
+    vfs = os.statvfs("/dev/shm")
+    if free < 230 * (1 << 30) or vfs.f_bavail * vfs.f_frsize < 16 * (1 << 30):
+        pytest.skip("needs about 230 GB of free device memory and 16 GB in /dev/shm")
+    ctx.pool_trim()
+    text = synth.workload_text_torch(dev, "huge_s").cpu().numpy()
+    torch.cuda.empty_cache()
+    assert len(text) == g["n"]
+    monkeypatch.setenv("PFP_MULTI_LOOPBACK", "1")
+    pfpmod = importlib.import_module("bigbwt_amd.pfp")
+    base = "/dev/shm/pfp_multi_huge_%d" % os.getpid()
+    try:
+        st = pfpmod.bigbwt_files_multi(text, base, [0] * 8, g["w"], g["p"], g["flags"])
+        del text
+        assert st["ranks"] == 8 and st["n"] == g["n"] and st["sa_shares"] == 8
+        for key, ext in (("bwt", ".bwt"), ("ssa", ".ssa")):
+            h = hashlib.sha256()
+            with open(base + ext, "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 26), b""):
+                    h.update(blk)
+            assert os.path.getsize(base + ext) == g[key + "_bytes"] and h.hexdigest() == g[key + "_sha256"], ext
+    finally:
+        for ext in (".bwt", ".ssa"):
+            if os.path.exists(base + ext):
+                os.unlink(base + ext)
+
+
 def test_north_star_12_6_gb_with_sampled_sa(pkg, ctx, synth, golden_full):
     """The north star's workload on one GPU: 1024 mutated copies, 12.6 GB, -w 10 -p 100 -s.  The reference took 42
     minutes for it in the build container (tests/golden/make_golden_huge.py); its .bwt and .ssa digests against
