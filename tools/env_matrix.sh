@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/env_matrix.sh [first [count]]  - the switches first .. first+count-1 of the list (default: all)
+# usage: tools/env_matrix.sh [first [count]]  - (13 variants x ~110 s: more than one 20-minute gpurun call, run it as "0 7" and "7 6") the switches first .. first+count-1 of the list (default: all)
 fail=0
 first=${1:-0}; count=${2:-1000}; idx=-1
 for e in "X=1" "PFP_NO_FINFLAG=1" "PFP_KEYBITS=63" "PFP_KEYBITS=23" "PFP_PIVOT_CAP=0" "PFP_PIVOT_CAP=16" "PFP_NO_SMALLSEG=1" "PFP_FORCE_IDX64=1" "PFP_POOL_DEBUG=1" "PFP_BIG_BUDGET=5000" "PFP_KEYSONLY=1" "PFP_NO_FINISHER=1" "PFP_PREC_DIRECT=1"; do
