@@ -248,6 +248,7 @@ struct pfp_ctx {
   static constexpr size_t kPinBytes = 32u << 20;
   void *pin[2] = {nullptr, nullptr};
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
+  uint64_t n_syncs = 0;           // host waits on the stream (PFP_TRACE_HOST prints the count when the context goes)
 };
 
 namespace pfp {
@@ -294,7 +295,7 @@ template <class T>
 inline void h2d(pfp_ctx *c, T *dst, const T *src, size_t count) {
   PFP_HIP(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
 }
-inline void sync(pfp_ctx *c) { PFP_HIP(hipStreamSynchronize(c->stream)); }
+inline void sync(pfp_ctx *c) { c->n_syncs++; PFP_HIP(hipStreamSynchronize(c->stream)); }
 
 // read one device scalar (syncs the stream)
 template <class T>

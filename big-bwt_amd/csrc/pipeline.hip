@@ -446,6 +446,7 @@ void pfp_ctx_destroy(pfp_ctx *c) {
   delete reinterpret_cast<K1Scratch *>(c->k1scratch);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->kt.destroy();
+  if (getenv("PFP_TRACE_HOST")) fprintf(stderr, "[pfp] host waits on the stream over the context's life: %llu\n", (unsigned long long)c->n_syncs);
   c->pool.print_peak();
   c->pool.destroy();
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);

@@ -1009,13 +1009,15 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     PFP_HIP(hipGetLastError());
     return true;
   };
-  auto seg_setup = [&](uint64_t mm, uint32_t &ng, uint32_t &maxlen) {      // segments = groups of the (grouped) active list
+  // (n_groups: the compaction that built the list counted its group heads - no read-back of the selection's count)
+  auto seg_setup = [&](uint64_t mm, uint64_t n_groups, uint32_t &ng, uint32_t &maxlen) {      // segments = groups of the (grouped) active list
     seg_bufs();
     if (!segb.p) { segb.alloc(c, list_cap + 1); sege.alloc(c, list_cap + 1); }
     hipLaunchKernelGGL(group_starts_kernel<I>, gdim(cdiv(mm, TB)), gdim(TB), 0, c->stream, mm, act_grp.p, gs.p);
     select_index<uint32_t>(c, gs.p, segb.p, nsel_d.p, mm);
     PFP_HIP(hipMemsetAsync(nseg_d.p + 1, 0, 4, c->stream));
-    ng = (uint32_t)read_scalar(c, nsel_d.p);
+    ng = (uint32_t)n_groups;
+    if (c->debug) PFP_REQUIRE(read_scalar(c, nsel_d.p) == n_groups, PFP_EHIP, "group count of the active list differs from the compaction's");
     hipLaunchKernelGGL(seg_end_kernel, gdim(cdiv(ng, TB)), gdim(TB), 0, c->stream, ng, (uint32_t)mm, segb.p, sege.p, nseg_d.p + 1);
     maxlen = read_scalar(c, nseg_d.p + 1);
   };
@@ -1200,7 +1202,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       auto try_seg = [&]() {
         if (use_segsort && m >= (1u << 20) && m < 0xFFFFFFFFull && m / ngrp >= seg_min_avg) {
           uint32_t maxlen = 0;
-          seg_setup(m, ng, maxlen);
+          seg_setup(m, ngrp, ng, maxlen);
           seg = maxlen <= (1u << 15) && m / ng >= seg_min_avg;
         }
       };
@@ -1252,7 +1254,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       if (seg_round) {
       } else if (use_segsort && m >= (1u << 20) && ngrp && m / ngrp >= 24) {
         uint32_t ng = 0, maxlen = 0;
-        seg_setup(m, ng, maxlen);
+        seg_setup(m, ngrp, ng, maxlen);
         if (maxlen <= (1u << 15) && m / ng >= 24) {
           { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
             hipLaunchKernelGGL(build_keys32_kernel, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
