@@ -397,9 +397,10 @@ __global__ void build_keys32_kernel(SufGeom g, uint64_t m, uint64_t h, const uin
 // not fit the window: the kernel then only raises *overflow and the caller sorts that round with the library.
 // Also writes the group-start flags gs[] the head detection of the round reads.
 // (Tried in round 3: the same kernel with a 2048-member window and 1024 positions per workgroup for the families of a
-//  1000-copy collection, in place of the library's segmented sort - 0.13 ns per element and round there, 126 GB/s.  Bit-exact,
-//  and 5x slower: 12.6 GB 58 -> 308 ms for these sorts.  Counting is quadratic in the group size and the count loop is a chain
-//  of dependent LDS reads with four waves per SIMD to hide them; a window that wide wants a real in-LDS sort, not counting.)
+//  1000-copy collection, in place of the library's segmented sort.  Bit-exact, and 5x slower: 12.6 GB 58 -> 308 ms for these
+//  sorts.  Counting is quadratic in the group size and the count loop is a chain of dependent LDS reads with four waves per
+//  SIMD to hide them.  A real sort of whole groups in LDS - block radix, bitonic - was tried too: no faster than the library's
+//  0.024 ns per element and round)
 constexpr uint32_t kSmallSeg = 64;
 template <class I>
 __global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const I *__restrict__ act_grp,
