@@ -1307,7 +1307,10 @@ static void dist_sort_global(pfp_ctx *c, DistState *ds, uint32_t part, uint32_t 
   const WordView wv = word_view(ds->G, ds->ix);
   const SlotPayloadSrc pay{wv, ds->G.wocc.p, ds->w};
   const SlotPayloadSrc *payp = (ds->flags & PFP_FLAG_SA) ? nullptr : &pay;      // full SA: the merge gathers wider records itself
-  ds->ord.wide = use_wide_index(c, ds->G.dsize);
+  // a share of a dictionary of 2^31 bytes or more takes the wide build: the 32-bit one has no spare bit for the settled flag
+  // there, so no pivot rounds - and a share cannot run doubling rounds instead (they read other shares' ranks).  The share is
+  // 1 / parts of the slots, so 8-byte indices are affordable where they would not be for the whole array.
+  ds->ord.wide = use_wide_index(c, ds->G.dsize) || (parts > 1 && ds->G.dsize >= (1ull << 31));
   // phrases per distinct word = text bytes per dictionary byte, near enough (the same on every rank: the keys-only
   // first round of the sorter is chosen from it)
   double rep_hint = 0;

@@ -937,7 +937,9 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   const int nb = bits_for(N);           // key of a later round = (group head << nb) | (1 + rank of the continuation)
   const int keybits = 2 * nb;
   static const bool no_finflag = getenv("PFP_NO_FINFLAG") != nullptr;      // tests: force the length-gather path
-  out.finbit = (g.mode == MODE_DICT && (kWide || N < (1ull << 31)) && !no_finflag) ? IdxTraits<I>::kTop : (I)0;
+  // (the flag rides in the top bit of a POSITION: it needs positions below 2^31 in the 32-bit build - all NP of them, also when
+  //  only a share of N < 2^31 suffixes is sorted here)
+  out.finbit = (g.mode == MODE_DICT && (kWide || NP < (1ull << 31)) && !no_finflag) ? IdxTraits<I>::kTop : (I)0;
   constexpr bool use_segsort = true;
   DBuf<uint8_t> gs;
   DBuf<uint32_t> k32, k32o, segb, sege, nseg_d;

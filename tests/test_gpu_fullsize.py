@@ -233,3 +233,23 @@ def test_dictionary_over_4gib_takes_the_wide_build():
     assert r["all_ok"] and r["index_bits"] == 64 and r["dict_over_4GiB"] and r["second_parse"]["index_bits"] == 64, r
     assert r["peak_device_bytes"] <= 215e9, r["peak_device_bytes"]          # round 2: 274 GB
     assert r["warm_pool"]["MBps"] >= 2000, r["warm_pool"]
+
+
+@pytest.mark.gpu
+def test_union_dictionary_between_2_and_4_gib_across_ranks():
+    """Multi-GPU chain, union dictionary of 2.4 GB (>= 2^31 bytes, < 2^32): the 32-bit build has no spare bit in a position for the
+    sorter's settled flag there and a share of the suffix array cannot fall back on doubling rounds, so the shares take the wide
+    build.  (Before round 3's fix the flag was granted by the share's size and positions >= 2^31 lost their top bit: "a dictionary
+    word was claimed by no share".)  Two virtual ranks x 100 copies at 3 % SNPs against the single-GPU chain on the concatenation."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    free, _total = torch.cuda.mem_get_info(torch.device("cuda", 0))
+    if free < 200 * (1 << 30):
+        pytest.skip("needs about 200 GB of free device memory")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_range31.py"), "2", "100"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["bwt_equal"] and j["complete"] and j["index_bits_multi"] == 64 and (1 << 31) <= j["union_dict_bytes"] < (1 << 32)
+
