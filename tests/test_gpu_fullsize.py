@@ -248,7 +248,8 @@ def test_union_dictionary_between_2_and_4_gib_across_ranks():
     free, _total = torch.cuda.mem_get_info(torch.device("cuda", 0))
     if free < 200 * (1 << 30):
         pytest.skip("needs about 200 GB of free device memory")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_range31.py"), "2", "100"], capture_output=True, text=True, timeout=900)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_range31.py"), "2", "100"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     j = json.loads(out.stdout.strip().splitlines()[-1])
     assert j["bwt_equal"] and j["complete"] and j["index_bits_multi"] == 64 and (1 << 31) <= j["union_dict_bytes"] < (1 << 32)
