@@ -1,0 +1,42 @@
+"""the 32-bit and the 64-bit index build on the same text must give the same BWT (GPU box).  python tools/check_width_agree.py [workload]"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+pkg = entry.load_package()
+synth = importlib.import_module("bigbwt_amd.synth")
+dev = torch.device("cuda", 0)
+name = sys.argv[1] if len(sys.argv) > 1 else "wide31"
+wl = synth.WORKLOADS[name]
+text = synth.workload_text_torch(dev, name)
+n = text.numel()
+out = {}
+for bits in (0, 64):
+    ctx = pkg.Context(0)
+    if bits:
+        ctx.set_index_bits(64)
+    bwt = torch.empty(n + 1 + 16, dtype=torch.uint8, device=dev)
+    t0 = time.perf_counter()
+    used = ctx.bigbwt_dev(text.data_ptr(), n, bwt.data_ptr(), None, wl["w"], wl["p"], 0)
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    for s in range(0, n + 1, 1 << 28):
+        h.update(bwt[s:min(s + (1 << 28), n + 1)].cpu().numpy().tobytes())
+    st = ctx.stats()
+    out[str(bits)] = dict(sha=h.hexdigest(), s=round(time.perf_counter() - t0, 3), index_bits=st["index_bits"], dict_bytes=st["dict_size"],
+                          peak=ctx.mem_stats()["peak"], used=used == n)
+    del bwt
+    ctx.close()
+    torch.cuda.empty_cache()
+ok = out["0"]["sha"] == out["64"]["sha"]
+print(json.dumps(dict(workload=name, n=n, agree=ok, runs=out)))
+sys.exit(0 if ok else 1)
