@@ -86,11 +86,11 @@ def test_benchmark_workloads_match_reference_digests(pkg, ctx, synth, golden_ful
         check(got, g)
 
 
-@pytest.mark.parametrize("name,ranks", [("c4s", 4), ("c5s", 3), ("c3", 2)])
+@pytest.mark.parametrize("name,ranks", [("c4s", 4), ("c5s", 3), ("c3", 2), ("c2", 3)])
 def test_benchmark_workloads_on_several_ranks(pkg, synth, golden_full, tmp_path, monkeypatch, name, ranks):
     """pfp_bigbwt_files_multi (the host of `bigbwt -G N`): BASELINE configs[3] / configs[4] flag sets on their 0.2 GB stand-ins and
-    configs[2] at full size, split over rank threads that share this card (device copies in place of RCCL): the FILES against the
-    reference's digests"""
+    configs[2] and configs[1] (non-repetitive, an 18 Mb run of N across a rank boundary) at full size, split over rank threads that
+    share this card (device copies in place of RCCL): the FILES against the reference's digests"""
     import importlib
     if name not in golden_full:
         pytest.skip("no reference digest committed for this workload")
