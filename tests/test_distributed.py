@@ -445,6 +445,25 @@ def test_c_driver_multi_gpu_mode(golden, O, tmp_path, name, G, opts, run):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opts,run", [(["-s", "-e"], "6"), (["-S"], "1")])
+def test_c_driver_multi_gpu_replicated_fallback(golden, O, tmp_path, opts, run):
+    """no pivot rounds (PFP_PIVOT_CAP=0: what a dictionary with long exact repeats comes to): no share of the suffix array can
+    finish alone, every rank sorts the whole dictionary and the output is split into equal slices - the native host's fallback"""
+    import subprocess
+    from textgen import make_text
+    c = {x["name"]: x for x in golden}["gen_small"]
+    f = tmp_path / "t.fa"
+    f.write_bytes(make_text(c["spec"], O).tobytes())
+    env = dict(os.environ, PFP_MULTI_LOOPBACK="1", PFP_PIVOT_CAP="0")
+    out = subprocess.run([EXE, "-G", "3", "-w", str(c["w"]), "-p", str(c["p"]), "--halo", "65536", "-c", "-v"] + opts + [str(f)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "BWTs match" in out.stdout and "in 1 share(s)" in out.stdout
+    for ext in ["bwt"] + [{"-s": "ssa", "-e": "esa", "-S": "sa"}[o] for o in opts]:
+        assert _sha(np.fromfile(str(f) + "." + ext, dtype=np.uint8)) == c["runs"][run][ext + "_sha256"], ext
+
+
+@pytest.mark.gpu
 def test_c_driver_multi_gpu_over_rccl(golden, O, tmp_path):
     """the same over RCCL, one rank per GPU; needs two GPUs, skips itself on a one-GPU box"""
     import subprocess
