@@ -1590,7 +1590,8 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   a.bwt = out.d_bwt - out_lo; a.out_sa = out.d_sa ? out.d_sa - out_lo : nullptr;
   DBuf<unsigned long long> hstats(c, 5);
   hstats.zero();
-  uint32_t big_cap = 1u << 20;
+  uint32_t big_cap = 1u << 20;      // queue of the groups of more than 1024 occurrences; redone larger if it overflows (PFP_BIG_CAP: tests)
+  { const char *e = getenv("PFP_BIG_CAP"); if (e && atoll(e) > 0) big_cap = (uint32_t)atoll(e); }
   DBuf<BigGroup> big(c, big_cap);
   // such a group emits > kHardSortMin positions
   const uint32_t mid_cap = (uint32_t)std::min<uint64_t>(n_out / (kHardSortMin + 1) + 64, 0x7FFFFFFFull);
