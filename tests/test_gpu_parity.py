@@ -247,6 +247,25 @@ def test_large_hard_groups_without_a_dominating_char(O, pkg, wctx, monkeypatch, 
             assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
 
 
+def test_trigger_dense_text_overflows_the_scan_buffer(O, pkg, wctx):
+    """a text of period 7 one of whose windows is a trigger: 300 K phrase ends in 2.1 MB where the fused scan kernel keeps room
+    for 4 n / p + 64 K of them - the pass reports the true count and is repeated with room for all (scan.hip: cap_hint); one word,
+    300 K occurrences, every group hard"""
+    unit = np.frombuffer(b"AAAGCTA", dtype=np.uint8)
+    assert len(O.scan(np.tile(unit, 60), 10, 100)) >= 50
+    text = np.tile(unit, 300000)
+    assert len(O.scan(text, 10, 100)) > 4 * len(text) // 100 + 65536
+    for flags, oflags in ((0, 0), (pkg.FLAG_SA, O.FLAG_SA), (pkg.FLAG_SSA | pkg.FLAG_ESA, O.FLAG_SSA | O.FLAG_ESA)):
+        got = wctx.bigbwt(text, 10, 100, flags)
+        want = O.bigbwt(text, 10, 100, oflags)
+        assert np.array_equal(got["bwt"], want["bwt"])
+        if flags & pkg.FLAG_SA:
+            assert np.array_equal(pkg.unpack5(got["sa"]), want["sa"])
+        if flags & pkg.FLAG_SSA:
+            assert np.array_equal(pkg.unpack5(got["ssa"]).reshape(-1, 2), want["ssa"])
+            assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
+
+
 def test_steady_state_calls_do_not_reach_the_driver(O, pkg):
     """the context's pool: a repeated call of the same size is served from cached blocks (no hipMalloc, no trim),
     and the device-format buffers handed out go back into the pool with pfp_dev_free"""
