@@ -277,6 +277,10 @@ void hash_word_list(pfp_ctx *c, const uint8_t *bytes, const uint64_t *wstart, co
 // Core of the dictionary build over any phrase geometry.  weight == nullptr: every phrase counts
 // once; otherwise occ of a distinct word is the sum of its copies' weights.  hbytes = total bytes
 // the phrases cover (for the kernel-trace byte accounting only).
+__global__ void mask_u64_kernel(uint64_t *v, uint64_t n, uint64_t mask) {
+  const uint64_t i = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (i < n) v[i] &= mask;
+}
 static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, uint64_t P, const uint32_t *weight,
                                   uint64_t hbytes, bool want_last, bool want_sai, uint64_t sai_base, Dictionary &D) {
   PFP_REQUIRE(P >= 1 && P <= 0xFFFFFFFEull, PFP_ELIMIT,
@@ -303,6 +307,14 @@ static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, u
                          nlong, hsum.p);
       hipLaunchKernelGGL(phrase_hash_long_finish_kernel, gdim(cdiv(nlong, 64)), gdim(64), 0, c->stream, g, long_list.p,
                          nlong, hsum.p, hash.p);
+    }
+    // test hook (PFP_TEST_HASH_BITS=n: the first attempt keeps only n bits of every hash; -n: every attempt): different phrases then
+    // share a hash, the byte verification below finds it and the pass is repeated with another seed / gives up after four
+    const char *tb_env = getenv("PFP_TEST_HASH_BITS");      // (per call: tests switch it)
+    const int test_bits = tb_env ? atoi(tb_env) : 0;
+    if (test_bits && (attempt == 0 || test_bits < 0)) {
+      const int b = test_bits < 0 ? -test_bits : test_bits;
+      hipLaunchKernelGGL(mask_u64_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, hash.p, P, b >= 64 ? ~0ull : ((1ull << b) - 1ull));
     }
     sort_pairs_u64_u32(c, hash.p, ks.p, iota.p, vs.p, P, 0, 64);
     { KScope kscope(c, "pfp::dedup_verify_kernel", 2 * n + 16 * P);

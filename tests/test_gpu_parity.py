@@ -247,6 +247,29 @@ def test_large_hard_groups_without_a_dominating_char(O, pkg, wctx, monkeypatch, 
             assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
 
 
+def test_hash_collisions_are_found_and_cured(O, pkg, monkeypatch):
+    """PFP_TEST_HASH_BITS=8: the first attempt of the phrase dedup keeps 8 bits of every hash, so different phrases collide; the byte
+    verification of every occurrence finds it (newscan.cpp:282 compares strings on every hit), the hash is reseeded and the result
+    is exact.  -8: every attempt collides and the call fails with PFP_ECOLLISION like the reference (newscan.cpp:282-286), not wrong."""
+    text = O.gen_fasta(200000, 4, 0.002, 77)
+    want = O.bigbwt(text, 10, 100, O.FLAG_SSA | O.FLAG_ESA)
+    monkeypatch.setenv("PFP_TEST_HASH_BITS", "8")
+    c = pkg.Context(0)
+    try:
+        got = c.bigbwt(text, 10, 100, pkg.FLAG_SSA | pkg.FLAG_ESA)
+        assert c.stats()["hash_reseeds"] >= 1
+        assert np.array_equal(got["bwt"], want["bwt"])
+        assert np.array_equal(pkg.unpack5(got["ssa"]).reshape(-1, 2), want["ssa"])
+        monkeypatch.setenv("PFP_TEST_HASH_BITS", "-8")
+        with pytest.raises(pkg.PfpError) as ei:
+            c.bigbwt(text, 10, 100, 0)
+        assert ei.value.code == -4          # PFP_ECOLLISION
+        monkeypatch.delenv("PFP_TEST_HASH_BITS")
+        assert np.array_equal(c.bigbwt(text, 10, 100, 0)["bwt"], want["bwt"])      # the context is usable afterwards
+    finally:
+        c.close()
+
+
 def test_trigger_dense_text_overflows_the_scan_buffer(O, pkg, wctx):
     """a text of period 7 one of whose windows is a trigger: 300 K phrase ends in 2.1 MB where the fused scan kernel keeps room
     for 4 n / p + 64 K of them - the pass reports the true count and is repeated with room for all (scan.hip: cap_hint); one word,
