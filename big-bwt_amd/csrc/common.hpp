@@ -78,6 +78,7 @@ struct pfp_pool {
   std::string corrupt;                             // first canary damage seen (debug mode)
   uint64_t debug_blocks = 0;
   size_t soft_limit = 0;                           // bytes held from the driver beyond which any cached block that fits is reused
+  size_t test_limit = 0;                           // PFP_TEST_POOL_LIMIT (read at pfp_ctx_create): requests beyond this many live bytes fail like a full device
   uint64_t driver_allocs = 0, trims = 0;           // hipMalloc calls; times a failed one made the pool give its cache back
   bool trace = false;                              // PFP_TRACE_POOL=1: remember what was live at the peak (printed by pfp_ctx_destroy)
   std::vector<Block> peak_blocks;
@@ -100,6 +101,7 @@ struct pfp_pool {
   }
   void *get(size_t bytes, hipError_t *err, const char *file = "", int line = 0) {
     *err = hipSuccess;
+    if (test_limit && live_bytes + bytes > test_limit) { *err = hipErrorOutOfMemory; return nullptr; }
     if (debug) return get_debug(bytes, err, file, line);
     size_t best = (size_t)-1, bi = (size_t)-1;
     for (size_t i = 0; i < free_list.size(); i++) {

@@ -417,6 +417,7 @@ int pfp_ctx_create(pfp_ctx **out, int device) {
     PFP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->pool.stream = c->stream;
     { const char *pd = getenv("PFP_POOL_DEBUG"); c->pool.debug = pd && pd[0] && pd[0] != '0'; }
+    { const char *tl = getenv("PFP_TEST_POOL_LIMIT"); if (tl) c->pool.test_limit = (size_t)strtoull(tl, nullptr, 10); }
     c->pool.trace = getenv("PFP_TRACE_POOL") != nullptr;
     { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->pool.soft_limit = tot / 10 * 7; else (void)hipGetLastError(); }
     PFP_HIP(hipHostMalloc((void **)&c->h_scalars, 16 * sizeof(uint64_t), hipHostMallocDefault));

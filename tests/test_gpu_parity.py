@@ -247,6 +247,29 @@ def test_large_hard_groups_without_a_dominating_char(O, pkg, wctx, monkeypatch, 
             assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
 
 
+def test_out_of_device_memory_is_an_error_not_a_leak(O, pkg, monkeypatch):
+    """PFP_TEST_POOL_LIMIT: the context's pool refuses requests beyond 32 .. 128 MB of live bytes, as a full device would.  A 12 MB text
+    fails with PFP_ENOMEM somewhere inside the chain - whichever stage it reaches, at several limits - nothing stays allocated,
+    and the same context then builds a small text's BWT bit-exact."""
+    big = O.gen_fasta(3000000, 4, 0.002, 5)
+    small = O.gen_fasta(40000, 3, 0.002, 6)
+    want = O.bigbwt(small, 10, 100, O.FLAG_SSA | O.FLAG_ESA)
+    for limit in (32, 48, 80, 128):
+        monkeypatch.setenv("PFP_TEST_POOL_LIMIT", str(limit << 20))
+        c = pkg.Context(0)
+        try:
+            for flags in (0, pkg.FLAG_SA, pkg.FLAG_SSA | pkg.FLAG_ESA):
+                with pytest.raises(pkg.PfpError) as ei:
+                    c.bigbwt(big, 10, 100, flags)
+                assert ei.value.code == -7, (limit, flags, str(ei.value))          # PFP_ENOMEM
+                assert c.mem_stats()["live"] == 0, (limit, flags)
+            got = c.bigbwt(small, 10, 100, pkg.FLAG_SSA | pkg.FLAG_ESA)
+            assert np.array_equal(got["bwt"], want["bwt"])
+            assert np.array_equal(pkg.unpack5(got["ssa"]).reshape(-1, 2), want["ssa"])
+        finally:
+            c.close()
+
+
 def test_hash_collisions_are_found_and_cured(O, pkg, monkeypatch):
     """PFP_TEST_HASH_BITS=8: the first attempt of the phrase dedup keeps 8 bits of every hash, so different phrases collide; the byte
     verification of every occurrence finds it (newscan.cpp:282 compares strings on every hit), the hash is reseeded and the result
