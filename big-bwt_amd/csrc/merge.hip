@@ -1590,14 +1590,16 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
   a.bwt = out.d_bwt - out_lo; a.out_sa = out.d_sa ? out.d_sa - out_lo : nullptr;
   DBuf<unsigned long long> hstats(c, 5);
   hstats.zero();
-  uint32_t big_cap = 1u << 20;      // queue of the groups of more than 1024 occurrences; redone larger if it overflows (PFP_BIG_CAP: tests)
+  // hard[] marks exactly the heads of the hard groups (group_flags_kernel): count, then compact them once
+  const uint64_t n_heads = count_flags(c, hard.p, N);
+  // queue of the groups of more than 1024 occurrences: each emits more than 1024 positions and is a hard group; redone larger
+  // if it overflows all the same (PFP_BIG_CAP: tests)
+  uint32_t big_cap = (uint32_t)std::min<uint64_t>({(uint64_t)1u << 20, n_heads + 1, n_out / 1024 + 1});
   { const char *e = getenv("PFP_BIG_CAP"); if (e && atoll(e) > 0) big_cap = (uint32_t)atoll(e); }
   DBuf<BigGroup> big(c, big_cap);
   // such a group emits > kHardSortMin positions
   const uint32_t mid_cap = (uint32_t)std::min<uint64_t>(n_out / (kHardSortMin + 1) + 64, 0x7FFFFFFFull);
   DBuf<BigGroup> mid(c, mid_cap);
-  // hard[] marks exactly the heads of the hard groups (group_flags_kernel): count, then compact them once
-  const uint64_t n_heads = count_flags(c, hard.p, N);
   DBuf<I> heads(c, n_heads + 1);
   DBuf<uint64_t> nheads(c, 2);
   select_index<I>(c, hard.p, heads.p, nheads.p, N);
