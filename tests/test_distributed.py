@@ -533,6 +533,33 @@ def test_c_driver_multi_gpu_fasta_and_failure(tmp_path):
 
 
 @pytest.mark.gpu
+def test_multi_gpu_out_of_memory_on_the_ranks_ends_the_call(golden, O, pkg, tmp_path, monkeypatch):
+    """PFP_TEST_POOL_LIMIT on every rank's pool: whichever library step runs out of memory first (a different one at every limit), all
+    rank threads leave together with PFP_ENOMEM - no hang, no partial file set taken for a result - and where the limit is large enough
+    the files are right"""
+    from textgen import make_text
+    import importlib
+    monkeypatch.setenv("PFP_MULTI_LOOPBACK", "1")
+    pfpmod = importlib.import_module("bigbwt_amd.pfp")
+    c = {x["name"]: x for x in golden}["gen_1e6x4"]
+    text = make_text(c["spec"], O)
+    seen = set()
+    for limit_mb in (1, 3, 6, 10, 16, 24, 40, 400):
+        monkeypatch.setenv("PFP_TEST_POOL_LIMIT", str(limit_mb << 20))
+        base = str(tmp_path / ("o%d" % limit_mb))
+        try:
+            pfpmod.bigbwt_files_multi(text, base, [0] * 3, c["w"], c["p"], 6, halo=1 << 16)
+            seen.add("ok")
+            want = c["runs"]["6"]
+            assert _sha(np.fromfile(base + ".bwt", dtype=np.uint8)) == want["bwt_sha256"]
+            assert _sha(np.fromfile(base + ".ssa", dtype=np.uint8)) == want["ssa_sha256"]
+        except pkg.PfpError as ex:
+            assert ex.code == -7, str(ex)
+            seen.add("enomem")
+    assert seen == {"ok", "enomem"}
+
+
+@pytest.mark.gpu
 def test_multi_gpu_entry_point_from_python(golden, O, pkg, tmp_path, monkeypatch):
     """pfp_bigbwt_files_multi called directly (ctypes): 8 rank threads on one device, every flag set"""
     from textgen import make_text
