@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void kr_flag_kernel(const uint8_t *__restrict_
 // 2-bit tag; value and tag travel in ONE 64-bit word, so relaxed device-scope atomics suffice - a release / acquire pair costs an
 // L2 write-back / invalidate per tile on this multi-L2 part: 14 ms instead of 0.4); then every lane writes its ends at their final places.  ends[] has room for `cap` entries: what lies beyond is
 // counted, not written (the caller repeats with the true size - a text whose windows trigger four times as often as 1 / p).
-constexpr unsigned long long kTagShift = 62, kTagAgg = 1ull << 62, kTagPre = 2ull << 62, kTagMask = 3ull << 62;
+constexpr unsigned long long kTagAgg = 1ull << 62, kTagPre = 2ull << 62, kTagMask = 3ull << 62;      // tag in the two top bits
 constexpr int kScanChunks = 16;                      // 4096-position chunks per tile: one look-back per 64 KB of text
 template <int W>
 __global__ __launch_bounds__(256) void kr_scan_kernel(const uint8_t *__restrict__ tbase, uint64_t n, KRParams kp, uint64_t ntiles,
