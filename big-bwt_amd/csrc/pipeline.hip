@@ -398,6 +398,11 @@ const char *pfp_strerror(int code) {
   }
 }
 
+int pfp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
 int pfp_ctx_create(pfp_ctx **out, int device) {
   if (!out) return PFP_EINVAL;
   *out = nullptr;

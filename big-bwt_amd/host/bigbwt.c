@@ -146,7 +146,7 @@ static void usage(const char *argv0) {
          "  --parsing        stop after the parsing phase (debug only)\n"
          "  --compress       compress output of the parsing phase (.parse.txz of .parse and .dicz)\n"
          "  -P, --probing    accepted for compatibility (deduplication here is exact)\n"
-         "  -G, --gpus N     one BWT on N GPUs of this node, devices --device .. --device + N - 1 (RCCL; not with -k / --parsing / --compress)\n"
+         "  -G, --gpus N     one BWT on N GPUs of this node, devices --device .. --device + N - 1 (0: all; RCCL; not with -k / --parsing / --compress)\n"
          "      --halo H     -G: bytes of each byte range its right neighbour also reads (def. 1048576; must cover a phrase)\n",
          argv0);
 }
@@ -191,6 +191,10 @@ int main(int argc, char **argv) {
   if (S && (s || e)) {   /* bigbwt:59-61 */
     printf("You can either compute the full SA or a sample of it, not both. Exiting...\n");
     return 0;
+  }
+  if (gpus == 0) {   /* -G 0: every GPU this process can see */
+    gpus = pfp_device_count() - device;
+    if (gpus < 1) { fprintf(stderr, "Cannot initialise the GPU (no device %d): this tool has no CPU path\n", device); return 1; }
   }
   if (gpus < 1 || (gpus > 1 && (keep || parsing || compress))) {
     printf("-G N needs N >= 1 and writes no temporary files: not with -k, --parsing or --compress. Exiting...\n");

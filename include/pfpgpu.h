@@ -42,6 +42,8 @@ extern "C" {
 
 typedef struct pfp_ctx pfp_ctx;
 
+/* number of HIP devices this process can see (0 without a GPU); `bigbwt -G 0` takes all of them */
+int pfp_device_count(void);
 int pfp_ctx_create(pfp_ctx **ctx, int device);
 void pfp_ctx_destroy(pfp_ctx *ctx);
 const char *pfp_last_error(const pfp_ctx *ctx);

@@ -530,6 +530,10 @@ def test_c_driver_multi_gpu_fasta_and_failure(tmp_path):
     same = subprocess.run([EXE, "-G", "2", str(h)], capture_output=True, text=True, timeout=600)     # RCCL wants one rank per GPU
     if torch.cuda.device_count() < 2:
         assert same.returncode == 1 and "does not exist" in same.stdout, same.stdout + same.stderr
+    allg = subprocess.run([EXE, "-G", "0", "-c", str(h)], capture_output=True, text=True, timeout=600)     # -G 0: every visible GPU
+    assert allg.returncode == 0 and "BWTs match" in allg.stdout, allg.stdout + allg.stderr
+    if torch.cuda.device_count() > 1:
+        assert "on %d GPUs" % torch.cuda.device_count() in allg.stdout
 
 
 @pytest.mark.gpu
