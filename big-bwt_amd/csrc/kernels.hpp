@@ -145,7 +145,9 @@ template <class I>
 void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const WordView &wv, uint64_t count, uint64_t *d_out);
 // plain suffix array of an integer string with unique smallest last symbol (sacak_int)
 // max_sym: largest symbol value (spare key bits then describe runs of equal symbols)
-void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym = 0xFFFFFFFFu);
+// occ (optional, n_sym entries): occ[x - 1] = occurrences of symbol x - lets the sorter pick its pivots (the parse of a collection)
+void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym = 0xFFFFFFFFu,
+                       const uint32_t *occ = nullptr, uint32_t n_sym = 0);
 // plain suffix array of a byte string with s[N-1]==0 unique smallest (sacak)
 template <class I> void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrderT<I> &out);
 

@@ -87,6 +87,15 @@ template void segsort_pairs_u32<uint32_t>(pfp_ctx *, const uint32_t *, uint32_t 
 template void segsort_pairs_u32<uint64_t>(pfp_ctx *, const uint32_t *, uint32_t *, const uint64_t *, uint64_t *, size_t, size_t,
                                           const uint32_t *, const uint32_t *, int, int);
 
+void segsort_pairs_u64_u32(pfp_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                           size_t nseg, const uint32_t *seg_begin, const uint32_t *seg_end, int bb, int eb) {
+  if (!n || !nseg) return;
+  PFP_REQUIRE(n < 0xFFFFFFFFull, PFP_ELIMIT, "segmented sort of 2^32 or more elements");
+  KScope ks(c, "rocprim::segmented_radix_sort_pairs<u64,u32>", n * (16 + 8) + nseg * 8);
+  PRIM2(rocprim::segmented_radix_sort_pairs(tmp, tb, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, seg_begin, seg_end,
+                                            (unsigned)bb, (unsigned)eb, c->stream));
+}
+
 void exclusive_sum_u32(pfp_ctx *c, const uint32_t *in, uint32_t *out, size_t n) {
   if (!n) return;
   KScope ks(c, "rocprim::scan<u32>", n * 8);

@@ -26,6 +26,9 @@ void sort_keys_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, size_t n, int begin_bit
 template <class V>
 void segsort_pairs_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, const V *vin, V *vout, size_t n,
                        size_t nseg, const uint32_t *seg_begin, const uint32_t *seg_end, int begin_bit, int end_bit);
+// the same with 64-bit keys and 32-bit values
+void segsort_pairs_u64_u32(pfp_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                           size_t nseg, const uint32_t *seg_begin, const uint32_t *seg_end, int begin_bit, int end_bit);
 // out[i] = sum_{j<i} in[j]
 void exclusive_sum_u32(pfp_ctx *c, const uint32_t *in, uint32_t *out, size_t n);
 void exclusive_sum_u32_u64(pfp_ctx *c, const uint32_t *in, uint64_t *out, size_t n);

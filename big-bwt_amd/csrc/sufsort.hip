@@ -30,6 +30,8 @@ enum : int { MODE_DICT = 0, MODE_PLAIN = 1 };
 struct SufGeom {
   int mode; uint64_t N; WordView wv;            // dictionary mode: where the word of a position ends
   const uint32_t *sym = nullptr;                // plain mode on an integer string (unique smallest last symbol): the string
+  const uint32_t *dist = nullptr;               // ... and, where the caller knows the symbols' frequencies (the parse), the distance from every
+                                                // position to the next RARE symbol at or after it: see the parse's pivot rounds below
 };
 // length of the suffix string starting at i, terminator included
 __device__ __forceinline__ uint64_t suf_len(const SufGeom &g, uint64_t i) {
@@ -485,6 +487,90 @@ __global__ void heads32_kernel(uint64_t m, const uint8_t *__restrict__ gs, const
   bool h = gs[a] || key[a] != key[a - 1];
   hd[a] = h ? 1 : 0;
   hv[a] = h ? aslot[a] : (I)0;
+}
+
+// ---- pivot rounds for the suffixes of the PARSE of a collection of near-identical sequences.
+// After the first round a group is one place of the genome in all its copies; two members agree until one of them meets a phrase
+// that only its own copy has (a variant word: a rare symbol).  Comparing every member with the group's FIRST member only halves
+// the group per round - that pivot has a variant of its own a few phrases on, and everybody who agrees with the consensus up to
+// there ties at that position (round 2 tried it: 13 rounds instead of doubling's 8).  The frequencies of the symbols tell which
+// member to compare with: the one whose next rare symbol is FARTHEST (dist[], one backward scan over the parse).  Every other
+// member then leaves the pivot at its own variant - a different (offset, symbol) for each - and one round places 99 % of a
+// group where doubling needs log2(offset) rounds (64 copies: 160 K unresolved -> 1.1 K after one round; first-member pivot: 81 K).
+// Order key, as for the dictionary's pivot rounds: smaller than the pivot: ascending offset, then symbol; the pivot's class; greater:
+// descending offset, then symbol - two 32-bit halves of a 64-bit key sorted inside every group.
+constexpr uint32_t kIntPivCap = 1024;      // symbols compared per member and round
+// smallest list such a round is tried on (PFP_PARSE_PIVOT_MIN: tests run it on small inputs; 0 = never)
+static uint64_t parse_pivot_min() {
+  const char *e = getenv("PFP_PARSE_PIVOT_MIN");
+  if (!e) return 1u << 16;
+  const uint64_t v = strtoull(e, nullptr, 10);
+  return v ? v : ~0ull;
+}
+template <class I>
+__global__ void ipivot_select_kernel(uint64_t m, uint64_t N, uint64_t h, const I *__restrict__ act_i, const I *__restrict__ act_grp,
+                                     const uint32_t *__restrict__ dist, unsigned long long *__restrict__ best) {
+  const uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  unsigned long long v = 0;
+  uint64_t g = ~0ull;
+  if (a < m) {
+    const uint64_t i = act_i[a];
+    g = act_grp[a];
+    const uint32_t dv = i + h < N ? dist[i + h] : 0u;
+    v = ((unsigned long long)dv << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)a);      // ties: the first member
+  }
+  // the members of a group are neighbours: maximum over the run of equal groups that ends at this lane, one atomic per run and wave
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long u = __shfl_up(v, o, 64);
+    const uint64_t ug = __shfl_up(g, o, 64);
+    if (lane >= o && ug == g && u > v) v = u;
+  }
+  const uint64_t gn = __shfl_down(g, 1, 64);
+  if (a < m && (lane == 63 || gn != g)) atomicMax(&best[g], v);
+}
+template <class I>
+__global__ void ipivot_keys_kernel(uint64_t m, uint64_t N, uint64_t h, uint32_t cap, const uint32_t *__restrict__ sym,
+                                   const I *__restrict__ act_i, const I *__restrict__ act_grp,
+                                   const unsigned long long *__restrict__ best, uint64_t *__restrict__ key, I *__restrict__ val) {
+  const uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  const uint64_t i = act_i[a];
+  const uint64_t piv = act_i[0xFFFFFFFFu - (uint32_t)(best[act_grp[a]] & 0xFFFFFFFFull)];
+  uint64_t k = (uint64_t)(cap + 1) << 32;      // the pivot itself, and whoever equals it for cap symbols
+  if (i != piv) {
+    for (uint32_t q = 0; q < cap; q++) {
+      const uint64_t pi = i + h + q, pp = piv + h + q;
+      const uint32_t x = pi < N ? sym[pi] : 0u, y = pp < N ? sym[pp] : 0u;
+      if (x != y) { k = ((uint64_t)(x < y ? q : 2 * cap + 2 - q) << 32) | x; break; }
+    }
+  }
+  key[a] = k;
+  val[a] = (I)i;
+}
+template <class I>
+__global__ void heads64seg_kernel(uint64_t m, const uint8_t *__restrict__ gs, const uint64_t *__restrict__ key,
+                                  const I *__restrict__ aslot, uint8_t *__restrict__ hd, I *__restrict__ hv) {
+  uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (a >= m) return;
+  bool h = gs[a] || key[a] != key[a - 1];
+  hd[a] = h ? 1 : 0;
+  hv[a] = h ? aslot[a] : (I)0;
+}
+// distance to the next rare symbol: marks over the reversed string (0 = common; else reversed index + 1), running maximum, difference
+__global__ void rare_marks_kernel(const uint32_t *__restrict__ s, uint32_t N, const uint32_t *__restrict__ occ, uint32_t n_sym,
+                                  uint32_t below, uint32_t *__restrict__ v) {
+  uint32_t j = BID * blockDim.x + threadIdx.x;      // reversed index
+  if (j >= N) return;
+  const uint32_t x = s[N - 1 - j];
+  const bool rare = x == 0 || x > n_sym || occ[x - 1] < below;
+  v[j] = rare ? j + 1 : 0u;
+}
+__global__ void rare_dist_kernel(uint32_t N, const uint32_t *__restrict__ pm, uint32_t *__restrict__ dist) {
+  uint32_t i = BID * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t j = N - 1 - i, mk = pm[j];
+  dist[i] = mk ? j + 1 - mk : 0xFFFFFFFFu;      // (the unique last symbol is rare: every position has one ahead)
 }
 
 // Compaction of the active list: kept suffixes and kept group heads counted per 256 list positions
@@ -949,6 +1035,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   bool pivot_round = false;     // the keys of this round are pivot order keys (build_keys_pivot_kernel)
   bool dbl_round = false;       // the keys of this round are doubling keys (type K)
   bool pivot_ok = true;
+  bool ipiv_round = false, ipiv_ok = true;      // parse: pivot rounds with the farthest-rare-symbol pivot (keys in keyo, sorted inside the groups)
   bool lazy_pending = false;    // dictionary mode: rank[] of the suffixes settled by the first round not scattered (yet)
   DBuf<uint8_t> veto, keep0;
   constexpr bool lazy_pivot_ranks = true;
@@ -1042,6 +1129,9 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
                            hd.p, tile_last.p, out.tab.p); }
       inclusive_max<I>(c, out.tab.p, out.tab.p, out.T);
       inclusive_max<I>(c, tile_last.p, tile_scan.p, cdiv64(m, 256));
+    } else if (ipiv_round) {
+      KScope ks(c, "pfp::heads_kernel", m * 18);
+      hipLaunchKernelGGL(heads64seg_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, gs.p, keyo.p, aslot.p, hd.p, hv.p);
     } else if (seg_round) {
       KScope ks(c, "pfp::heads_kernel", m * 14);
       hipLaunchKernelGGL(heads32_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, gs.p, k32o.p, aslot.p, hd.p, hv.p);
@@ -1151,6 +1241,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     // as the bytes such a round may read - every member the full window - stay below 256 per dictionary byte; the
     // variants of long phrases settle there (-p 200: 3.3 M suffixes went through nine doubling rounds instead).
     // After the widest window the rest is doubling's business.
+    if (ipiv_round && m2 * 4 > m) ipiv_ok = false;      // a parse pivot round that left more than a quarter: doubling from here
     if (pivot_round && m2 * 2 > m) {
       const uint32_t next_cap = std::min<uint32_t>(piv_cap * 4, kPivCapMax - 16);
       if (piv_cap < kPivCapMax - 16 && piv_cap >= 16 && m2 * (uint64_t)next_cap < N * 128) piv_cap = next_cap;
@@ -1189,7 +1280,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     // 7 x 24 B of a global 53-bit radix sort (big: 240 -> 126 ms of sorting).  rocPRIM's segmented
     // sort serialises a giant segment on one workgroup (the 300 k run of one symbol in a parse cost
     // 68 ms), and for tiny groups its bookkeeping eats the gain, so the choice is per round.
-    seg_round = false; dbl_round = false;
+    seg_round = false; dbl_round = false; ipiv_round = false;
     pivot_round = pivot_ok && g.mode == MODE_DICT && out.finbit && kPivotCap >= 16 && ngrp && m / ngrp <= kPivotAvg &&
                   (uint64_t)nb + kPivBits <= 64;
     if (pivot_round) {
@@ -1226,6 +1317,26 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       else { sort_pairs_db(c, key, keyo, val, valo, m, 0, nb + kPivBits); std::swap(key, keyo); std::swap(val, valo); }
       out.rounds++;
       continue;                 // the sorted prefix common to all groups is still h: no doubling of h
+    }
+    if constexpr (sizeof(I) == 4) {
+      // the parse of a collection: a pivot round with the member whose next rare symbol is farthest (see ipivot_select_kernel)
+      if (g.mode == MODE_PLAIN && g.dist && g.sym && ipiv_ok && ngrp && m >= parse_pivot_min() && m < 0xFFFFFFFFull && m / ngrp >= 4) {
+        uint32_t ng = 0, maxlen = 0;
+        seg_setup(m, ngrp, ng, maxlen);
+        if (maxlen <= (1u << 15)) {
+          DBuf<unsigned long long> best(c, N);
+          best.zero();
+          { KScope ks(c, "pfp::build_keys_pivot_kernel", m * (4 + 4 + 4 + 12 + 64));
+            hipLaunchKernelGGL(ipivot_select_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, NP, h, act_i.p, act_grp.p, g.dist, best.p);
+            hipLaunchKernelGGL(ipivot_keys_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, NP, h, kIntPivCap, g.sym, act_i.p,
+                               act_grp.p, best.p, key.p, val.p); }
+          segsort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, 32 + bits_for(2 * kIntPivCap + 3));
+          seg_round = true; ipiv_round = true;
+          out.rounds++;
+          continue;               // the sorted prefix common to all groups is still h
+        }
+        ipiv_ok = false;
+      }
     }
     if (range_mode) { out.complete = false; break; }     // doubling would read ranks of suffixes other ranks hold
     if (late_rank && !rank_alloc) {      // the first doubling round: rank[] is needed after all
@@ -1570,7 +1681,8 @@ void sort_byte_suffixes(pfp_ctx *c, const uint8_t *bytes, uint64_t N, SuffixOrde
 template void sort_byte_suffixes<uint32_t>(pfp_ctx *, const uint8_t *, uint64_t, SuffixOrderT<uint32_t> &);
 template void sort_byte_suffixes<uint64_t>(pfp_ctx *, const uint8_t *, uint64_t, SuffixOrderT<uint64_t> &);
 
-void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym) {
+void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym, const uint32_t *occ,
+                       uint32_t n_sym) {
   PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "parse too large for 32-bit suffix indices");
   SufGeom g{MODE_PLAIN, N, WordView{}};
   DBuf<uint64_t> key(c, N);
@@ -1583,6 +1695,17 @@ void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder 
   PFP_REQUIRE(real_max <= max_sym, PFP_EFORMAT, "integer string holds a symbol above its alphabet size");
   const int sb = bits_for(real_max);
   g.sym = sym;
+  // occ[x - 1] = occurrences of symbol x (the parse: the words' counts): rare = fewer than the mean; dist[] for the pivot rounds
+  DBuf<uint32_t> dist;
+  if (occ && n_sym && N >= parse_pivot_min()) {
+    DBuf<uint32_t> mk(c, N), pm(c, N);
+    dist.alloc(c, N);
+    const uint32_t below = (uint32_t)std::max<uint64_t>(2, N / n_sym);
+    hipLaunchKernelGGL(rare_marks_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, (uint32_t)N, occ, n_sym, below, mk.p);
+    inclusive_max_u32(c, mk.p, pm.p, N);
+    hipLaunchKernelGGL(rare_dist_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, (uint32_t)N, pm.p, dist.p);
+    g.dist = dist.p;
+  }
   if (64 - 2 * sb >= 6) {
     DBuf<uint32_t> v(c, N), pm(c, N);
     hipLaunchKernelGGL(run_marks_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, (uint32_t)N, v.p);
