@@ -404,20 +404,20 @@ __global__ void build_keys32_kernel(SufGeom g, uint64_t m, uint64_t h, const uin
 //  SIMD to hide them.  A real sort of whole groups in LDS - block radix, bitonic - was tried too: no faster than the library's
 //  0.024 ns per element and round)
 constexpr uint32_t kSmallSeg = 64;
-template <class I>
+template <class I, class KT>
 __global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const I *__restrict__ act_grp,
-                                                             const uint32_t *__restrict__ key, const I *__restrict__ val,
-                                                             uint8_t *__restrict__ gs, uint32_t *__restrict__ keyo,
+                                                             const KT *__restrict__ key, const I *__restrict__ val,
+                                                             uint8_t *__restrict__ gs, KT *__restrict__ keyo,
                                                              I *__restrict__ valo, uint32_t *__restrict__ overflow,
                                                              uint8_t *__restrict__ big) {
   constexpr int K = (int)kSmallSeg, W = 256 + 2 * K;
-  __shared__ uint32_t lkey[W];
+  __shared__ KT lkey[W];
   __shared__ I lgrp[W];
   const uint64_t B = (uint64_t)BID * 256;
   for (int idx = threadIdx.x; idx < W; idx += 256) {
     const uint64_t j = B + idx;                   // list position + K
     const bool ok = j >= (uint64_t)K && j - K < m;
-    lkey[idx] = ok ? key[j - K] : 0u;
+    lkey[idx] = ok ? key[j - K] : (KT)0;
     lgrp[idx] = ok ? act_grp[j - K] : IdxTraits<I>::kNone;      // outside the list: no group
   }
   __syncthreads();
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const I
   // a group of more than K members: with `big` its elements are passed through in place and flagged (the caller
   // sorts just those), without it the round is the library's.  Groups are contiguous, so two probes tell: the
   // position K back, and - once the start is known - the position K past it.
-  const uint32_t ka = lkey[la];
+  const KT ka = lkey[la];
   bool too_long = lgrp[la - K] == g;      // the group starts K or more positions back
   int ls = la;
   if (!too_long) {
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void seg_small_sort_kernel(uint64_t m, const I
   }
   uint32_t r = 0;
   for (int j = ls; j < ls + K && lgrp[j] == g; j++) {
-    const uint32_t kj = lkey[j];
+    const KT kj = lkey[j];
     r += (kj < ka || (kj == ka && j < la)) ? 1u : 0u;
   }
   if (big) big[a] = 0;
@@ -1087,7 +1087,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     const bool side = big_side && !kWide;
     if (side && (!bigf.p || bigf.n < mm + 16)) bigf.alloc(c, list_cap + 16);
     { KScope ks(c, "pfp::seg_small_sort_kernel", mm * (8 + 3 * sizeof(I) + 1));
-      hipLaunchKernelGGL(seg_small_sort_kernel<I>, gdim(cdiv(mm, TB)), gdim(TB), 0, c->stream, mm, act_grp.p, k32.p, val.p, gs.p, k32o.p,
+      hipLaunchKernelGGL((seg_small_sort_kernel<I, uint32_t>), gdim(cdiv(mm, TB)), gdim(TB), 0, c->stream, mm, act_grp.p, k32.p, val.p, gs.p, k32o.p,
                          valo.p, ovf_d.p, side ? bigf.p : (uint8_t *)nullptr); }
     if (read_scalar(c, ovf_d.p) == 0) return true;
     if (!side) return false;
@@ -1320,17 +1320,33 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     }
     if constexpr (sizeof(I) == 4) {
       // the parse of a collection: a pivot round with the member whose next rare symbol is farthest (see ipivot_select_kernel)
-      if (g.mode == MODE_PLAIN && g.dist && g.sym && ipiv_ok && ngrp && m >= parse_pivot_min() && m < 0xFFFFFFFFull && m / ngrp >= 4) {
-        uint32_t ng = 0, maxlen = 0;
-        seg_setup(m, ngrp, ng, maxlen);
-        if (maxlen <= (1u << 15)) {
+      if (g.mode == MODE_PLAIN && g.dist && g.sym && ipiv_ok && ngrp && m >= parse_pivot_min() && m < 0xFFFFFFFFull && m / ngrp >= 2) {
+        {
           DBuf<unsigned long long> best(c, N);
           best.zero();
-          { KScope ks(c, "pfp::build_keys_pivot_kernel", m * (4 + 4 + 4 + 12 + 64));
-            hipLaunchKernelGGL(ipivot_select_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, NP, h, act_i.p, act_grp.p, g.dist, best.p);
-            hipLaunchKernelGGL(ipivot_keys_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, NP, h, kIntPivCap, g.sym, act_i.p,
-                               act_grp.p, best.p, key.p, val.p); }
-          segsort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, 32 + bits_for(2 * kIntPivCap + 3));
+          KScope ks(c, "pfp::build_keys_pivot_kernel", m * (4 + 4 + 4 + 12 + 64));
+          hipLaunchKernelGGL(ipivot_select_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, NP, h, act_i.p, act_grp.p, g.dist, best.p);
+          hipLaunchKernelGGL(ipivot_keys_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, NP, h, kIntPivCap, g.sym, act_i.p,
+                             act_grp.p, best.p, key.p, val.p);
+        }
+        bool sorted = false;
+        if (m / ngrp <= kSmallSeg / 2) {      // small groups (pairs of copies with a common SNP): placed by counting in LDS
+          seg_bufs();
+          ovf_d.zero();
+          { KScope ks(c, "pfp::seg_small_sort_kernel", m * (16 + 3 * sizeof(I) + 1));
+            hipLaunchKernelGGL((seg_small_sort_kernel<I, uint64_t>), gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, act_grp.p, key.p, val.p, gs.p,
+                               keyo.p, valo.p, ovf_d.p, (uint8_t *)nullptr); }
+          sorted = read_scalar(c, ovf_d.p) == 0;
+        }
+        if (!sorted && m / ngrp >= 4) {
+          uint32_t ng = 0, maxlen = 0;
+          seg_setup(m, ngrp, ng, maxlen);
+          if (maxlen <= (1u << 15)) {
+            segsort_pairs_u64_u32(c, key.p, keyo.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, 32 + bits_for(2 * kIntPivCap + 3));
+            sorted = true;
+          }
+        }
+        if (sorted) {
           seg_round = true; ipiv_round = true;
           out.rounds++;
           continue;               // the sorted prefix common to all groups is still h
