@@ -145,6 +145,10 @@ template <class I>
 void gather_slots_range(pfp_ctx *c, const SuffixOrderT<I> &so, const WordView &wv, uint64_t count, uint64_t *d_out);
 // plain suffix array of an integer string with unique smallest last symbol (sacak_int)
 // max_sym: largest symbol value (spare key bits then describe runs of equal symbols)
+// one rank's share of the same suffix array (the suffixes whose first-round key lies in share `part` of `parts`): out.N slots from
+// out.slot_base on, out.complete = false where only a doubling round could go on
+void sort_int_suffixes_range(pfp_ctx *c, const uint32_t *sym, uint64_t N, uint32_t max_sym, const uint32_t *occ, uint32_t n_sym,
+                             uint32_t part, uint32_t parts, SuffixOrder &out);
 // occ (optional, n_sym entries): occ[x - 1] = occurrences of symbol x - lets the sorter pick its pivots (the parse of a collection)
 void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder &out, uint32_t max_sym = 0xFFFFFFFFu,
                        const uint32_t *occ = nullptr, uint32_t n_sym = 0);
@@ -177,8 +181,9 @@ struct ParseBWT {         // outputs of bwtparse.c in HBM
   uint64_t rounds = 0;
 };
 // parse symbols are 1-based lexicographic ranks; occ_lex[r] = occurrences of rank r
+// sa_given (optional): the suffix array of the parse + its end symbol, P + 1 entries, computed elsewhere
 void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t *last, const uint64_t *sai,
-               const uint32_t *occ_lex, uint64_t d, ParseBWT &out);
+               const uint32_t *occ_lex, uint64_t d, ParseBWT &out, const uint32_t *sa_given = nullptr);
 
 struct BwtOutputs {
   uint64_t n_out = 0;      // n+1

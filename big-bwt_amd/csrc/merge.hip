@@ -196,14 +196,19 @@ __global__ void parse_gather_kernel(uint64_t P, const uint32_t *__restrict__ sa,
 }
 
 void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t *last, const uint64_t *sai,
-               const uint32_t *occ_lex, uint64_t d, ParseBWT &out) {
+               const uint32_t *occ_lex, uint64_t d, ParseBWT &out, const uint32_t *sa_given) {
   PFP_REQUIRE(P >= 2, PFP_ESHORT, "parse has fewer than 2 phrases (bwtparse.c:244)");
   out.P = P;
   DBuf<uint32_t> sym(c, P + 1);
   PFP_HIP(hipMemcpyAsync(sym.p, parse_sym, P * 4, hipMemcpyDeviceToDevice, c->stream));
   PFP_HIP(hipMemsetAsync(sym.p + P, 0, 4, c->stream));
   SuffixOrder so;
-  sort_int_suffixes(c, sym.p, P + 1, so, d, occ_lex, (uint32_t)d);      // symbols are 1-based word ranks <= d; occ_lex[rank] = the word's count
+  if (sa_given) {      // multi-GPU chain: the ranks sorted a share each and gathered them (pfp_dist_parse_sort)
+    so.N = so.NP = P + 1;
+    so.sa.alloc(c, P + 1);
+    PFP_HIP(hipMemcpyAsync(so.sa.p, sa_given, (P + 1) * 4, hipMemcpyDeviceToDevice, c->stream));
+  } else
+    sort_int_suffixes(c, sym.p, P + 1, so, d, occ_lex, (uint32_t)d);      // symbols are 1-based word ranks <= d; occ_lex[rank] = the word's count
   if (c->debug) validate_int_sa(c, sym.p, so);
   out.rounds = so.rounds;
   out.ilist.alloc(c, P + 1);

@@ -1143,6 +1143,8 @@ struct DistState {
   Dictionary Own;               // distinct words of this rank's hash class (first-arrival order) with summed occ
   DBuf<uint32_t> gid_local;     // [L.d] global word id of local word j
   bool have_gid = false;
+  DBuf<uint32_t> parse_sa;      // [P + 1] the parse's suffix array gathered from the ranks' shares (pfp_dist_set_parse_sa), used by the next merge
+  uint64_t parse_sa_n = 0;
 };
 static DistState *dist_of(pfp_ctx *c) {
   if (!c->dist) c->dist = new DistState();
@@ -1538,6 +1540,41 @@ int pfp_dist_global(pfp_ctx *c, const void *d_union, uint64_t union_bytes, const
   return rc;
 }
 
+int pfp_dist_parse_sort(pfp_ctx *c, const void *d_sym, uint64_t P, uint32_t part, uint32_t parts, void *d_sa_out, uint64_t out_info[4]) {
+  if (!c || !c->dist || !d_sym || !d_sa_out || !out_info || parts < 1 || part >= parts) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  PFP_REQUIRE(ds->occ_lex.p && ds->G.d, PFP_EINVAL, "pfp_dist_global_finish has not run");
+  PFP_REQUIRE(P >= 2, PFP_ESHORT, "parse has fewer than 2 phrases (bwtparse.c:244)");
+  PhaseTimer t(c, &c->stats.ms_sa_parse);
+  DBuf<uint32_t> sym(c, P + 1);      // the parse and its end symbol (bwtparse.c:212-230)
+  PFP_HIP(hipMemcpyAsync(sym.p, d_sym, P * 4, hipMemcpyDeviceToDevice, c->stream));
+  PFP_HIP(hipMemsetAsync(sym.p + P, 0, 4, c->stream));
+  SuffixOrder so;
+  sort_int_suffixes_range(c, sym.p, P + 1, (uint32_t)ds->G.d, ds->occ_lex.p, (uint32_t)ds->G.d, part, parts, so);
+  if (so.complete && so.N) PFP_HIP(hipMemcpyAsync(d_sa_out, so.sa.p, so.N * 4, hipMemcpyDeviceToDevice, c->stream));
+  sync(c);
+  out_info[0] = so.N; out_info[1] = so.slot_base; out_info[2] = so.complete ? 1 : 0; out_info[3] = so.rounds;
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+int pfp_dist_set_parse_sa(pfp_ctx *c, const void *d_sa, uint64_t count) {
+  if (!c || !c->dist || (!d_sa && count)) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  DistState *ds = dist_of(c);
+  ds->parse_sa.release(); ds->parse_sa_n = 0;
+  if (!count) return PFP_OK;
+  ds->parse_sa.alloc(c, count);
+  PFP_HIP(hipMemcpyAsync(ds->parse_sa.p, d_sa, count * 4, hipMemcpyDeviceToDevice, c->stream));
+  sync(c);
+  ds->parse_sa_n = count;
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
 int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last, const void *d_sai, int flags,
                    uint64_t n_total, uint64_t out_lo, uint64_t out_hi, void *d_bwt_slice, void *d_sa_slice) {
   if (!c || !c->dist || !d_sym || !d_last || !d_bwt_slice || (flags && !d_sai) || ((flags & PFP_FLAG_SA) && !d_sa_slice)) return PFP_EINVAL;
@@ -1549,8 +1586,11 @@ int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last
   PFP_REQUIRE(out_lo <= out_hi && out_hi <= n_total + 1, PFP_EINVAL, "bad output slice");
   ParseBWT pb;
   { PhaseTimer t(c, &c->stats.ms_sa_parse);
+    PFP_REQUIRE(!ds->parse_sa_n || ds->parse_sa_n == P + 1, PFP_EINVAL, "the gathered suffix array of the parse has " +
+                std::to_string(ds->parse_sa_n) + " entries, the parse " + std::to_string(P) + " phrases");
     parse_bwt(c, (const uint32_t *)d_sym, P, (const uint8_t *)d_last, flags ? (const uint64_t *)d_sai : nullptr,
-              ds->occ_lex.p, ds->G.d, pb);
+              ds->occ_lex.p, ds->G.d, pb, ds->parse_sa_n ? ds->parse_sa.p : nullptr);
+    ds->parse_sa.release(); ds->parse_sa_n = 0;
     c->stats.sa_rounds_parse = pb.rounds; }
   if (c->debug) validate_parse_bwt(c, pb);
   ds->out = BwtOutputs();       // (-s / -e with d_sa_slice == NULL: what pfp_dist_sample_runs reads afterwards)

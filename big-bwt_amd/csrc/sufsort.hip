@@ -1320,7 +1320,8 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     }
     if constexpr (sizeof(I) == 4) {
       // the parse of a collection: a pivot round with the member whose next rare symbol is farthest (see ipivot_select_kernel)
-      if (g.mode == MODE_PLAIN && g.dist && g.sym && ipiv_ok && ngrp && m >= parse_pivot_min() && m < 0xFFFFFFFFull && m / ngrp >= 2) {
+      // (a share of the parse - range mode - has no doubling rounds to fall back on: it tries whatever the list's size)
+      if (g.mode == MODE_PLAIN && g.dist && g.sym && ipiv_ok && ngrp && (range_mode || m >= parse_pivot_min()) && m < 0xFFFFFFFFull && m / ngrp >= 2) {
         {
           DBuf<unsigned long long> best(c, N);
           best.zero();
@@ -1338,7 +1339,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
                                keyo.p, valo.p, ovf_d.p, (uint8_t *)nullptr); }
           sorted = read_scalar(c, ovf_d.p) == 0;
         }
-        if (!sorted && m / ngrp >= 4) {
+        if (!sorted && (m / ngrp >= 4 || range_mode)) {      // (a share has nothing else to fall back on)
           uint32_t ng = 0, maxlen = 0;
           seg_setup(m, ngrp, ng, maxlen);
           if (maxlen <= (1u << 15)) {
@@ -1732,6 +1733,110 @@ void sort_int_suffixes(pfp_ctx *c, const uint32_t *sym, uint64_t N, SuffixOrder 
     hipLaunchKernelGGL(init_keys_int_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, N, key.p, val.p);
   }
   doubling<uint32_t>(c, g, key, val, 2, out);
+}
+
+// ---- one rank's share of the parse's suffix array (multi-GPU chain).  The parse is replicated, its suffix array was too; with the
+// pivot round above a rank can sort the suffixes whose first-round key falls in its range without anybody's ranks, exactly as it
+// sorts its share of the dictionary: the same keys for all N positions (a streaming pass), splitters from a deterministic sample
+// (identical on every rank), the range's positions as a list, first sort + pivot round + comparison finisher on the list.
+// out.complete = false where a doubling round would be needed (the caller then sorts the whole parse as before).
+__global__ void sample_u64_kernel(const uint64_t *__restrict__ key, uint64_t stride, uint32_t ns, uint64_t *__restrict__ out, uint32_t *__restrict__ idx) {
+  uint32_t j = BID * blockDim.x + threadIdx.x;
+  if (j < ns) { out[j] = key[(uint64_t)j * stride]; idx[j] = j; }
+}
+__global__ __launch_bounds__(256) void range_flags_u64_kernel(const uint64_t *__restrict__ key, uint64_t N, uint64_t klo, uint64_t khi, int khi_open,
+                                                              uint8_t *__restrict__ flag, unsigned long long *__restrict__ tile_below) {
+  __shared__ unsigned long long ws[4];
+  const uint64_t i = (uint64_t)BID * 256 + threadIdx.x;
+  unsigned long long lt = 0;
+  if (i < N) {
+    const uint64_t k = key[i];
+    flag[i] = (k >= klo && (khi_open || k < khi)) ? 1 : 0;
+    lt = k < klo ? 1ull : 0ull;
+  }
+  for (int o = 32; o > 0; o >>= 1) lt += __shfl_down(lt, o, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = lt;
+  __syncthreads();
+  // (per-workgroup sums: an atomic per wave on one address serialises a million of them - 12 ms for 63 M keys)
+  if (threadIdx.x == 0 && (uint64_t)BID * 256 < N) tile_below[BID] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ void gather_list_keys_kernel(uint64_t n, const uint32_t *__restrict__ idx, const uint64_t *__restrict__ key,
+                                        uint64_t *__restrict__ lkey, uint32_t *__restrict__ lval) {
+  const uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (a < n) { const uint32_t i = idx[a]; lkey[a] = key[i]; lval[a] = i; }
+}
+void sort_int_suffixes_range(pfp_ctx *c, const uint32_t *sym, uint64_t N, uint32_t max_sym, const uint32_t *occ, uint32_t n_sym,
+                             uint32_t part, uint32_t parts, SuffixOrder &out) {
+  PFP_REQUIRE(N >= 1 && N < 0xFFFFFFF0ull, PFP_ELIMIT, "parse too large for 32-bit suffix indices");
+  PFP_REQUIRE(parts >= 1 && part < parts && occ && n_sym, PFP_EINVAL, "bad share of the parse's suffix array");
+  SufGeom g{MODE_PLAIN, N, WordView{}};
+  DBuf<uint32_t> mx(c, 1);
+  mx.zero();
+  hipLaunchKernelGGL(max_u32_kernel, gdim((int)std::min<uint64_t>(cdiv64(N, 256), 1024)), gdim(256), 0, c->stream, sym, N, mx.p);
+  const uint32_t real_max = read_scalar(c, mx.p);
+  PFP_REQUIRE(real_max <= max_sym, PFP_EFORMAT, "integer string holds a symbol above its alphabet size");
+  const int sb = bits_for(real_max);
+  g.sym = sym;
+  DBuf<uint32_t> dist(c, N);
+  {
+    KScope ks(c, "pfp::parse_share_dist", N * 24);
+    DBuf<uint32_t> mk(c, N), pm(c, N);
+    const uint32_t below = (uint32_t)std::max<uint64_t>(2, N / n_sym);
+    hipLaunchKernelGGL(rare_marks_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, (uint32_t)N, occ, n_sym, below, mk.p);
+    inclusive_max_u32(c, mk.p, pm.p, N);
+    hipLaunchKernelGGL(rare_dist_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, (uint32_t)N, pm.p, dist.p);
+    g.dist = dist.p;
+  }
+  DBuf<uint64_t> key(c, N);
+  {
+    KScope ks(c, "pfp::parse_share_keys", N * 28);
+    DBuf<uint32_t> val(c, N);
+    if (64 - 2 * sb >= 6) {
+      DBuf<uint32_t> v(c, N), pm(c, N);
+      hipLaunchKernelGGL(run_marks_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, (uint32_t)N, v.p);
+      inclusive_max_u32(c, v.p, pm.p, N);
+      hipLaunchKernelGGL(init_keys_int_run_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, (uint32_t)N, pm.p, sb, key.p, val.p);
+    } else {
+      hipLaunchKernelGGL(init_keys_int_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, N, key.p, val.p);
+    }
+  }
+  uint64_t klo = 0, khi = ~0ull;
+  if (parts > 1) {
+    const uint32_t ns = (uint32_t)std::min<uint64_t>(N, 1u << 16);
+    const uint64_t stride = N / ns;
+    DBuf<uint64_t> sk(c, ns), sko(c, ns);
+    DBuf<uint32_t> sv(c, ns), svo(c, ns);
+    hipLaunchKernelGGL(sample_u64_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, key.p, stride, ns, sk.p, sv.p);
+    sort_pairs_u64_u32(c, sk.p, sko.p, sv.p, svo.p, ns, 0, 64);
+    std::vector<uint64_t> hs(ns);
+    PFP_HIP(hipMemcpyAsync(hs.data(), sko.p, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    if (part > 0) klo = hs[(uint64_t)part * ns / parts];
+    if (part + 1 < parts) khi = hs[(uint64_t)(part + 1) * ns / parts];
+  }
+  const int khi_open = part + 1 == parts ? 1 : 0;
+  auto *ks_sel = new KScope(c, "pfp::parse_share_select", N * 10);
+  DBuf<uint8_t> flag(c, N + 16);
+  PFP_HIP(hipMemsetAsync(flag.p + N, 0, 16, c->stream));
+  const uint64_t nblk = cdiv64(N, 256);
+  DBuf<unsigned long long> below(c, 2), tb(c, nblk);
+  below.zero();
+  hipLaunchKernelGGL(range_flags_u64_kernel, gdim(nblk), gdim(256), 0, c->stream, key.p, N, klo, khi, khi_open, flag.p, tb.p);
+  hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, tb.p, tb.p, nblk, below.p);
+  const uint64_t n_mine = count_flags(c, flag.p, N);
+  DBuf<uint32_t> idx(c, std::max<uint64_t>(n_mine, 1));
+  DBuf<uint64_t> cnt_d(c, 1);
+  select_index<uint32_t>(c, flag.p, idx.p, cnt_d.p, N);
+  const uint64_t slot_base = read_scalar(c, (const uint64_t *)below.p);
+  flag.release();
+  DBuf<uint64_t> lkey(c, std::max<uint64_t>(n_mine, 1));
+  DBuf<uint32_t> lval(c, std::max<uint64_t>(n_mine, 1));
+  if (n_mine) hipLaunchKernelGGL(gather_list_keys_kernel, gdim(cdiv(n_mine, 256)), gdim(256), 0, c->stream, n_mine, idx.p, key.p, lkey.p, lval.p);
+  PFP_HIP(hipGetLastError());
+  key.release(); idx.release();
+  delete ks_sel;
+  doubling<uint32_t>(c, g, lkey, lval, 2, out, 64, false, n_mine, 0);
+  out.slot_base = slot_base; out.klo = klo; out.khi = khi_open ? ~0ull : khi;
 }
 
 }  // namespace pfp

@@ -128,7 +128,7 @@ class _Step:
 
 
 # ----------------------------------------------------------------------------- the algorithm
-def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True, dedup="alltoall"):
+def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True, dedup="alltoall", shard_parse=True):
     """Generator.  `shard`: 1-D uint8 device tensor, this rank's byte range of the text.
     Yields ('allgather', tensor) and receives the list of all ranks' tensors, or ('alltoall', [tensor per rank])
     and receives what every rank sent to this one.
@@ -282,6 +282,29 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
     if want_sai:
         sais = yield ("allgather", d_sai)
         sai_all = torch.cat(sais).contiguous()
+    # --- the suffix array of the parse in shares (key ranges, like the dictionary's): a rank sorts its range with the first sort,
+    #     a pivot round and the comparison finisher - no ranks of other ranges needed; if any range would need a doubling round,
+    #     nobody sets anything and every rank sorts the whole parse inside the merge as before
+    if size > 1 and shard_parse and sym_all.numel() >= 2:
+        P_all = sym_all.numel()
+        share = torch.empty(P_all + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        pinfo = step.run(lambda: ctx.dist_parse_sort(sym_all.data_ptr(), P_all, rank, size, share.data_ptr()))
+        okp = pinfo is not None and pinfo["complete"]
+        pst = yield ("allgather", torch.tensor([pinfo["entries"] if okp else 0, 1 if okp else 0, int(step.status()[0])], dtype=torch.int64, device=dev))
+        step.check([t[2:3] for t in pst], "parse suffix sort")
+        if all(int(t[1]) for t in pst) and sum(int(t[0]) for t in pst) == P_all + 1:
+            pieces = yield ("allgather", share[: pinfo["entries"]].contiguous())
+            sa_parse = torch.cat(pieces).contiguous()
+            torch.cuda.synchronize(dev)
+            step.run(lambda: ctx.dist_set_parse_sa(sa_parse.data_ptr(), sa_parse.numel()))
+            del pieces, sa_parse
+            parse_shares = size
+        else:
+            parse_shares = 1
+        del share
+    else:
+        parse_shares = 1
     n_out = n_total + 1
     if parts > 1:
         if sum(emits) != n_out:
@@ -345,7 +368,7 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
                 out[key + "_off"] = 10 * sum(int(t[j]) for t in ks[:rank])
         out["sampled_total"] = {key: sum(int(t[j]) for t in ks) for j, key in enumerate(("ssa", "esa")) if key in out}
     out["stats"] = dict(local=info, glob=ginfo, phrases_total=int(sym_all.numel()), shard_bytes=n_shard, extra_triggers=len(extra),
-                        sa_shares=parts, dedup=dedup)
+                        sa_shares=parts, parse_shares=parse_shares, dedup=dedup)
     return out
 
 
@@ -391,11 +414,11 @@ def write_outputs(ctx, path, res, group=None, create=None):
             ctx.pwrite_dev(path + ext, res[key + "_off"], res[key].data_ptr(), res[key].numel())
 
 
-def run(ctx, shard, w=10, p=100, flags=0, halo=DEFAULT_HALO, group=None, shard_sa=True, dedup="alltoall"):
+def run(ctx, shard, w=10, p=100, flags=0, halo=DEFAULT_HALO, group=None, shard_sa=True, dedup="alltoall", shard_parse=True):
     """Drive `phases` with torch.distributed (backend nccl == RCCL on ROCm; gloo works for CPU tests of the plumbing)."""
     import torch.distributed as dist
     rank, size = dist.get_rank(group), dist.get_world_size(group)
-    gen = phases(ctx, shard, rank, size, w, p, flags, halo, shard_sa, dedup)
+    gen = phases(ctx, shard, rank, size, w, p, flags, halo, shard_sa, dedup, shard_parse)
     reply = None
     import time
     log = []          # (kind, bytes this rank contributed, bytes it received, ms) per collective, in order
@@ -422,12 +445,12 @@ def run(ctx, shard, w=10, p=100, flags=0, halo=DEFAULT_HALO, group=None, shard_s
         return res
 
 
-def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True, dedup="alltoall", trim=False):
+def simulate(ctxs, shards, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True, dedup="alltoall", trim=False, shard_parse=True):
     """Run R virtual ranks in one process (ctxs[r], shards[r] may all live on one GPU): every
     collective is served by plain concatenation.  Used by the GPU tests to check the distributed
     chain bit for bit against the single-GPU chain."""
     size = len(shards)
-    gens = [phases(ctxs[r], shards[r], r, size, w, p, flags, halo, shard_sa, dedup) for r in range(size)]
+    gens = [phases(ctxs[r], shards[r], r, size, w, p, flags, halo, shard_sa, dedup, shard_parse) for r in range(size)]
     replies = [None] * size
     results = [None] * size
     live = set(range(size))

@@ -32,7 +32,7 @@ SYMBOLS = ["pfp_device_count", "pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_er
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_files", "pfp_bigbwt_dev", "pfp_bigbwt_formats_dev", "pfp_dev_free", "pfp_memcpy_d2h", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
            "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
            "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_partition_words", "pfp_dist_export_partition",
-           "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_sample_runs", "pfp_dist_release", "pfp_bigbwt_files_multi"]
+           "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_sample_runs", "pfp_dist_release", "pfp_bigbwt_files_multi", "pfp_dist_parse_sort", "pfp_dist_set_parse_sa"]
 
 
 class PfpError(RuntimeError):
@@ -466,6 +466,15 @@ class Context:
     def dist_global_finish(self, d_wslot_all, parts, my_word_base, d_sym_out):
         self._check(self.lib.pfp_dist_global_finish(self._h, C.c_void_p(d_wslot_all), C.c_uint32(parts), C.c_uint64(my_word_base),
                                                     C.c_void_p(d_sym_out)))
+
+    def dist_parse_sort(self, d_sym, P, part, parts, d_sa_out):
+        info = (C.c_uint64 * 4)()
+        self._check(self.lib.pfp_dist_parse_sort(self._h, C.c_void_p(d_sym), C.c_uint64(P), C.c_uint32(part), C.c_uint32(parts),
+                                                 C.c_void_p(d_sa_out), info))
+        return dict(entries=int(info[0]), slot_base=int(info[1]), complete=bool(info[2]), rounds=int(info[3]))
+
+    def dist_set_parse_sa(self, d_sa, count):
+        self._check(self.lib.pfp_dist_set_parse_sa(self._h, C.c_void_p(d_sa) if count else None, C.c_uint64(count)))
 
     def dist_merge(self, d_sym, P, d_last, d_sai, flags, n_total, out_lo, out_hi, d_bwt_slice, d_sa_slice=None):
         self._check(self.lib.pfp_dist_merge(self._h, C.c_void_p(d_sym), C.c_uint64(P), C.c_void_p(d_last),

@@ -310,6 +310,14 @@ int pfp_dist_export_owned(pfp_ctx *ctx, void *d_bytes, void *d_occ);
 int pfp_dist_global_sort_distinct(pfp_ctx *ctx, const void *d_dict, uint64_t dict_bytes, const void *d_occ, uint64_t n_words,
                                   const void *d_gid_sent, uint32_t part, uint32_t parts, void *d_wslot_out,
                                   uint64_t out_info[8]);
+/* The suffix array of the (replicated) parse in shares, like the dictionary's: pfp_dist_parse_sort sorts the suffixes of the whole
+ * parse d_sym (u32[P], all ranks') whose first-round key lies in share `part` of `parts` into d_sa_out (u32, room for P + 1) -
+ * out_info = {entries, first slot, complete, rounds}; complete = 0: only a doubling round could go on (then, or if any rank says so,
+ * nobody sets anything and pfp_dist_merge sorts the whole parse itself as bwtparse.c does).  The caller all-gathers the shares in
+ * rank order (they are consecutive ranges of the array) and hands the P + 1 entries to pfp_dist_set_parse_sa before
+ * pfp_dist_merge, which uses them once. */
+int pfp_dist_parse_sort(pfp_ctx *ctx, const void *d_sym, uint64_t P, uint32_t part, uint32_t parts, void *d_sa_out, uint64_t out_info[4]);
+int pfp_dist_set_parse_sa(pfp_ctx *ctx, const void *d_sa, uint64_t count);
 int pfp_dist_merge(pfp_ctx *ctx, const void *d_sym, uint64_t P, const void *d_last, const void *d_sai, int flags,
                    uint64_t n_total, uint64_t out_lo, uint64_t out_hi, void *d_bwt_slice, void *d_sa_slice);
 /* After pfp_dist_merge with PFP_FLAG_SSA / PFP_FLAG_ESA and d_sa_slice == NULL (the SA values then stay inside: 8 bytes

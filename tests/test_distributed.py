@@ -196,6 +196,33 @@ def test_distributed_chain_matches_oracle(O, pkg, R, shard_sa, nblock):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R", [2, 3, 8])
+def test_parse_suffix_array_in_shares(O, pkg, R):
+    """the replicated parse's suffix array sorted in R key ranges (pfp_dist_parse_sort: first sort, pivot round with the member whose
+    next rare symbol is farthest, comparison finisher - no ranks of other ranges) and all-gathered, against every rank sorting the whole
+    parse inside the merge: the same files, and the shares really are used on a collection of copies"""
+    import importlib
+    d = importlib.import_module("bigbwt_amd.dist")
+    text = O.gen_fasta(150000, 12, 0.002, 61)
+    n = len(text)
+    dev = torch.device("cuda:0")
+    want = O.bigbwt(text, 10, 100, O.FLAG_SSA | O.FLAG_ESA)
+    for shard_parse in (True, False):
+        ctxs = [pkg.Context(0) for _ in range(R)]
+        try:
+            shards = [torch.from_numpy(text[n * r // R: n * (r + 1) // R].copy()).to(dev) for r in range(R)]
+            res = d.simulate(ctxs, shards, 10, 100, pkg.FLAG_SSA | pkg.FLAG_ESA, halo=8192, shard_parse=shard_parse)
+            assert res[0]["stats"]["parse_shares"] == (R if shard_parse else 1)
+            bwt = np.concatenate([x["bwt"].cpu().numpy() for x in res])
+            assert np.array_equal(bwt, want["bwt"])
+            ssa = np.concatenate([x["ssa"].cpu().numpy() for x in res])
+            assert np.array_equal(pkg.unpack5(ssa).reshape(-1, 2), want["ssa"])
+        finally:
+            for c in ctxs:
+                c.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R", [4, 6])
 def test_many_ranks_on_a_tiny_dictionary(O, pkg, R):
     """a dictionary of ~120 suffixes split over 4-6 key ranges (shares of a few dozen slots, emit counts from 1 up)"""
