@@ -440,6 +440,28 @@ void run_rank(Shared &S, int rank, int device, const Job &J, RankResult &res) {
     Dev sai_all;
     if (want_sai) sai_all = C.allgatherv(d_sai.p, P_local * 8, pc);
     d_sym.release(); d_last.release(); d_sai.release();
+    // ---- the suffix array of the parse in key ranges, one per rank (first sort, pivot round, comparison finisher: no ranks of
+    //      other ranges); if any range would need a doubling round nobody sets anything and the merge sorts the whole parse itself
+    uint64_t parse_shares = 1;
+    if (size > 1 && P_total >= 2) {
+      Dev share;
+      uint64_t pinfo[4] = {0, 0, 0, 0};
+      st.run([&] {
+        share.alloc((P_total + 1) * 4 + 16);
+        return pfp_dist_parse_sort(ctx, sym_all.p, P_total, (uint32_t)rank, (uint32_t)size, share.p, pinfo);
+      });
+      std::vector<uint64_t> pst;
+      { uint64_t v[2] = {st.rc == PFP_OK && pinfo[2] ? pinfo[0] : 0ull, st.rc == PFP_OK && pinfo[2] ? 1ull : 0ull}; agree(C, st, "parse suffix sort", ctx, v, 2, &pst); }
+      bool all_ok = true;
+      uint64_t entries = 0;
+      for (int r = 0; r < size; r++) { if (!pst[(size_t)r * 3 + 2]) all_ok = false; entries += pst[(size_t)r * 3 + 1]; }
+      if (all_ok && entries == P_total + 1) {
+        std::vector<uint64_t> sc;
+        Dev sa_parse = C.allgatherv(share.p, pinfo[0] * 4, sc);
+        st.run([&] { return pfp_dist_set_parse_sa(ctx, sa_parse.p, P_total + 1); });
+        parse_shares = (uint64_t)size;
+      }
+    }
     const uint64_t n_out = n_total + 1;
     uint64_t lo = 0, hi = 0;
     if (parts > 1) {
@@ -528,7 +550,7 @@ void run_rank(Shared &S, int rank, int device, const Job &J, RankResult &res) {
     });
     agree(C, st, "writing the output files", ctx);
     res.st.n = n_total; res.st.n_words = d_words; res.st.n_phrases = P_total; res.st.dict_size = info[1];
-    res.st.index_bits = info[7]; res.st.sa_shares = parts; res.st.ranks = (uint64_t)size;
+    res.st.index_bits = info[7]; res.st.sa_shares = parts; res.st.parse_shares = parse_shares; res.st.ranks = (uint64_t)size;
     res.st.ms_chain = ms_chain;
     res.st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   } catch (const Failure &f) {

@@ -272,8 +272,8 @@ int main(int argc, char **argv) {
             (unsigned long long)ms.ranks, (unsigned long long)ms.n_words, (unsigned long long)ms.n_phrases,
             (unsigned long long)ms.dict_size, (unsigned long long)ms.index_bits);
     if (verbose)
-      printf("  %llu ranks: chain %.1f ms, with files %.1f ms; suffix array of the dictionary in %llu share(s)\n", (unsigned long long)ms.ranks,
-             ms.ms_chain, ms.ms_total, (unsigned long long)ms.sa_shares);
+      printf("  %llu ranks: chain %.1f ms, with files %.1f ms; suffix array of the dictionary in %llu share(s), of the parse in %llu\n",
+             (unsigned long long)ms.ranks, ms.ms_chain, ms.ms_total, (unsigned long long)ms.sa_shares, (unsigned long long)ms.parse_shares);
     printf("Elapsed time: %.4f\n", now_s() - start);
   }
 

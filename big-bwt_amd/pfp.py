@@ -510,7 +510,7 @@ def bigbwt_files_multi(text, base, devices, w=10, p=100, flags=0, halo=0):
     lib = load_library()
 
     class MultiStats(C.Structure):
-        _fields_ = [(k, C.c_uint64) for k in ("n", "n_words", "n_phrases", "dict_size", "index_bits", "ranks", "sa_shares")] + \
+        _fields_ = [(k, C.c_uint64) for k in ("n", "n_words", "n_phrases", "dict_size", "index_bits", "ranks", "sa_shares", "parse_shares")] + \
                    [("ms_chain", C.c_double), ("ms_total", C.c_double)]
     text = _arr(text, np.uint8)
     st = MultiStats()

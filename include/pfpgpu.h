@@ -343,6 +343,7 @@ void pfp_dist_release(pfp_ctx *ctx);
 typedef struct {
   uint64_t n, n_words, n_phrases, dict_size, index_bits;
   uint64_t ranks, sa_shares;      /* sa_shares = 1: a key range could not finish alone, every rank sorted the whole dictionary */
+  uint64_t parse_shares;          /* ranks when the parse's suffix array was sorted in key ranges too, 1 when every rank sorted all of it */
   double ms_chain, ms_total;      /* rank 0: upload to finished device outputs; + files */
 } pfp_multi_stats;
 int pfp_bigbwt_files_multi(int n_dev, const int *devices, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags,

@@ -103,6 +103,8 @@ def test_benchmark_workloads_on_several_ranks(pkg, synth, golden_full, tmp_path,
     try:
         st = pfpmod.bigbwt_files_multi(text, base, [0] * ranks, g["w"], g["p"], g["flags"])
         assert st["ranks"] == ranks and st["n"] == g["n"] and st["sa_shares"] == ranks
+        if name != "c2":          # (the copies of a collection: the parse's suffix array is sorted in shares too)
+            assert st["parse_shares"] == ranks
         for key, ext, bit in (("bwt", ".bwt", 0), ("sa", ".sa", 1), ("ssa", ".ssa", 2), ("esa", ".esa", 4)):
             if bit == 0 or g["flags"] & bit:
                 h = hashlib.sha256()
@@ -140,7 +142,7 @@ def test_north_star_workload_on_8_ranks(pkg, ctx, synth, golden_full, monkeypatc
     try:
         st = pfpmod.bigbwt_files_multi(text, base, [0] * 8, g["w"], g["p"], g["flags"])
         del text
-        assert st["ranks"] == 8 and st["n"] == g["n"] and st["sa_shares"] == 8
+        assert st["ranks"] == 8 and st["n"] == g["n"] and st["sa_shares"] == 8 and st["parse_shares"] == 8
         for key, ext in (("bwt", ".bwt"), ("ssa", ".ssa")):
             h = hashlib.sha256()
             with open(base + ext, "rb") as fh:
