@@ -1629,6 +1629,7 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   {
     const uint64_t nblk = cdiv64(N, kKeyPos);
     DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
+    KScope ks(c, "pfp::range_flags_kernel", N * 2);
     hipLaunchKernelGGL(range_flags_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, kc, klo, khi, khi_open,
                        count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
     hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, tb.p, te.p, nblk,
