@@ -1325,7 +1325,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
         {
           DBuf<unsigned long long> best(c, N);
           best.zero();
-          KScope ks(c, "pfp::build_keys_pivot_kernel", m * (4 + 4 + 4 + 12 + 64));
+          KScope ks(c, "pfp::ipivot_kernels", m * (4 + 4 + 4 + 8 + 16 + 12 + 64));
           hipLaunchKernelGGL(ipivot_select_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, NP, h, act_i.p, act_grp.p, g.dist, best.p);
           hipLaunchKernelGGL(ipivot_keys_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, NP, h, kIntPivCap, g.sym, act_i.p,
                              act_grp.p, best.p, key.p, val.p);
