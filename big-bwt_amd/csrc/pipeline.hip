@@ -1145,6 +1145,7 @@ struct DistState {
   bool have_gid = false;
   DBuf<uint32_t> parse_sa;      // [P + 1] the parse's suffix array gathered from the ranks' shares (pfp_dist_set_parse_sa), used by the next merge
   uint64_t parse_sa_n = 0;
+  uint64_t parse_share_rounds = 0;      // rounds of this rank's share sort (reported when the gathered array is used)
 };
 static DistState *dist_of(pfp_ctx *c) {
   if (!c->dist) c->dist = new DistState();
@@ -1556,6 +1557,7 @@ int pfp_dist_parse_sort(pfp_ctx *c, const void *d_sym, uint64_t P, uint32_t part
   if (so.complete && so.N) PFP_HIP(hipMemcpyAsync(d_sa_out, so.sa.p, so.N * 4, hipMemcpyDeviceToDevice, c->stream));
   sync(c);
   out_info[0] = so.N; out_info[1] = so.slot_base; out_info[2] = so.complete ? 1 : 0; out_info[3] = so.rounds;
+  ds->parse_share_rounds = so.rounds;
   return PFP_OK;
   PFP_CATCH(c)
 }
@@ -1590,8 +1592,8 @@ int pfp_dist_merge(pfp_ctx *c, const void *d_sym, uint64_t P, const void *d_last
                 std::to_string(ds->parse_sa_n) + " entries, the parse " + std::to_string(P) + " phrases");
     parse_bwt(c, (const uint32_t *)d_sym, P, (const uint8_t *)d_last, flags ? (const uint64_t *)d_sai : nullptr,
               ds->occ_lex.p, ds->G.d, pb, ds->parse_sa_n ? ds->parse_sa.p : nullptr);
-    ds->parse_sa.release(); ds->parse_sa_n = 0;
-    c->stats.sa_rounds_parse = pb.rounds; }
+    c->stats.sa_rounds_parse = ds->parse_sa_n ? ds->parse_share_rounds : pb.rounds;
+    ds->parse_sa.release(); ds->parse_sa_n = 0; }
   if (c->debug) validate_parse_bwt(c, pb);
   ds->out = BwtOutputs();       // (-s / -e with d_sa_slice == NULL: what pfp_dist_sample_runs reads afterwards)
   ds->out_lo = out_lo;
