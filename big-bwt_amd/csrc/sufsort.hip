@@ -19,6 +19,7 @@
 #include "devutil.hpp"
 #include <algorithm>
 #include <cmath>
+#include <optional>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -1816,7 +1817,8 @@ void sort_int_suffixes_range(pfp_ctx *c, const uint32_t *sym, uint64_t N, uint32
     if (part + 1 < parts) khi = hs[(uint64_t)(part + 1) * ns / parts];
   }
   const int khi_open = part + 1 == parts ? 1 : 0;
-  auto *ks_sel = new KScope(c, "pfp::parse_share_select", N * 10);
+  std::optional<KScope> ks_sel;      // (ended before the list is sorted)
+  ks_sel.emplace(c, "pfp::parse_share_select", N * 10);
   DBuf<uint8_t> flag(c, N + 16);
   PFP_HIP(hipMemsetAsync(flag.p + N, 0, 16, c->stream));
   const uint64_t nblk = cdiv64(N, 256);
@@ -1835,7 +1837,7 @@ void sort_int_suffixes_range(pfp_ctx *c, const uint32_t *sym, uint64_t N, uint32
   if (n_mine) hipLaunchKernelGGL(gather_list_keys_kernel, gdim(cdiv(n_mine, 256)), gdim(256), 0, c->stream, n_mine, idx.p, key.p, lkey.p, lval.p);
   PFP_HIP(hipGetLastError());
   key.release(); idx.release();
-  delete ks_sel;
+  ks_sel.reset();
   doubling<uint32_t>(c, g, lkey, lval, 2, out, 64, false, n_mine, 0);
   out.slot_base = slot_base; out.klo = klo; out.khi = khi_open ? ~0ull : khi;
 }
