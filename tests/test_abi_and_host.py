@@ -67,7 +67,7 @@ def test_c_driver_built_and_usage():
     exe = os.path.join(ROOT, "big-bwt_amd", "bigbwt")
     assert os.path.exists(exe)
     out = subprocess.run([exe, "-h"], capture_output=True, text=True)
-    assert out.returncode == 0 and "--parsing" in out.stdout and "-S" in out.stdout
+    assert out.returncode == 0 and "--parsing" in out.stdout and "-S" in out.stdout and "--gpus N" in out.stdout and "--halo" in out.stdout
     both = subprocess.run([exe, "-S", "-s", "/dev/null"], capture_output=True, text=True)
     assert "not both" in both.stdout       # bigbwt:59-61
 
@@ -110,3 +110,19 @@ def test_bench_starts_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_rank_script_splits_the_input_like_the_reference_threads():
+    """dist_main.py (the Python ranks of `bigbwt -G N` under PFP_MULTI_PYTHON=1): byte ranges [n r / N, n (r + 1) / N) - consecutive,
+    covering, never empty for n >= N (pscan.hpp:114-165 splits the input the same way)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pfp_dist_main", os.path.join(ROOT, "big-bwt_amd", "dist_main.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for n in (0, 1, 7, 1000, 12_596_936_618):
+        for size in (1, 2, 3, 8):
+            rs = [m.shard_range(n, r, size) for r in range(size)]
+            assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[k][1] == rs[k + 1][0] for k in range(size - 1))
+            if n >= size:
+                assert all(hi > lo for lo, hi in rs)
+
