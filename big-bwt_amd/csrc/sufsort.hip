@@ -1548,6 +1548,90 @@ __global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restr
     tile_emits[BID] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
   }
 }
+// The same selection without a key per position.  A share of the suffix array only has to be a contiguous range of the final
+// order, and "is this suffix below that one" is a string comparison: the suffix at i against the suffix at a boundary position,
+// 16 bytes at a time - decided at the first byte for three positions in four (DNA), never more than kRangeCmp bytes: a suffix that
+// equals the boundary's that far goes to the upper side whichever way it would end (the suffixes that share 64 bytes with the
+// boundary stand together in the order, so the cut just moves below them: still one cut, the same on both sides of it).
+// Identical strings of different words (both reach their terminator) are a tie: upper side, never split.
+// 8.7 -> ~2 ms for the 0.9 G positions of the 8-rank union dictionary (the key kernel codes every character of every position).
+constexpr int kRangeCmp = 64;
+__device__ __forceinline__ int cmp_suffix_boundary(const uint8_t *__restrict__ s, uint64_t i, uint64_t b) {
+  if (i == b) return 0;
+#pragma unroll 1
+  for (int q = 0; q < kRangeCmp / 16; q++) {
+    const uint4 xv = ld16u(s + i + 16 * q), yv = ld16u(s + b + 16 * q);
+    const uint32_t x[4] = {xv.x, xv.y, xv.z, xv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t diff = x[k] ^ y[k];
+      const uint32_t term = (x[k] - 0x02020202u) & ~x[k] & 0x80808080u;      // bytes < 2 of x (lowest flag exact)
+      if (diff | term) {
+        const int fd = diff ? (__builtin_ctz(diff) >> 3) : 4, ft = term ? (__builtin_ctz(term) >> 3) : 4;
+        if (ft < fd) return 0;                                    // both end before they differ: the same string
+        const uint32_t bx = (x[k] >> (8 * fd)) & 0xffu, by = (y[k] >> (8 * fd)) & 0xffu;
+        return bx < by ? -1 : 1;
+      }
+    }
+  }
+  return 0;      // equal for kRangeCmp bytes: upper side
+}
+// the first 16 bytes of both suffixes in registers (two 64-bit words each); the full compare only where they do not decide
+__device__ __forceinline__ int cmp_head16(const uint4 xv, const uint4 yv, const uint8_t *__restrict__ s, uint64_t i, uint64_t b) {
+  const uint64_t x[2] = {(uint64_t)xv.x | ((uint64_t)xv.y << 32), (uint64_t)xv.z | ((uint64_t)xv.w << 32)};
+  const uint64_t y[2] = {(uint64_t)yv.x | ((uint64_t)yv.y << 32), (uint64_t)yv.z | ((uint64_t)yv.w << 32)};
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint64_t diff = x[k] ^ y[k];
+    const uint64_t term = (x[k] - 0x0202020202020202ull) & ~x[k] & 0x8080808080808080ull;      // bytes < 2 of x (lowest flag exact)
+    if (diff | term) {
+      const int fd = diff ? (__builtin_ctzll(diff) >> 3) : 8, ft = term ? (__builtin_ctzll(term) >> 3) : 8;
+      if (ft < fd) return 0;
+      const uint32_t bx = (uint32_t)(x[k] >> (8 * fd)) & 0xffu, by = (uint32_t)(y[k] >> (8 * fd)) & 0xffu;
+      return bx < by ? -1 : 1;
+    }
+  }
+  return cmp_suffix_boundary(s, i, b);      // (16 equal bytes: rare)
+}
+__global__ __launch_bounds__(256) void range_flags_cmp_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t b_lo, int has_lo,
+                                                              uint64_t b_hi, int has_hi, SlotPayloadSrc count, int want_count,
+                                                              uint8_t *__restrict__ flag, unsigned long long *__restrict__ tile_below,
+                                                              unsigned long long *__restrict__ tile_emits) {
+  __shared__ unsigned long long wsum[2][4];
+  __shared__ uint32_t wt[4];
+  const uint64_t B0 = (uint64_t)BID * 256;
+  if (B0 >= N) return;      // a workgroup of the padded last grid row
+  const uint64_t i = B0 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+  const uint32_t ch = i < N ? (uint32_t)s[i] : 0xffu;
+  const unsigned long long tm = __ballot(ch == (uint32_t)kEndOfWord);
+  if (lane == 0) wt[wvi] = (uint32_t)__popcll(tm);
+  unsigned long long cnt = 0, emits = 0;
+  bool mine = false;
+  if (i < N) {
+    // one 16-byte load of the suffix's head against the two boundaries' heads (uniform: loaded once per wave); the full compare
+    // only where 16 bytes do not decide
+    const uint4 xv = ld16u(s + i);
+    const int cl = !has_lo ? 1 : cmp_head16(xv, ld16u(s + b_lo), s, i, b_lo);
+    cnt = cl < 0 ? 1ull : 0ull;
+    mine = cl >= 0 && (!has_hi || cmp_head16(xv, ld16u(s + b_hi), s, i, b_hi) < 0);
+    flag[i] = mine ? 1 : 0;
+  }
+  __syncthreads();
+  if (mine && want_count) {      // the position's word: the block's first (blocks start at multiples of 64) plus the terminators before it
+    uint32_t wd = count.wv.blk_word[B0 >> 6] + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
+    for (int q = 0; q < wvi; q++) wd += wt[q];
+    if (wd < count.wv.d && count.wv.wend[wd] - i > (uint64_t)count.w) emits = count.wocc[wd];
+  }
+  cnt = (unsigned long long)__popcll(__ballot(cnt != 0));      // (0 / 1 per lane: one ballot instead of a shuffle tree)
+  if (__ballot(emits != 0)) for (int o = 32; o > 0; o >>= 1) emits += __shfl_down(emits, o, 64);
+  if (lane == 0) { wsum[0][wvi] = cnt; wsum[1][wvi] = emits; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tile_below[BID] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+    tile_emits[BID] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+  }
+}
 __global__ __launch_bounds__(256) void sum2_u64_kernel(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b,
                                                        uint64_t n, unsigned long long *__restrict__ out) {
   __shared__ unsigned long long ws[2][4];
@@ -1608,8 +1692,12 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   SufGeom g{MODE_DICT, N, wv};
   KeyCode kc = dict_key_code(c, bytes, N, out.rep_hint);
   const int idx_bits = keysonly_bits<I>(N, out.rep_hint, kc);      // (before the splitters: every rank cuts the same keys)
-  // splitters: every stride-th suffix's key, sorted; the same on every rank
-  uint64_t klo = 0, khi = ~0ull;
+  // splitters: every stride-th suffix's key, sorted; the same on every rank.  The share is cut by comparing every suffix with the
+  // boundary SUFFIXES (range_flags_cmp_kernel) - boundaries with distinct keys, so that they stand in the order they are used in;
+  // PFP_RANGE_BY_KEY=1: by computing every position's key and comparing keys (the first form, kept for comparison)
+  static const bool by_key = getenv("PFP_RANGE_BY_KEY") != nullptr;
+  uint64_t klo = 0, khi = ~0ull, b_lo = 0, b_hi = 0;
+  bool has_lo = false, has_hi = false;
   if (parts > 1) {
     const uint32_t ns = (uint32_t)std::min<uint64_t>(N, 1u << 16);
     const uint64_t stride = N / ns;
@@ -1618,21 +1706,43 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
     hipLaunchKernelGGL(sample_keys_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, bytes, N, stride, ns, kc, sk.p, sv.p);
     sort_pairs_u64_u32(c, sk.p, sko.p, sv.p, svo.p, ns, 0, 64);
     std::vector<uint64_t> hs(ns);
+    std::vector<uint32_t> hv(ns);
     PFP_HIP(hipMemcpyAsync(hs.data(), sko.p, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(hipMemcpyAsync(hv.data(), svo.p, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
     sync(c);
     if (part > 0) klo = hs[(uint64_t)part * ns / parts];
     if (part + 1 < parts) khi = hs[(uint64_t)(part + 1) * ns / parts];
+    // boundary of part q (q >= 1): the sample at q ns / parts - or the boundary before it, if that sample's key is no larger
+    // (equal keys do not say which suffix is the smaller: such a part holds nothing)
+    auto boundary = [&](uint32_t q, uint64_t &pos) {
+      uint64_t prev_key = 0; bool have = false;
+      for (uint32_t t = 1; t <= q; t++) {
+        const uint64_t at = (uint64_t)t * ns / parts;
+        if (!have || hs[at] > prev_key) { pos = (uint64_t)hv[at] * stride; prev_key = hs[at]; have = true; }
+      }
+      return have;
+    };
+    if (part > 0) has_lo = boundary(part, b_lo);
+    if (part + 1 < parts) has_hi = boundary(part + 1, b_hi);
   }
   const int khi_open = part + 1 == parts ? 1 : 0;
   DBuf<uint8_t> flag(c, N);
   DBuf<unsigned long long> below(c, 2);
   below.zero();
-  {
+  if (by_key) {
     const uint64_t nblk = cdiv64(N, kKeyPos);
     DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
     KScope ks(c, "pfp::range_flags_kernel", N * 2);
     hipLaunchKernelGGL(range_flags_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, kc, klo, khi, khi_open,
                        count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
+    hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, tb.p, te.p, nblk,
+                       below.p);
+  } else {
+    const uint64_t nblk = cdiv64(N, 256);
+    DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
+    KScope ks(c, "pfp::range_flags_kernel", N * 2);
+    hipLaunchKernelGGL(range_flags_cmp_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, b_lo, has_lo ? 1 : 0, b_hi,
+                       has_hi ? 1 : 0, count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
     hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, tb.p, te.p, nblk,
                        below.p);
   }
