@@ -1632,6 +1632,88 @@ __global__ __launch_bounds__(256) void range_flags_cmp_kernel(const uint8_t *__r
     tile_emits[BID] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
   }
 }
+// the same with four consecutive positions per thread: their heads come out of five ALIGNED dwords (byte shifts) instead of four
+// unaligned 16-byte loads and four byte loads, the four flags leave as one dword - the one-position form is bound by its byte-wide
+// memory instructions, not by the compares.  1024 positions per workgroup.
+__device__ __forceinline__ int cmp_words16(uint64_t x0, uint64_t x1, uint64_t y0, uint64_t y1, const uint8_t *__restrict__ s, uint64_t i, uint64_t b) {
+  const uint64_t x[2] = {x0, x1}, y[2] = {y0, y1};
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint64_t diff = x[k] ^ y[k];
+    const uint64_t term = (x[k] - 0x0202020202020202ull) & ~x[k] & 0x8080808080808080ull;
+    if (diff | term) {
+      const int fd = diff ? (__builtin_ctzll(diff) >> 3) : 8, ft = term ? (__builtin_ctzll(term) >> 3) : 8;
+      if (ft < fd) return 0;
+      const uint32_t bx = (uint32_t)(x[k] >> (8 * fd)) & 0xffu, by = (uint32_t)(y[k] >> (8 * fd)) & 0xffu;
+      return bx < by ? -1 : 1;
+    }
+  }
+  return i == b ? 0 : cmp_suffix_boundary(s, i, b);
+}
+__global__ __launch_bounds__(256) void range_flags_cmp4_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t b_lo, int has_lo,
+                                                               uint64_t b_hi, int has_hi, SlotPayloadSrc count, int want_count,
+                                                               uint8_t *__restrict__ flag, unsigned long long *__restrict__ tile_below,
+                                                               unsigned long long *__restrict__ tile_emits) {
+  __shared__ unsigned long long wsum[2][4];
+  __shared__ uint32_t wt[4];
+  const uint64_t B0 = (uint64_t)BID * 1024;
+  if (B0 >= N) return;      // a workgroup of the padded last grid row
+  const uint64_t p0 = B0 + (uint64_t)threadIdx.x * 4;
+  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+  // bytes [p0, p0 + 20): the dictionary is padded with 64 zero bytes, so the loads of the last positions stay inside it
+  uint32_t d[5] = {0u, 0u, 0u, 0u, 0u};
+  if (p0 < N) {
+    const uint4 v = ld16u(s + p0);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    d[4] = *reinterpret_cast<const uint32_t *>(s + p0 + 16);
+  }
+  const uint4 lo4 = has_lo ? ld16u(s + b_lo) : make_uint4(0u, 0u, 0u, 0u), hi4 = has_hi ? ld16u(s + b_hi) : make_uint4(0u, 0u, 0u, 0u);
+  const uint64_t lo0 = (uint64_t)lo4.x | ((uint64_t)lo4.y << 32), lo1 = (uint64_t)lo4.z | ((uint64_t)lo4.w << 32);
+  const uint64_t hi0 = (uint64_t)hi4.x | ((uint64_t)hi4.y << 32), hi1 = (uint64_t)hi4.z | ((uint64_t)hi4.w << 32);
+  uint32_t tmask = 0, fl = 0, below = 0, minemask = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint64_t i = p0 + k;
+    if (i >= N) break;
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = k ? ((d[j] >> (8 * k)) | (d[j + 1] << (32 - 8 * k))) : d[j];
+    const uint64_t x0 = (uint64_t)w[0] | ((uint64_t)w[1] << 32), x1 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    if ((w[0] & 0xffu) == (uint32_t)kEndOfWord) tmask |= 1u << k;
+    const int cl = !has_lo ? 1 : cmp_words16(x0, x1, lo0, lo1, s, i, b_lo);
+    if (cl < 0) below++;
+    const bool mine = cl >= 0 && (!has_hi || cmp_words16(x0, x1, hi0, hi1, s, i, b_hi) < 0);
+    if (mine) { fl |= 1u << (8 * k); minemask |= 1u << k; }
+  }
+  if (p0 + 4 <= N) *reinterpret_cast<uint32_t *>(flag + p0) = fl;
+  else for (int k = 0; k < 4 && p0 + k < N; k++) flag[p0 + k] = (uint8_t)((fl >> (8 * k)) & 1u);
+  // terminators before this thread's positions in the block (only the emit count of the share's own positions wants them)
+  uint32_t tc = (uint32_t)__popc(tmask), inc = tc;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+  if (lane == 63) wt[wvi] = inc;
+  __syncthreads();
+  unsigned long long emits = 0;
+  if (minemask && want_count) {
+    uint32_t before = inc - tc;
+    for (int q = 0; q < wvi; q++) before += wt[q];
+    const uint32_t wbase = count.wv.blk_word[B0 >> 6] + before;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if ((minemask >> k) & 1u) {
+        const uint32_t wd = wbase + (uint32_t)__popc(tmask & ((1u << k) - 1u));
+        if (wd < count.wv.d && count.wv.wend[wd] - (p0 + k) > (uint64_t)count.w) emits += count.wocc[wd];
+      }
+  }
+  unsigned long long cnt = below;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  if (__ballot(emits != 0)) for (int o = 32; o > 0; o >>= 1) emits += __shfl_down(emits, o, 64);
+  if (lane == 0) { wsum[0][wvi] = cnt; wsum[1][wvi] = emits; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tile_below[BID] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+    tile_emits[BID] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+  }
+}
 __global__ __launch_bounds__(256) void sum2_u64_kernel(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b,
                                                        uint64_t n, unsigned long long *__restrict__ out) {
   __shared__ unsigned long long ws[2][4];
@@ -1738,11 +1820,16 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
     hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, tb.p, te.p, nblk,
                        below.p);
   } else {
-    const uint64_t nblk = cdiv64(N, 256);
+    static const bool one_per_thread = getenv("PFP_RANGE_CMP1") != nullptr;      // (the first form of the comparison kernel)
+    const uint64_t nblk = cdiv64(N, one_per_thread ? 256 : 1024);
     DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
     KScope ks(c, "pfp::range_flags_kernel", N * 2);
-    hipLaunchKernelGGL(range_flags_cmp_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, b_lo, has_lo ? 1 : 0, b_hi,
-                       has_hi ? 1 : 0, count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
+    if (one_per_thread)
+      hipLaunchKernelGGL(range_flags_cmp_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, b_lo, has_lo ? 1 : 0, b_hi,
+                         has_hi ? 1 : 0, count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
+    else
+      hipLaunchKernelGGL(range_flags_cmp4_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, b_lo, has_lo ? 1 : 0, b_hi,
+                         has_hi ? 1 : 0, count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
     hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, tb.p, te.p, nblk,
                        below.p);
   }
