@@ -141,7 +141,7 @@ def north_star_leg(pkg, synth, ctx, dev, steps=2):
             if key in outs and key + "_sha256" in gold:
                 digests[key] = hashlib.sha256(ctx.fetch_dev(*outs[key]).tobytes()).hexdigest() == gold[key + "_sha256"]
     R = {k: outs[k][1] // 10 for k in ("ssa", "esa") if k in outs}
-    t_formats = sum(kt.get(k, 0.0) for k in ("pfp::run_count_kernel", "pfp::run_place_kernel", "pfp::pack5_kernel"))
+    t_formats = sum(kt.get(k, 0.0) for k in ("pfp::run_count_kernel", "pfp::run_place_kernel", "pfp::bitmap_place_kernel", "pfp::pack5_kernel"))
     passes = pass_rows(st, w, flags, st["n"] + 1, st["n_phrases"], st["dict_size"], R, kt.get("pfp::phrase_hash_kernel", 0.0), t_formats, ms)
     mem = ctx.mem_stats()
     top = sorted(kt.items(), key=lambda x: -x[1])[:8]
@@ -351,7 +351,7 @@ def main():
                         launches_per_step=dom["launches_per_step"], algo_bytes_per_launch=dom["algo_bytes_per_launch"],
                         share_of_step=round(dom["ms_per_step"] / ms_per_step, 3))
         # HBM traffic of that kernel from the committed PMC passes of the same workload, per launch like `achieved`
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04",):          # (same round only: the kernels of earlier rounds are not this code)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{wl_name}_pmc_traffic.json")))
                 if world == 1 and dom["kernel"] in pmc["kernels"]:
@@ -372,7 +372,7 @@ def main():
             R = {k: (res[k].numel() // 10 if k in res and res[k] is not None else 0) for k in ("ssa", "esa")}
         ktime = {r["kernel"]: r["ms_per_step"] for r in rows}
         t_hash = ktime.get("pfp::phrase_hash_kernel", 0.0)
-        t_formats = sum(ktime.get(k, 0.0) for k in ("pfp::run_count_kernel", "pfp::run_place_kernel", "pfp::pack5_kernel"))
+        t_formats = sum(ktime.get(k, 0.0) for k in ("pfp::run_count_kernel", "pfp::run_place_kernel", "pfp::bitmap_place_kernel", "pfp::pack5_kernel"))
         passes = pass_rows(st, w, flags, n_slice, P_merge, D_, R, t_hash, t_formats, ms_per_step)
 
         scan_row = next((x for x in rows if x["kernel"] in ("pfp::kr_flag_kernel", "pfp::kr_scan_kernel")), None)

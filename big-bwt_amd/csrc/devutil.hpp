@@ -45,6 +45,18 @@ __device__ __forceinline__ uint32_t group8_or(uint32_t v) {
   return v;
 }
 
+// inclusive prefix sum over the 64 lanes of a wave with DPP moves only (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then
+// the two row broadcasts gfx9 keeps for exactly this): six v_add with a DPP operand instead of six ds_bpermute round trips
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // 16 flag bytes -> four words with bit 0 of every byte set where the flag is non-zero
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
   x |= x >> 4; x |= x >> 2; x |= x >> 1;

@@ -23,11 +23,13 @@ struct StagedText {
 struct KRParams {
   static constexpr uint32_t kMaxExtra = 32;
   uint32_t negpw, pinv, pshift, plimit;
+  uint32_t fast = 0, fseed = 0, fthr = 0;      // fused chain only (round 4): the cheap window hash of scan.hip instead of Karp-Rabin
   uint32_t nextra;            // extra trigger hashes (fused chain only), 0 in the reference-exact scan
   uint64_t bloom;             // bit (h & 63) set for every extra hash
   uint32_t extra[kMaxExtra];
 };
 KRParams make_kr_params(int w, uint64_t p);
+KRParams make_fast_params(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p);
 void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p, uint16_t *flags16,
                 uint32_t *block_counts, unsigned long long *first_bad, const KRParams *kp_override = nullptr);
 uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, DBuf<uint64_t> &d_ends,

@@ -53,7 +53,7 @@ void build_dict_index(pfp_ctx *c, const Dictionary &D, DictIndex &ix) {
   DBuf<uint32_t> cnt(c, nlines + 1);
   ix.blk_word.alloc(c, nlines + 1);
   ix.wend.alloc(c, D.d + 1);
-  KScope ks(c, "pfp::dict_index_fill_kernel", N + nlines * 12 + D.d * 20);
+  KScope ks(c, "pfp::line_terms_kernel", N + nlines * 12 + D.d * 20);
   hipLaunchKernelGGL(line_terms_kernel, gdim(cdiv(nlines + 1, TB)), gdim(TB), 0, c->stream, D.bytes.p, N, nlines, cnt.p);
   exclusive_sum_u32(c, cnt.p, ix.blk_word.p, nlines + 1);
   hipLaunchKernelGGL(word_ends_kernel, gdim(cdiv((uint64_t)D.d + 1, TB)), gdim(TB), 0, c->stream, (uint32_t)D.d, D.woff.p, D.wlen.p, N, ix.wend.p);
@@ -1546,7 +1546,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     if (!direct) {
       const uint64_t np256 = cdiv64(NP, 256) * 256;
       prec.alloc(c, np256);
-      KScope ks(c, "pfp::pprec_kernel", NP * (1 + 16) + (uint64_t)d * 40);
+      KScope ks(c, "pfp::pprec16_kernel", NP * (1 + 16) + (uint64_t)d * 40);
       hipLaunchKernelGGL(pprec16_kernel, gdim(cdiv(np256, TB)), gdim(TB), 0, c->stream, wv, w, reinterpret_cast<const uint4 *>(wrec.p),
                          dense ? 1 : 0, (uint64_t)0, NP, prec.p);
     }
@@ -1555,13 +1555,13 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
     sfirst.alloc(c, ntile << kOffTileLog);
     if (!dense) slast.alloc(c, ntile << kOffTileLog);
     if (samode != SA_NONE) ssl.alloc(c, ntile << kOffTileLog);
-    { KScope ks(c, "pfp::slot_gather_kernel", N * (2 * sizeof(I) + (direct ? 64 + 32 : 16) + 4 + 1 + 4 + (slast.p ? 4 : 0) + (ssl.p ? 4 : 0)));
+    { KScope ks(c, "pfp::slot_records_kernel", N * (2 * sizeof(I) + (direct ? 64 + 32 : 16) + 4 + 1 + 4 + (slast.p ? 4 : 0) + (ssl.p ? 4 : 0)));
       hipLaunchKernelGGL(slot_records_kernel<I>, gdim((unsigned)ntile), gdim(256), 0, c->stream, N, so.sa.p, so.grp.p,
                          direct ? (const PosRec *)nullptr : prec.p, loc.p, pc.p, sfirst.p, slast.p, ssl.p, tsum.p, ovf.p, tile_full.p,
                          first_full.p, hard.p, dense ? 1 : 0, wv, w, reinterpret_cast<const uint4 *>(wrec.p), dense ? 1 : 0); }
     prec.release();
   } else {
-    { KScope ks(c, "pfp::slot_gather_kernel", N * (8 + 1 + 5));
+    { KScope ks(c, "pfp::slot_payload_kernel", N * (8 + 1 + 5));
       hipLaunchKernelGGL(slot_payload_kernel<I>, gdim(cdiv(cdiv64(N, 8), 256)), gdim(256), 0, c->stream, N, so.sa.p, so.skeys.p,
                          so.refined.p, D.bytes.p, wv, D.wocc.p, d, w, cnt.p, pc.p, tile_full.p, first_full.p); }
     { KScope ks(c, "pfp::slot_loc_kernel", N * 8);
@@ -1950,7 +1950,7 @@ uint64_t sample_runs_dev(pfp_ctx *c, const uint8_t *bwt, const SaView &sa, uint6
     const uint64_t pairs = run_end ? sa.n_ends : sa.n_starts;
     out10.alloc(c, pairs * 10 + 16);
     if (sa.n_words) {
-      KScope ks(c, "pfp::run_place_kernel", sa.n_words * 24 + pairs * 18);
+      KScope ks(c, "pfp::bitmap_place_kernel", sa.n_words * 24 + pairs * 18);
       hipLaunchKernelGGL(bitmap_place_kernel, gdim(cdiv(sa.n_words, 256)), gdim(256), 0, c->stream, map, run_end ? sa.epre : sa.spre, sa.bmap,
                          sa.bpre, sa.sa_c, sa.n_words, out10.p, (uint64_t)0, 0, ~0ull);
       PFP_HIP(hipGetLastError());
@@ -1969,7 +1969,7 @@ uint64_t sample_runs_maps(pfp_ctx *c, const SaView &sa, uint64_t slice_n, bool r
   const uint64_t all = run_end ? sa.n_ends : sa.n_starts;
   const uint64_t pairs = all - ((drop_edge && all) ? 1 : 0);
   if (!out10 || !pairs || !sa.n_words) return pairs;
-  KScope ks(c, "pfp::run_place_kernel", sa.n_words * 24 + pairs * 18);
+  KScope ks(c, "pfp::bitmap_place_kernel", sa.n_words * 24 + pairs * 18);
   hipLaunchKernelGGL(bitmap_place_kernel, gdim(cdiv(sa.n_words, 256)), gdim(256), 0, c->stream, map, run_end ? sa.epre : sa.spre, sa.bmap,
                      sa.bpre, sa.sa_c, sa.n_words, out10, pos_base, (drop_edge && !run_end) ? 1 : 0,
                      (drop_edge && run_end && slice_n) ? slice_n - 1 : ~0ull);

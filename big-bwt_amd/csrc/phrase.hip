@@ -430,7 +430,7 @@ void reorder_dictionary_by_occ(pfp_ctx *c, Dictionary &D, DBuf<uint32_t> &perm) 
   const int TB = 256;
   perm.alloc(c, std::max<uint32_t>(d, 1));
   if (d < 2) { if (d) perm.zero(); return; }
-  KScope ks(c, "pfp::dict_reorder_kernels", 2 * D.dsize + 40ull * d);
+  KScope ks(c, "pfp::occ_order_apply_kernel", 2 * D.dsize + 40ull * d);
   DBuf<uint32_t> key(c, d), keyo(c, d), val(c, d), order(c, d), nlen(c, d), len1(c, (size_t)d + 1), nocc(c, d), long_list(c, d), cnt(c, 1);
   DBuf<uint64_t> wsrc(c, d), nwoff(c, (size_t)d + 1);
   hipLaunchKernelGGL(occ_sort_keys_kernel, gdim(cdiv(d, TB)), gdim(TB), 0, c->stream, d, D.wocc.p, key.p, val.p);

@@ -199,7 +199,9 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
   {
     PhaseTimer t(c, &st.ms_scan);
     uint32_t n_extra = 0;
-    if (exact_reference_parse || !c->max_phrase) ch.n_ends = scan_text(c, ch.tx, n, w, p, ch.ends, &ch.n_used);
+    // the staged entry points parse exactly as the reference does (newscan.cpp:168-202, 363-377); the fused chain cuts by
+    // its own window hash (pfp_set_window_hash) and splits giant phrases with extra triggers (pfp_set_max_phrase)
+    if (exact_reference_parse || (!c->max_phrase && !c->fast_triggers)) ch.n_ends = scan_text(c, ch.tx, n, w, p, ch.ends, &ch.n_used);
     else ch.n_ends = scan_text_adaptive(c, ch.tx, n, w, p, c->max_phrase, ch.ends, &ch.n_used, &n_extra);
     st.extra_triggers = n_extra;
     if (c->debug) validate_scan(c, ch.ends, ch.n_ends, ch.n_used, w);
@@ -429,6 +431,7 @@ int pfp_ctx_create(pfp_ctx **out, int device) {
     const char *dbg = getenv("PFP_DEBUG");
     c->debug = dbg && dbg[0] && dbg[0] != '0';
     { const char *fw = getenv("PFP_FORCE_IDX64"); c->force_wide = fw && fw[0] && fw[0] != '0'; }
+    { const char *wh = getenv("PFP_WINDOW_HASH"); if (wh && !strcmp(wh, "kr")) c->fast_triggers = false; }
     (void)hipGetLastError();
   } catch (const pfp::Error &e) {
     (void)hipGetLastError();
@@ -514,6 +517,7 @@ int pfp_get_kernel_trace(pfp_ctx *c, pfp_kernel_stat *out, int cap) {
   return k;
 }
 void pfp_set_max_phrase(pfp_ctx *c, uint64_t max_phrase) { if (c) c->max_phrase = max_phrase; }
+void pfp_set_window_hash(pfp_ctx *c, int fast) { if (c) c->fast_triggers = fast != 0; }
 int pfp_set_index_bits(pfp_ctx *c, int bits) {
   if (!c || (bits != 0 && bits != 64)) return PFP_EINVAL;
   c->force_wide = bits == 64;

@@ -194,7 +194,7 @@ static void select_bytes(pfp_ctx *c, const uint8_t *flags, int eq, I *out, uint6
   DBuf<uint32_t> bsum(c, nblk + 1);
   DBuf<uint64_t> boff(c, nblk + 1);
   PFP_HIP(hipMemsetAsync(bsum.p + nblk, 0, 4, c->stream));
-  KScope ks(c, "pfp::select_flags_kernel", n * 2);
+  KScope ks(c, "pfp::flag_place_kernel", n * 2);      // (+ flag_count_kernel and the scan of the tile counts)
   hipLaunchKernelGGL(flag_count_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, flags, (uint64_t)n, eq, bsum.p);
   exclusive_sum_u32_u64(c, bsum.p, boff.p, nblk + 1);
   hipLaunchKernelGGL(flag_place_kernel<I>, gdim((unsigned)nblk), gdim(256), 0, c->stream, flags, (uint64_t)n, eq, boff.p, out);

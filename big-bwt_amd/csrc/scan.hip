@@ -15,6 +15,7 @@
 // kernel B turns the masks into the dense, ordered ends[] array (wave-shuffle prefix sums).
 #include "kernels.hpp"
 #include "prims.hpp"
+#include "devutil.hpp"
 
 namespace pfp {
 
@@ -59,6 +60,43 @@ __device__ __forceinline__ bool kr_divides(uint32_t h, const KRParams &kp) {
   return t;
 }
 
+// ---- the fused chain's own trigger (round 4).  The outputs of the chain do not depend on the parse, so
+// pfp_bigbwt* is free to cut the text where ANY function of the last w bytes says so; the staged entry points (pfp_scan,
+// pfp_parse, -k: the reference's files) keep Karp-Rabin above.  The exact `mod 1999999973, then mod p` costs ~20 vector
+// instructions per text byte and bounds the scan pass at 0.2 of the HBM roofline; this one costs a third of that:
+//     h(window) = sum_i c_i * m_i          m_i: fixed odd byte multipliers; evaluated as ceil(w / 4) v_dot4_u32_u8 on the unaligned
+//                                          dwords of the window, which neighbouring positions share (one v_alignbyte per position)
+//     trigger  <=>  (h + seed) * K mod 2^32  <  floor(2^32 / p)          (multiplicative hashing of the small integer h: density 1 / p)
+// seed: the first value for which the text's FIRST window takes the decision the reference's hash takes for it (the reference
+// writes 0x02 where the end-of-string byte belongs exactly when its first window triggers, SURVEY.md 2.2-Q1: reproduced), and
+// for which no run of one DNA letter is cut into (w + 1)-byte crumbs.
+__host__ __device__ constexpr uint32_t kFastMul(int i) {
+  constexpr uint8_t m[20] = {0xB5, 0x6B, 0xD3, 0x97, 0xE9, 0x4F, 0xC7, 0x8D, 0xF1, 0x59, 0xA3, 0x3D, 0xDF, 0x75, 0xBB, 0x67, 0xCD, 0x9B, 0xE5, 0x53};
+  return m[i];
+}
+constexpr uint32_t kFastK = 0x9E3779B1u;      // 2^32 / golden ratio, odd
+// multipliers of dword q of a window of W bytes: dword 0 holds the newest four bytes (byte 3 = the window's last), bytes that lie
+// before the window get 0
+__host__ __device__ constexpr uint32_t fast_mvec(int W, int q) {
+  uint32_t m = 0;
+  for (int k = 0; k < 4; k++) { const int i = W - 4 - 4 * q + k; if (i >= 0) m |= kFastMul(i) << (8 * k); }
+  return m;
+}
+// host / slow-path evaluation of the same hash: win = the w bytes of a window, oldest first
+__host__ __device__ inline uint32_t fast_hash_bytes(const uint8_t *win, int w) {
+  uint32_t h = 0;
+  for (int i = 0; i < w; i++) h += (uint32_t)win[i] * kFastMul(i);
+  return h;
+}
+// (everything on the device works with the SEEDED value hs = h + seed: the seed is the dot products' initial accumulator, and
+//  the extra trigger hashes of a fast-mode KRParams are seeded values too)
+__device__ __forceinline__ bool fast_extra(uint32_t hs, const KRParams &kp) {
+  bool t = false;
+  if ((kp.bloom >> (hs & 63)) & 1ull)
+    for (uint32_t q = 0; q < kp.nextra; q++) t |= (hs == kp.extra[q]);
+  return t;
+}
+
 __device__ __forceinline__ uint32_t byte_of(const uint32_t (&r)[8], int k) {
   return (r[k >> 2] >> (8 * (k & 3))) & 0xffu;
 }
@@ -67,22 +105,51 @@ __device__ __forceinline__ uint32_t byte_of(const uint32_t (&r)[8], int k) {
 __device__ __forceinline__ uint32_t bad_bytes(uint32_t x) {
   return (x - 0x03030303u) & ~x & 0x80808080u;
 }
+// ... in any of four words (the mask applied once)
+__device__ __forceinline__ uint32_t bad_bytes4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  return (((a - 0x03030303u) & ~a) | ((b - 0x03030303u) & ~b) | ((c - 0x03030303u) & ~c) | ((d - 0x03030303u) & ~d)) & 0x80808080u;
+}
 
 // trigger mask of the 16 positions pos0 .. pos0 + 15 (bit j: position pos0 + j ends a phrase); reports the first byte <= 2
-template <int W>
+// interior (uniform): all 16 positions are known to be valid window ends inside the text (no clipping masks to compute)
+template <int W, bool FAST = false>
 __device__ __forceinline__ uint32_t kr_mask16(const uint8_t *__restrict__ tbase, uint64_t pos0, uint64_t n, const KRParams &kp,
-                                              unsigned long long *__restrict__ first_bad) {
+                                              unsigned long long *__restrict__ first_bad, bool interior = false) {
   static_assert(W >= 2 && W <= 17, "register path needs w-1 <= 16");
   const uint4 pv = *reinterpret_cast<const uint4 *>(tbase + pos0 - 16);
   const uint4 cv = *reinterpret_cast<const uint4 *>(tbase + pos0);
   const uint32_t r[8] = {pv.x, pv.y, pv.z, pv.w, cv.x, cv.y, cv.z, cv.w};
   // bytes <= 2 stop the parse (newscan.cpp:364): report the first one
-  uint32_t bad = bad_bytes(cv.x) | bad_bytes(cv.y) | bad_bytes(cv.z) | bad_bytes(cv.w);
+  uint32_t bad = bad_bytes4(cv.x, cv.y, cv.z, cv.w);
   if (bad) {
 #pragma unroll
     for (int k = 0; k < 16; k++)
       if (byte_of(r, 16 + k) <= 2 && pos0 + k < n) { atomicMin(first_bad, (unsigned long long)(pos0 + k)); break; }
   }
+  uint32_t mask = 0;
+  if constexpr (FAST) {
+    // dv[e] = the four bytes that END at byte e of r[] (bytes before r[] read as 0: their multipliers are 0)
+    uint32_t dv[32];
+#pragma unroll
+    for (int e = 0; e < 32; e++) {
+      const int hi = e >> 2, sh = (e & 3) + 1;
+      dv[e] = sh == 4 ? r[hi] : __builtin_amdgcn_alignbyte(r[hi], hi ? r[hi - 1] : 0u, sh);
+    }
+    constexpr int nq = (W + 3) / 4;
+    uint32_t hs[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      uint32_t h = kp.fseed;
+#pragma unroll
+      for (int q = 0; q < nq; q++) h = __builtin_amdgcn_udot4(dv[16 + j - 4 * q], fast_mvec(W, q), h, false);
+      hs[j] = h;
+      mask |= (h * kFastK < kp.fthr ? 1u : 0u) << j;
+    }
+    if (kp.bloom) {      // (uniform: a text whose giant phrases were split by extra triggers)
+#pragma unroll
+      for (int j = 0; j < 16; j++) mask |= (fast_extra(hs[j], kp) ? 1u : 0u) << j;
+    }
+  } else {
   // first window: bytes [16-(W-1) .. 16], Horner 3 bytes per step
   uint32_t h = 0;
   constexpr int first = 16 - (W - 1);
@@ -95,7 +162,7 @@ __device__ __forceinline__ uint32_t kr_mask16(const uint8_t *__restrict__ tbase,
   }
   if (W % 3 == 1) { h = kr_reduce<8>(((uint64_t)h << 8) | byte_of(r, k)); }
   if (W % 3 == 2) { h = kr_reduce<15>(((uint64_t)h << 16) | (byte_of(r, k) << 8) | byte_of(r, k + 1)); }
-  uint32_t mask = kr_divides(h, kp) ? 1u : 0u;
+  mask = kr_divides(h, kp) ? 1u : 0u;
 #pragma unroll
   for (int j = 1; j < 16; j++) {
     const uint32_t cin = byte_of(r, 16 + j), cout = byte_of(r, 16 + j - W);
@@ -103,6 +170,8 @@ __device__ __forceinline__ uint32_t kr_mask16(const uint8_t *__restrict__ tbase,
     h = kr_reduce40((uint32_t)T, (uint32_t)(T >> 32));
     mask |= (kr_divides(h, kp) ? 1u : 0u) << j;
   }
+  }
+  if (interior) return mask;
   // positions before w-1 (words shorter than w+1 are never saved, newscan.cpp:248) and past the text end
   const uint64_t lo_valid = (uint64_t)(W - 1);
   uint32_t valid = 0xFFFFu;
@@ -142,7 +211,7 @@ __global__ __launch_bounds__(256) void kr_flag_kernel(const uint8_t *__restrict_
 // counted, not written (the caller repeats with the true size - a text whose windows trigger four times as often as 1 / p).
 constexpr unsigned long long kTagAgg = 1ull << 62, kTagPre = 2ull << 62, kTagMask = 3ull << 62;      // tag in the two top bits
 constexpr int kScanChunks = 16;                      // 4096-position chunks per tile: one look-back per 64 KB of text
-template <int W>
+template <int W, bool FAST>
 __global__ __launch_bounds__(256) void kr_scan_kernel(const uint8_t *__restrict__ tbase, uint64_t n, KRParams kp, uint64_t ntiles,
                                                       unsigned int *__restrict__ ticket, unsigned long long *__restrict__ state,
                                                       uint64_t *__restrict__ ends, uint64_t cap,
@@ -158,14 +227,14 @@ __global__ __launch_bounds__(256) void kr_scan_kernel(const uint8_t *__restrict_
   uint32_t mask[kScanChunks], incl[kScanChunks];
 #pragma unroll 1
   for (int j = 0; j < kScanChunks; j++) {
-    const uint64_t pos0 = ((tile * kScanChunks + j) * 256 + threadIdx.x) * 16;
-    mask[j] = pos0 < n ? kr_mask16<W>(tbase, pos0, n, kp, first_bad) : 0u;
+    const uint64_t c0 = (tile * kScanChunks + j) * 4096;      // first position of the chunk (uniform)
+    const uint64_t pos0 = c0 + (uint64_t)threadIdx.x * 16;
+    const bool interior = c0 >= 16 && c0 + 4096 <= n;
+    mask[j] = pos0 < n ? kr_mask16<W, FAST>(tbase, pos0, n, kp, first_bad, interior) : 0u;
   }
 #pragma unroll
   for (int j = 0; j < kScanChunks; j++) {
-    uint32_t v = __popc(mask[j]);
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t u = __shfl_up(v, off, 64); if (lane >= off) v += u; }
+    const uint32_t v = wave_incl_sum(__popc(mask[j]));
     incl[j] = v;
     if (lane == 63) wsum[j][wv] = v;
   }
@@ -309,6 +378,42 @@ KRParams make_kr_params(int w, uint64_t p) {
   return kp;
 }
 
+// the fused chain's trigger for a staged text (see fast_triggers): needs the text's first window for the seed
+KRParams make_fast_params(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p) {
+  KRParams kp = make_kr_params(w, p);
+  if (w < 4 || w > 17) return kp;          // (the register path of the scan kernel; wider windows keep Karp-Rabin)
+  kp.fast = 1;
+  kp.fthr = p >= (1ull << 32) ? 0u : (uint32_t)((1ull << 32) / p);
+  bool have_first = false, ref_first = false;
+  uint8_t fw[32] = {0};
+  if (n >= (uint64_t)w) {
+    PFP_HIP(hipMemcpyAsync(fw, tx.tbase(), (size_t)w, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    uint64_t h = 0;
+    for (int k = 0; k < w; k++) h = (h * 256 + fw[k]) % kPrime;      // newscan.cpp:168-202
+    ref_first = h % p == 0;
+    have_first = true;
+  }
+  const uint32_t h_first = fast_hash_bytes(fw, w);      // (unseeded here: the loop below is what chooses the seed)
+  auto fires = [&](uint32_t h, uint32_t seed) { return (uint32_t)((h + seed) * kFastK) < kp.fthr; };
+  uint32_t best = 0;
+  for (uint32_t seed = 0; seed < (1u << 20); seed++) {
+    if (have_first && fires(h_first, seed) != ref_first) continue;
+    best = seed;
+    bool crumbs = false;
+    if (p >= 32)
+      for (const char ch : {'A', 'C', 'G', 'T', 'N', 'a', 'c', 'g', 't', 'n'}) {
+        uint8_t run[32];
+        memset(run, ch, sizeof run);
+        const uint32_t hr = fast_hash_bytes(run, w);
+        if (fires(hr, seed) && !(have_first && hr == h_first)) crumbs = true;
+      }
+    if (!crumbs) break;
+  }
+  kp.fseed = best;
+  return kp;
+}
+
 template <int W>
 static void launch_flag(pfp_ctx *c, int nblocks, const uint8_t *tbase, uint64_t n, const KRParams &kp,
                         uint16_t *flags16, uint32_t *bc, unsigned long long *fb) {
@@ -336,7 +441,8 @@ void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p,
 template <int W>
 static void launch_scan(pfp_ctx *c, uint64_t ntiles, const uint8_t *tbase, uint64_t n, const KRParams &kp, unsigned int *ticket,
                         unsigned long long *state, uint64_t *ends, uint64_t cap, unsigned long long *fb) {
-  hipLaunchKernelGGL(kr_scan_kernel<W>, gdim(ntiles), gdim(256), 0, c->stream, tbase, n, kp, ntiles, ticket, state, ends, cap, fb);
+  if (kp.fast) hipLaunchKernelGGL((kr_scan_kernel<W, true>), gdim(ntiles), gdim(256), 0, c->stream, tbase, n, kp, ntiles, ticket, state, ends, cap, fb);
+  else hipLaunchKernelGGL((kr_scan_kernel<W, false>), gdim(ntiles), gdim(256), 0, c->stream, tbase, n, kp, ntiles, ticket, state, ends, cap, fb);
 }
 
 // Full stage 1a on a staged text.  Returns the number of trigger ends; d_ends receives them.
@@ -444,9 +550,10 @@ __global__ void giant_phrases_kernel(const uint64_t *__restrict__ ends, uint64_t
 // hashes of kCand consecutive windows starting at every pick (one block per pick)
 constexpr uint32_t kCand = 256;
 __global__ void window_hash_kernel(const uint8_t *__restrict__ tbase, int w, const uint64_t *__restrict__ picks,
-                                   uint32_t *__restrict__ out) {
+                                   uint32_t *__restrict__ out, int fast, uint32_t seed) {
   uint64_t e = picks[BID] + threadIdx.x;
   uint32_t h = 0;
+  if (fast) { out[BID * kCand + threadIdx.x] = fast_hash_bytes(tbase + e - (uint64_t)(w - 1), w) + seed; return; }
   for (int k = 0; k < w; k++) h = kr_reduce<8>(((uint64_t)h << 8) | tbase[e - (uint64_t)(w - 1) + (uint64_t)k]);
   out[BID * kCand + threadIdx.x] = h;
 }
@@ -466,7 +573,7 @@ uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_use
   uint32_t ng = read_scalar(c, cnt.p);
   if (!ng) return 0;
   uint32_t take = ng < cap ? ng : cap;
-  hipLaunchKernelGGL(window_hash_kernel, gdim(take), gdim(kCand), 0, c->stream, tx.tbase(), w, picks.p, hashes.p);
+  hipLaunchKernelGGL(window_hash_kernel, gdim(take), gdim(kCand), 0, c->stream, tx.tbase(), w, picks.p, hashes.p, (int)kp.fast, kp.fseed);
   PFP_HIP(hipMemcpyAsync(hv.data(), hashes.p, (size_t)take * kCand * 4, hipMemcpyDeviceToHost, c->stream));
   sync(c);
   // The first window of the text must never become a trigger by this route: the reference writes 0x02
@@ -479,7 +586,7 @@ uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_use
     sync(c);
     uint64_t h = 0;
     for (int k = 0; k < w; k++) h = (h * 256 + fw[k]) % 1999999973ull;      // newscan.cpp:168-202
-    h_first = (uint32_t)h;
+    h_first = kp.fast ? fast_hash_bytes(fw.data(), w) + kp.fseed : (uint32_t)h;
   }
   // per giant phrase: the candidate window that is rarest among kCand consecutive ones.  A
   // window seen more than 4 times there recurs every < 64 bytes (a run of one repeated char,
@@ -504,10 +611,14 @@ uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_use
 
 uint64_t scan_text_adaptive(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, uint64_t max_phrase,
                             DBuf<uint64_t> &d_ends, uint64_t *n_used, uint32_t *n_extra) {
-  KRParams kp = make_kr_params(w, p);
+  KRParams kp = c->fast_triggers ? make_fast_params(c, tx, n, w, p) : make_kr_params(w, p);
   *n_extra = 0;
   uint64_t ne = scan_text(c, tx, n, w, p, d_ends, n_used, &kp);
-  for (int iter = 0; iter < 4; iter++) {
+  if (kp.fast && ne == 0) {      // no cut at all: the reference's own hash decides whether this text has a parse (bwtparse.c:244)
+    kp = make_kr_params(w, p);
+    ne = scan_text(c, tx, n, w, p, d_ends, n_used, &kp);
+  }
+  for (int iter = 0; iter < 4 && max_phrase; iter++) {
     if (!propose_extra_triggers(c, tx, *n_used, w, max_phrase, d_ends, ne, kp)) break;
     ne = scan_text(c, tx, *n_used, w, p, d_ends, n_used, &kp);
   }

@@ -1068,7 +1068,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     DBuf<uint8_t> act(c, N);
     act.zero();
     if (m_active) hipLaunchKernelGGL(mark_slots_kernel<I>, gdim(cdiv(m_active, TB)), gdim(TB), 0, c->stream, m_active, aslot_list, act.p);
-    KScope ks(c, "pfp::write_back_kernel", N * 6);
+    KScope ks(c, "pfp::repair_ranks_kernel", N * 6);
     hipLaunchKernelGGL(repair_ranks_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, keep0.p, act.p, out.sa.p, out.grp.p,
                        out.finbit, out.rank.p);
     ranks_stale = false;
@@ -1125,16 +1125,16 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     DBuf<I> tile_last, tile_scan;      // first round of dictionary mode: last head per 256 slots, and its running maximum
     if (first && lazy) {
       tile_last.alloc(c, cdiv64(m, 256)); tile_scan.alloc(c, cdiv64(m, 256));
-      { KScope ks(c, "pfp::heads_kernel", m * 13);
+      { KScope ks(c, "pfp::heads0_kernel", m * 13);
         hipLaunchKernelGGL(heads0_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, keyo.p, out.keymask, out.shift, out.T,
                            hd.p, tile_last.p, out.tab.p); }
       inclusive_max<I>(c, out.tab.p, out.tab.p, out.T);
       inclusive_max<I>(c, tile_last.p, tile_scan.p, cdiv64(m, 256));
     } else if (ipiv_round) {
-      KScope ks(c, "pfp::heads_kernel", m * 18);
+      KScope ks(c, "pfp::heads64seg_kernel", m * 18);
       hipLaunchKernelGGL(heads64seg_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, gs.p, keyo.p, aslot.p, hd.p, hv.p);
     } else if (seg_round) {
-      KScope ks(c, "pfp::heads_kernel", m * 14);
+      KScope ks(c, "pfp::heads32_kernel", m * 14);
       hipLaunchKernelGGL(heads32_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, gs.p, k32o.p, aslot.p, hd.p, hv.p);
     } else if (dbl_round && kWide) {
       KScope ks(c, "pfp::heads_kernel", m * 25);
@@ -1147,7 +1147,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     first = false;
     if (!round0) inclusive_max<I>(c, hv.p, newhead.p, m);
     if (round0) {
-      { KScope ks(c, "pfp::write_back_kernel", m * (4 + 4 + 1 + 8 + 4 + 1));
+      { KScope ks(c, "pfp::write_back0_kernel", m * (4 + 4 + 1 + 8 + 4 + 1));
         hipLaunchKernelGGL(write_back0_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, valo.p, tile_scan.p, hd.p, keyo.p,
                            rank_p, out.grp.p, keep.p, (lazy_active || no_rank) ? 0 : 1); }
       if (lazy_active) active_stale = true;
@@ -1192,7 +1192,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
                           tile_off.alloc(c, cdiv64(N, kTile) + 1); tile_hoff.alloc(c, cdiv64(N, kTile) + 1); }
       PFP_HIP(hipMemsetAsync(tile_keep.p + ntile, 0, 4, c->stream));
       PFP_HIP(hipMemsetAsync(tile_heads.p + ntile, 0, 4, c->stream));
-      KScope ks(c, "pfp::compact3_kernel", m * 2 + 0);      // label kept from the kernel this replaced (profiles compare rounds)
+      KScope ks(c, "pfp::active_place_kernel", m * 2 + 0);      // (+ active_count_kernel and the two tile scans)
       hipLaunchKernelGGL(active_count_kernel, gdim((unsigned)cdiv64(ntile, 16)), gdim(256), 0, c->stream, keep.p, hd.p, m,
                          tile_keep.p, tile_heads.p);
       exclusive_sum_u32_to<I>(c, tile_keep.p, tile_off.p, ntile + 1);
@@ -1260,7 +1260,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     if (use_finisher && finisher_ok && m <= kFinishMax && out.rounds >= 1 && (g.mode == MODE_DICT || (g.mode == MODE_PLAIN && g.sym))) {
       DBuf<uint32_t> flt(c, m), feq(c, m), fgs(c, m), fov(c, 1);
       fov.zero();
-      KScope ks(c, "pfp::finish_kernels", m * (sizeof(I) * 4 + 12));
+      KScope ks(c, "pfp::finish_rank_kernel", m * (sizeof(I) * 4 + 12));
       hipLaunchKernelGGL(finish_rank_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, out.bytes, m, act_i.p, act_grp.p, flt.p, feq.p,
                          fgs.p, fov.p);
       if (read_scalar(c, fov.p) == 0) {
@@ -1326,7 +1326,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
         {
           DBuf<unsigned long long> best(c, N);
           best.zero();
-          KScope ks(c, "pfp::ipivot_kernels", m * (4 + 4 + 4 + 8 + 16 + 12 + 64));
+          KScope ks(c, "pfp::ipivot_keys_kernel", m * (4 + 4 + 4 + 8 + 16 + 12 + 64));
           hipLaunchKernelGGL(ipivot_select_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, NP, h, act_i.p, act_grp.p, g.dist, best.p);
           hipLaunchKernelGGL(ipivot_keys_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, m, NP, h, kIntPivCap, g.sym, act_i.p,
                              act_grp.p, best.p, key.p, val.p);
@@ -1364,7 +1364,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     if (lazy_pending) {
       lazy_pending = false;
       if (m * kLazyRatio > N) {      // most lookups would need the search: scatter the settled ranks once
-        KScope ks(c, "pfp::write_back_kernel", N * (4 + 4 + 1 + 4));
+        KScope ks(c, "pfp::scatter_settled_kernel", N * (4 + 4 + 1 + 4));
         hipLaunchKernelGGL(scatter_settled_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, N, out.sa.p, out.grp.p, keep0.p,
                            out.finbit, out.rank.p);
         if (!out.paybits) out.skeys.release();      // with payload the merge still reads the records from skeys
@@ -1382,7 +1382,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       static const bool use_small = getenv("PFP_NO_SMALLSEG") == nullptr;
       if (use_segsort && use_small && ngrp && m / ngrp <= (kWide ? kSmallSeg / 4 : kSmallSeg / 2) && (!small_failed || m / ngrp <= 3)) {
         seg_bufs();
-        { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
+        { KScope ks(c, "pfp::build_keys32_kernel", m * (4 + 4 + 8));
           hipLaunchKernelGGL(build_keys32_kernel, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
         seg_round = seg_small_sort(m);
         if (!seg_round) small_failed = true;
@@ -1392,7 +1392,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
         uint32_t ng = 0, maxlen = 0;
         seg_setup(m, ngrp, ng, maxlen);
         if (maxlen <= (1u << 15) && m / ng >= 24) {
-          { KScope ks(c, "pfp::build_keys_kernel", m * (4 + 4 + 8));
+          { KScope ks(c, "pfp::build_keys32_kernel", m * (4 + 4 + 8));
             hipLaunchKernelGGL(build_keys32_kernel, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, h, act_i.p, L, k32.p, val.p); }
           segsort_pairs_u32<I>(c, k32.p, k32o.p, val.p, valo.p, m, ng, segb.p, sege.p, 0, bits_for(N));
           seg_round = true;
@@ -1753,7 +1753,7 @@ static void sort_suffix_list(pfp_ctx *c, const SufGeom &g, const KeyCode &kc, in
   out.paybits = 0;
   out.keymask = kc.kbits + 1 >= 64 ? ~0ull : ((1ull << (kc.kbits + 1)) - 1);
   if (n) {
-    KScope ks(c, "pfp::init_keys_packed_kernel", (uint64_t)n * 17);
+    KScope ks(c, "pfp::init_keys_list_kernel", (uint64_t)n * 17);
     hipLaunchKernelGGL(init_keys_list_kernel<I>, gdim(cdiv(n, 256)), gdim(256), 0, c->stream, g.wv.bytes, (uint64_t)n, kc, idx.p, key.p, val.p,
                        idx_bits);
   }
@@ -1823,7 +1823,7 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
     static const bool one_per_thread = getenv("PFP_RANGE_CMP1") != nullptr;      // (the first form of the comparison kernel)
     const uint64_t nblk = cdiv64(N, one_per_thread ? 256 : 1024);
     DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
-    KScope ks(c, "pfp::range_flags_kernel", N * 2);
+    KScope ks(c, one_per_thread ? "pfp::range_flags_cmp_kernel" : "pfp::range_flags_cmp4_kernel", N * 2);
     if (one_per_thread)
       hipLaunchKernelGGL(range_flags_cmp_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, b_lo, has_lo ? 1 : 0, b_hi,
                          has_hi ? 1 : 0, count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
@@ -1978,7 +1978,7 @@ void sort_int_suffixes_range(pfp_ctx *c, const uint32_t *sym, uint64_t N, uint32
   g.sym = sym;
   DBuf<uint32_t> dist(c, N);
   {
-    KScope ks(c, "pfp::parse_share_dist", N * 24);
+    KScope ks(c, "pfp::rare_dist_kernel", N * 24);      // (+ rare_marks_kernel and the running maximum between them)
     DBuf<uint32_t> mk(c, N), pm(c, N);
     const uint32_t below = (uint32_t)std::max<uint64_t>(2, N / n_sym);
     hipLaunchKernelGGL(rare_marks_kernel, gdim(cdiv(N, 256)), gdim(256), 0, c->stream, sym, (uint32_t)N, occ, n_sym, below, mk.p);
@@ -1988,7 +1988,7 @@ void sort_int_suffixes_range(pfp_ctx *c, const uint32_t *sym, uint64_t N, uint32
   }
   DBuf<uint64_t> key(c, N);
   {
-    KScope ks(c, "pfp::parse_share_keys", N * 28);
+    KScope ks(c, "pfp::init_keys_int_run_kernel", N * 28);      // (+ run_marks_kernel and its running maximum)
     DBuf<uint32_t> val(c, N);
     if (64 - 2 * sb >= 6) {
       DBuf<uint32_t> v(c, N), pm(c, N);
@@ -2015,7 +2015,7 @@ void sort_int_suffixes_range(pfp_ctx *c, const uint32_t *sym, uint64_t N, uint32
   }
   const int khi_open = part + 1 == parts ? 1 : 0;
   std::optional<KScope> ks_sel;      // (ended before the list is sorted)
-  ks_sel.emplace(c, "pfp::parse_share_select", N * 10);
+  ks_sel.emplace(c, "pfp::range_flags_u64_kernel", N * 10);      // (+ the flag count and the index selection)
   DBuf<uint8_t> flag(c, N + 16);
   PFP_HIP(hipMemsetAsync(flag.p + N, 0, 16, c->stream));
   const uint64_t nblk = cdiv64(N, 256);

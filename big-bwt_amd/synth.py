@@ -120,6 +120,8 @@ def first_window_triggers(first_bytes, w, p):
 
 # BASELINE.json configs as synthetic workloads, shared by bench.py and the parity tests
 WORKLOADS = {
+    "c1": dict(G=12_100_020, C=1, r=0.0, nblocks=[], w=10, p=100, flags=0, seed=1,
+               desc="BASELINE configs[0]: 1x yeast-shaped FASTA (~12.3 MB), -w 10 -p 100, BWT checked against the whole-text SACA-K BWT (-c)"),
     "c2": dict(G=249_000_000, C=1, r=0.0, nblocks=[(120_000_000, 18_000_000), (30_000_000, 10_000), (200_000_000, 10_000)],
                w=10, p=100, flags=0, seed=2,
                desc="BASELINE configs[1]: 1x human-chr1-shaped FASTA (~253 MB), -w 10 -p 100, BWT only"),
@@ -131,6 +133,10 @@ WORKLOADS = {
                  desc="1024x mutated yeast-shaped FASTA (~12.6 GB; the north star's >= 10 GB repetitive input on one GPU), BWT only"),
     "huge_s": dict(G=12_100_020, C=1024, r=1e-3, nblocks=[], w=10, p=100, flags=2, seed=3,
                    desc="1024x mutated yeast-shaped FASTA (~12.6 GB; the north star's >= 10 GB repetitive input on one GPU), BWT + -s sampled SA"),
+    "big_S": dict(G=12_100_020, C=512, r=1e-3, nblocks=[], w=10, p=100, flags=1, seed=3,
+                  desc="BASELINE configs[3] flag set (-w 10 -p 100 -S, full SA in 5-byte integers) on 512 copies (~6.3 GB > 2^32 bytes: SA values above 4 G)"),
+    "huge_w12": dict(G=12_100_020, C=1024, r=1e-3, nblocks=[], w=12, p=200, flags=2, seed=3,
+                     desc="BASELINE configs[4] flag set (-w 12 -p 200 -s) on the 12.6 GB, 1024-copy text"),
     "wide": dict(G=4_260_000_000, C=1, r=0.0, nblocks=[], w=10, p=100, flags=0, seed=3,
                  desc="one 4.26 G-base random genome as FASTA (~4.33 GB, non-repetitive): dictionary > 4 GiB, exercises the 64-bit index build"),
     "wide31": dict(G=12_100_020, C=200, r=3e-2, nblocks=[], w=10, p=100, flags=0, seed=3,

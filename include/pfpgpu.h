@@ -233,6 +233,12 @@ int pfp_get_kernel_trace(pfp_ctx *ctx, pfp_kernel_stat *out, int cap);
  * as the reference does).  The .bwt/.sa/.ssa/.esa outputs do not depend on the parse
  * (SURVEY.md 2.2-Q11); pfp_scan / pfp_parse always use the reference's trigger set. */
 void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
+/* Fused chain only: which function of the last w bytes cuts the text.  fast != 0 (default): a multiply-add hash of the window,
+ * a third of the arithmetic of the reference's `KR_window` (newscan.cpp:168-202: mod 1999999973, then mod p) with the same 1 / p
+ * density; 0 (or PFP_WINDOW_HASH=kr in the environment at pfp_ctx_create): Karp-Rabin as in the reference.  The outputs do not
+ * depend on the choice (quirk Q1 is reproduced either way); pfp_scan / pfp_parse / the stage executables
+ * always cut exactly where the reference does.  With fast == 0 and max_phrase == 0 the fused chain parses like the reference. */
+void pfp_set_window_hash(pfp_ctx *ctx, int fast);
 /* Index width of dictionary positions and suffix-array slots: 0 = by size (32 bits below 4 GiB of dictionary /
  * text, 64 above: the reference's choice between its 32-bit and -DM64 executables, bigbwt:109-151), 64 = always
  * the wide build (what PFP_FORCE_IDX64=1 in the environment sets at pfp_ctx_create).  Outputs are identical. */

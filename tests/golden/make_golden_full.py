@@ -31,6 +31,10 @@ def main():
     import importlib
     synth = importlib.import_module("bigbwt_amd.synth")
     cases = {
+        # BASELINE configs[0]: the plumbing case with the -c check (simplebwt's .Bwt must equal the .bwt): the synth-family text
+        # and BASELINE.md section 5's literal GEN(12.1e6,1,0,1)
+        "c1": lambda: (synth.workload_text_np("c1"), dict(synth.WORKLOADS["c1"], check=True)),
+        "c1_gen": lambda: (O.gen_fasta(12_100_000, 1, 0.0, 1), dict(w=10, p=100, flags=0, check=True, desc="BASELINE.md section 5 C1-syn: GEN(12.1e6,1,0,1), -w 10 -p 100 -c")),
         "c2": lambda: (synth.workload_text_np("c2"), synth.WORKLOADS["c2"]),
         "c3": lambda: (synth.workload_text_np("c3"), synth.WORKLOADS["c3"]),
         "c4s": lambda: (synth.workload_text_np("c4s"), synth.WORKLOADS["c4s"]),
@@ -45,9 +49,12 @@ def main():
         text, wl = cases[name]()
         t0 = time.time()
         tmp = os.path.join("/tmp", f"pfp_golden_full_{name}")
-        r = O.run_ref(text.tobytes(), wl["w"], wl["p"], wl["flags"], threads=0, keep_dir=tmp, want_intermediates=False)
+        r = O.run_ref(text.tobytes(), wl["w"], wl["p"], wl["flags"], threads=0, keep_dir=tmp, want_intermediates=False, check=bool(wl.get("check")))
         rec = dict(desc=wl["desc"], n=int(len(text)), w=wl["w"], p=wl["p"], flags=wl["flags"], text_sha256=sha(text.tobytes()),
                    ref_seconds={k: round(v, 1) for k, v in r["seconds"].items()})
+        if wl.get("check"):          # bigbwt -c (bigbwt:177-194): `cmp file.bwt file.Bwt`
+            rec["check_bwts_match"] = bool(r["Bwt"] == r["bwt"])
+            assert rec["check_bwts_match"]
         for ext in ("bwt", "sa", "ssa", "esa"):
             if ext in r:
                 rec[ext + "_sha256"] = sha(r[ext])

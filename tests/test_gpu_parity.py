@@ -62,12 +62,15 @@ def test_stage_files_match_reference_golden(golden, O, pkg, wctx, idx):
     assert sha(out["bwt"]) == c["runs"]["0"]["bwt_sha256"]
 
 
+@pytest.mark.parametrize("fast_hash", [True, False])
 @pytest.mark.parametrize("max_phrase", [0, 700, 3000])
-def test_outputs_do_not_depend_on_the_parse(golden, O, pkg, ctx, max_phrase):
-    """fused chain with adaptive extra triggers (giant-phrase splitting) on/off: identical
-    .bwt/.sa/.ssa/.esa; the staged pfp_parse keeps the reference's parse."""
+def test_outputs_do_not_depend_on_the_parse(golden, O, pkg, ctx, max_phrase, fast_hash):
+    """fused chain with adaptive extra triggers (giant-phrase splitting) on/off, cutting by its own window hash (round 4:
+    pfp_set_window_hash) or by the reference's Karp-Rabin hash: identical .bwt/.sa/.ssa/.esa (the Q1
+    case `kat_q1`, where the reference's first window triggers, included); the staged pfp_parse keeps the reference's parse."""
     try:
         ctx.set_max_phrase(max_phrase)
+        ctx.set_window_hash(fast_hash)
         used = 0
         for c in golden:
             if c["n"] > 200000:
@@ -87,6 +90,25 @@ def test_outputs_do_not_depend_on_the_parse(golden, O, pkg, ctx, max_phrase):
         assert (used > 0) == (max_phrase > 0)
     finally:
         ctx.set_max_phrase(1 << 15)
+        ctx.set_window_hash(True)
+
+
+def test_window_hash_parses_differently_but_as_densely(O, ctx):
+    """the fused chain's window hash is not Karp-Rabin (different phrases) and cuts about as often (1 / p)"""
+    text = O.gen_fasta(400000, 3, 0.001, 9)
+    counts = {}
+    try:
+        for fast in (True, False):
+            ctx.set_window_hash(fast)
+            ctx.set_max_phrase(0)
+            ctx.bigbwt(text, 10, 100, 0)
+            st = ctx.stats()
+            counts[fast] = (st["n_phrases"], st["n_words"], st["dict_size"])
+    finally:
+        ctx.set_window_hash(True)
+        ctx.set_max_phrase(1 << 15)
+    assert counts[True] != counts[False]
+    assert 0.8 < counts[True][0] / counts[False][0] < 1.25, counts
 
 
 def test_scan_matches_oracle(O, ctx):
@@ -301,15 +323,37 @@ def test_trigger_dense_text_overflows_the_scan_buffer(O, pkg, wctx):
     assert len(O.scan(np.tile(unit, 60), 10, 100)) >= 50
     text = np.tile(unit, 300000)
     assert len(O.scan(text, 10, 100)) > 4 * len(text) // 100 + 65536
-    for flags, oflags in ((0, 0), (pkg.FLAG_SA, O.FLAG_SA), (pkg.FLAG_SSA | pkg.FLAG_ESA, O.FLAG_SSA | O.FLAG_ESA)):
-        got = wctx.bigbwt(text, 10, 100, flags)
-        want = O.bigbwt(text, 10, 100, oflags)
-        assert np.array_equal(got["bwt"], want["bwt"])
-        if flags & pkg.FLAG_SA:
-            assert np.array_equal(pkg.unpack5(got["sa"]), want["sa"])
-        if flags & pkg.FLAG_SSA:
-            assert np.array_equal(pkg.unpack5(got["ssa"]).reshape(-1, 2), want["ssa"])
-            assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
+
+    def check(text):
+        for flags, oflags in ((0, 0), (pkg.FLAG_SA, O.FLAG_SA), (pkg.FLAG_SSA | pkg.FLAG_ESA, O.FLAG_SSA | O.FLAG_ESA)):
+            got = wctx.bigbwt(text, 10, 100, flags)
+            assert wctx.stats()["n_phrases"] > 4 * len(text) // 100 + 65536
+            want = O.bigbwt(text, 10, 100, oflags)
+            assert np.array_equal(got["bwt"], want["bwt"])
+            if flags & pkg.FLAG_SA:
+                assert np.array_equal(pkg.unpack5(got["sa"]), want["sa"])
+            if flags & pkg.FLAG_SSA:
+                assert np.array_equal(pkg.unpack5(got["ssa"]).reshape(-1, 2), want["ssa"])
+                assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want["esa"])
+    try:
+        wctx.set_window_hash(False)          # that text is dense in Karp-Rabin triggers
+        check(text)
+        wctx.set_window_hash(True)           # the chain's own window hash: look for a period-7 text one of whose windows it cuts
+        rng = np.random.default_rng(5)
+        for _ in range(400):
+            # (a random tail gives the reference's hash - the oracle's parse - something to cut as well)
+            cand = np.concatenate([np.tile(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 7)], 300000), O.gen_fasta(20000, 1, 0.0, 77)[8:]])
+            try:
+                wctx.bigbwt(cand[:70000], 10, 100, 0)
+            except pkg.PfpError:          # (no window of this period cuts at all: PFP_ESHORT like the reference, bwtparse.c:244)
+                continue
+            if wctx.stats()["n_phrases"] > 9000:
+                check(cand)
+                break
+        else:
+            pytest.fail("no trigger-dense periodic text found for the window hash")
+    finally:
+        wctx.set_window_hash(True)
 
 
 def test_steady_state_calls_do_not_reach_the_driver(O, pkg):

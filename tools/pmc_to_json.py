@@ -12,12 +12,7 @@ def bench_name(n):
     m = re.search(r'pfp::(\w+)', n)
     if m and 'rocprim' not in n[:40]:
         k = m.group(1)
-        k = {'heads0_kernel': 'heads_kernel', 'heads32_kernel': 'heads_kernel', 'write_back0_kernel': 'write_back_kernel',
-             'scatter_settled_kernel': 'write_back_kernel', 'build_keys32_kernel': 'build_keys_kernel',
-             'slot_payload_kernel': 'slot_gather_kernel', 'active_place_kernel': 'compact3_kernel', 'active_count_kernel': 'compact3_kernel',
-             'flag_place_kernel': 'select_flags_kernel', 'flag_count_kernel': 'select_flags_kernel',
-             'slot_records_kernel': 'slot_gather_kernel', 'slot_fetch_kernel': 'slot_gather_kernel', 'pprec16_kernel': 'pprec_kernel',
-             'line_terms_kernel': 'dict_index_fill_kernel', 'word_ends_kernel': 'dict_index_words_kernel'}.get(k, k)
+        # (round 4: bench.py's trace labels are the launched kernels' own names - no mapping table)
         return 'pfp::' + k
     if 'onesweep' in n or 'radix_sort' in n or 'block_sort' in n:
         return 'rocprim::radix_sort_pairs<u64,u32>' if re.search(r'unsigned long, unsigned int|unsigned long,unsigned int', n) else 'rocprim::radix_sort_pairs<u32,u32>'
@@ -35,7 +30,7 @@ def load(f):
 
 fetch, disp = load(sys.argv[1])
 write, _ = load(sys.argv[2])
-chains = max(1, disp.get('pfp::dict_index_fill_kernel', 1))
+chains = max(1, disp.get('pfp::line_terms_kernel', 1))
 out = dict(workload=sys.argv[3], chains_in_profiled_run=chains,
            source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), tools/pmc_to_json.py",
            correction="traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB*1024); the x2 is calibrated for 16 B/lane streaming loads, gathers are over-corrected",
