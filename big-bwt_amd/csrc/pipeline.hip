@@ -1691,6 +1691,31 @@ int pfp_scan_staged(pfp_ctx *c, uint64_t p, uint64_t *n_ends) {
   PFP_CATCH(c)
 }
 
+// diagnostic: the first-round sort of radix.hip on caller data - keys (and 32-bit values, may be null) sorted in place, stable
+// on key bits [lo, hi)
+int pfp_debug_msd_sort(pfp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t n, int lo, int hi) {
+  if (!c || (!keys && n)) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  if (!n) return PFP_OK;
+  DBuf<uint64_t> k(c, n), ka(c, n);
+  h2d(c, k.p, keys, n);
+  if (vals) {
+    DBuf<uint32_t> v(c, n), va(c, n);
+    h2d(c, v.p, vals, n);
+    msd_sort_pairs_db<uint32_t>(c, k, ka, v, va, n, lo, hi);
+    d2h(c, vals, v.p, n);
+    d2h(c, keys, k.p, n);
+    sync(c);
+  } else {
+    msd_sort_keys_db(c, k, ka, n, lo, hi);
+    d2h(c, keys, k.p, n);
+    sync(c);
+  }
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
 int pfp_scan_k1_enqueue(pfp_ctx *c, uint64_t p) {
   if (!c) return PFP_EINVAL;
   PFP_TRY(c)

@@ -65,6 +65,12 @@ void sort_keys_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, size_t n, int bb, int e
   PRIM2(rocprim::radix_sort_keys(tmp, tb, dk, n, (unsigned)bb, (unsigned)eb, c->stream));
   if (dk.current() != k.p) std::swap(k, kalt);
 }
+void sort_keys_raw(pfp_ctx *c, const uint64_t *in, uint64_t *out, size_t n, int bb, int eb) {
+  if (!n) return;
+  if (bb > 0 && eb == 64 && n <= (size_t(1) << 22)) bb = 0;      // (the merge path's mask: see sort_keys_db)
+  KScope ks(c, "rocprim::radix_sort_keys<u64>", n * 16);
+  PRIM2(rocprim::radix_sort_keys(tmp, tb, in, out, n, (unsigned)bb, (unsigned)eb, c->stream));
+}
 template void sort_keys_db<uint64_t>(pfp_ctx *, DBuf<uint64_t> &, DBuf<uint64_t> &, size_t, int, int);
 template void sort_pairs<uint64_t, uint32_t>(pfp_ctx *, const uint64_t *, uint64_t *, const uint32_t *, uint32_t *, size_t, int, int);
 template void sort_pairs<uint32_t, uint32_t>(pfp_ctx *, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, size_t, int, int);

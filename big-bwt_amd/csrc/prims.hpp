@@ -22,6 +22,13 @@ void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &v
 // begin_bit must be a unique index that ascends with the input order (small inputs are sorted on the whole word)
 template <class K>
 void sort_keys_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, size_t n, int begin_bit, int end_bit);
+// keys only, in -> out (the library keeps a temporary copy); same rule about the bits below begin_bit
+void sort_keys_raw(pfp_ctx *c, const uint64_t *in, uint64_t *out, size_t n, int begin_bit, int end_bit);
+// radix.hip (round 4): the hand-written first-round sort - stable on key bits [lo, hi), same buffer contract as sort_pairs_db /
+// sort_keys_db (result in k / v, DBufs swapped where the last pass ended in the alternates)
+template <class V>
+void msd_sort_pairs_db(pfp_ctx *c, DBuf<uint64_t> &k, DBuf<uint64_t> &kalt, DBuf<V> &v, DBuf<V> &valt, size_t n, int lo, int hi);
+void msd_sort_keys_db(pfp_ctx *c, DBuf<uint64_t> &k, DBuf<uint64_t> &kalt, size_t n, int lo, int hi);
 // stable radix sort inside each segment [begin[k], end[k]) (one already-grouped array, n < 2^32)
 template <class V>
 void segsort_pairs_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, const V *vin, V *vout, size_t n,

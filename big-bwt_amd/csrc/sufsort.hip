@@ -980,14 +980,21 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   //      pairs (no third copy inside the library); afterwards keyo/valo hold the sorted pairs
   DBuf<uint64_t> keyo(c, N);
   DBuf<I> valo(c, N);
+  // the first round's sort: rocPRIM's onesweep, or (PFP_OWN_SORT=1) the hand-written MSD sort of radix.hip - bit-exact, and measured
+  // slower on every workload of round 4 (configs[2] 5.0 vs 3.8 ms, configs[1] 14.0 vs 13.4): the alphabetic code's bits carry ~0.8 bit
+  // of entropy each, so a partition by key BITS needs three passes where 16 uniform bits would do, and each pass reads its input
+  // twice
+  static const bool lib_sort = getenv("PFP_OWN_SORT") == nullptr;
   if (idx_bits) {
     // keys-only first round: the words are (key << idx_bits | position), 16 bytes per element and pass instead of 24;
     // the sort is stable on the key bits alone, so ties stay in position order; one streaming pass splits the result
-    sort_keys_db(c, key, keyo, N, idx_bits, idx_bits + key0_bits);
+    if (lib_sort) sort_keys_db(c, key, keyo, N, idx_bits, idx_bits + key0_bits);
+    else msd_sort_keys_db(c, key, keyo, N, idx_bits, idx_bits + key0_bits);
     KScope ks(c, "pfp::split_keys_kernel", N * (16 + sizeof(I)));
     hipLaunchKernelGGL(split_keys_kernel<I>, gdim(cdiv(N, TB)), gdim(TB), 0, c->stream, key.p, N, idx_bits, keyo.p, valo.p);
   } else {
-    sort_pairs_db(c, key, keyo, val, valo, N, 0, key0_bits);
+    if (lib_sort) sort_pairs_db(c, key, keyo, val, valo, N, 0, key0_bits);
+    else msd_sort_pairs_db<I>(c, key, keyo, val, valo, N, 0, key0_bits);
     std::swap(key, keyo); std::swap(val, valo);
   }
   if (lazy) { key.release(); val.release(); }      // dictionary mode: later rounds sort the (much smaller) unresolved set

@@ -232,6 +232,10 @@ int pfp_get_kernel_trace(pfp_ctx *ctx, pfp_kernel_stat *out, int cap);
  * by adding a few extra trigger windows taken from inside them (default 32768; 0 = parse exactly
  * as the reference does).  The .bwt/.sa/.ssa/.esa outputs do not depend on the parse
  * (SURVEY.md 2.2-Q11); pfp_scan / pfp_parse always use the reference's trigger set. */
+/* Diagnostic (tests): the hand-written first-round sort (csrc/radix.hip: what replaces the bucket passes of gsacak.c:1395-1524
+ * in the first round of the suffix sorter) on caller data: keys, and 32-bit values if vals != NULL, sorted in place, stable on
+ * key bits [lo, hi). */
+int pfp_debug_msd_sort(pfp_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t n, int lo, int hi);
 void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
 /* Fused chain only: which function of the last w bytes cuts the text.  fast != 0 (default): a multiply-add hash of the window,
  * a third of the arithmetic of the reference's `KR_window` (newscan.cpp:168-202: mod 1999999973, then mod p) with the same 1 / p

@@ -455,3 +455,35 @@ def test_c_driver_end_to_end(golden, O, tmp_path):
     assert sha(np.fromfile(str(f) + ".sa", dtype=np.uint8)) == c["runs"]["1"]["sa_sha256"]
     for ext in ("dict", "occ", "parse", "last", "sai", "ilist", "bwlast", "bwsai"):
         assert sha(np.fromfile(str(f) + "." + ext, dtype=np.uint8)) == c["runs"]["6"][ext + "_sha256"], ext
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 2047, 2049, 4096, 4097, 50000, 300001, 2_500_000, 9_000_000])
+def test_first_round_sort_against_numpy(ctx, n):
+    """csrc/radix.hip (the hand-written first-round sort: partition passes + bucket sorts in LDS) against numpy's stable sort:
+    pairs and keys only, bit ranges as the suffix sorter passes them, uniform / skewed / constant keys (oversize buckets go
+    to the library, more than 4096 of them send the whole array there)"""
+    rng = np.random.default_rng(n)
+    for lo, hi, kind in ((0, 48, "uniform"), (0, 40, "skew"), (0, 64, "uniform"), (28, 64, "keysonly"), (0, 36, "const"), (0, 17, "few"), (3, 11, "uniform")):
+        if kind == "uniform":
+            keys = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+        elif kind == "skew":          # half of the elements share one key, a tenth a second one
+            keys = rng.integers(0, 1 << 40, n, dtype=np.uint64)
+            keys[rng.random(n) < 0.5] = np.uint64(0x123456789)
+            keys[rng.random(n) < 0.1] = np.uint64(0xFFFFFFFFFF)
+        elif kind == "const":
+            keys = np.full(n, 0x5A5A5A5A5, dtype=np.uint64)
+        elif kind == "few":
+            keys = rng.integers(0, 7, n, dtype=np.uint64) << np.uint64(10)
+        else:                          # (key << 28 | index): the keys-only form of the suffix sorter
+            keys = (rng.integers(0, 1 << 36, n, dtype=np.uint64) << np.uint64(28)) | np.arange(n, dtype=np.uint64)
+        mask = np.uint64(((1 << hi) - 1) ^ ((1 << lo) - 1))
+        order = np.argsort(keys & mask, kind="stable")
+        if kind == "keysonly":
+            got = keys.copy()
+            ctx.debug_msd_sort(got, None, lo, hi)
+            assert np.array_equal(got, keys[order]), (n, lo, hi, kind)
+        else:
+            got, vals = keys.copy(), np.arange(n, dtype=np.uint32)
+            ctx.debug_msd_sort(got, vals, lo, hi)
+            assert np.array_equal(vals, order.astype(np.uint32)), (n, lo, hi, kind)
+            assert np.array_equal(got, keys[order]), (n, lo, hi, kind)
