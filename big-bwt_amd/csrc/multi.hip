@@ -38,25 +38,34 @@ struct Rccl {
   void *h = nullptr;
   int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommAbort)(ncclComm_t) = nullptr;
   int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  bool complete() const { return h && CommInitAll && CommDestroy && CommAbort && Send && Recv && AllGather && GroupStart && GroupEnd && GetErrorString; }
+  // (idempotent: a call after a partial failure starts over instead of returning a table with holes)
   bool load(std::string &err) {
-    if (h) return true;
+    if (complete()) return true;
+    if (h) { dlclose(h); h = nullptr; }
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (h) break; }
     if (!h) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
     auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
     CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
     CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
     Send = (decltype(Send))sym("ncclSend");
     Recv = (decltype(Recv))sym("ncclRecv");
+    AllGather = (decltype(AllGather))sym("ncclAllGather");
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-    return CommInitAll && CommDestroy && Send && Recv && GroupStart && GroupEnd && GetErrorString;
+    if (complete()) return true;
+    dlclose(h); h = nullptr;
+    return false;
   }
 };
 
@@ -109,6 +118,20 @@ struct Shared {
   std::vector<const void *> ptr;            // loopback: every rank's current send buffer
   std::vector<std::vector<uint64_t>> vals;  // small host values of the current exchange
   explicit Shared(int n, bool lb) : size(n), loopback(lb), bar(n), ptr(n), vals(n) {}
+  // a rank that fails takes everybody out: the host barrier is aborted and every communicator too, so that send / recv kernels
+  // already waiting for the failed rank end (ncclCommAbort may be called from any thread) instead of hanging their streams
+  std::atomic<bool> aborted{false};
+  std::mutex abort_mu;
+  bool comms_gone = false;
+  void abort_all() {
+    aborted.store(true);
+    bar.abort();
+    std::lock_guard<std::mutex> lk(abort_mu);
+    if (!loopback && rccl && !comms_gone) {
+      for (auto &cm : comms) if (cm) { (void)rccl->CommAbort(cm); cm = nullptr; }
+      comms_gone = true;
+    }
+  }
 };
 
 __global__ void add_u32_kernel(uint32_t *v, uint64_t n, uint32_t add) {
@@ -157,8 +180,8 @@ struct Coll {
       S.bar.wait();
       return out;
     }
-    exchange_same(d_send, bytes, out.p, counts);
-    MG_HIP(hipStreamSynchronize(stream));
+    exchange_same(d_send, bytes, out, counts);
+    wait_stream();
     return out;
   }
   // d_send = the pieces for ranks 0 .. size-1 back to back (send[r] bytes each) -> what everybody sent here, in rank order
@@ -184,34 +207,80 @@ struct Coll {
       return out;
     }
     exchange(d_send, send, out.p, recv);
-    MG_HIP(hipStreamSynchronize(stream));
+    wait_stream();
     return out;
   }
 
+ public:
+  bool force_grouped = false;      // (self test: the send / recv form of the all-gather whatever the counts)
  private:
   void nccl_check(int rc, const char *what) { if (rc != 0) fail(PFP_EHIP, "rank %d: RCCL %s: %s", rank, what, S.rccl->GetErrorString(rc)); }
+  // the stream's RCCL work is done - or some rank has given up (its abort_all ends the kernels this stream waits in)
+  void wait_stream() {
+    for (;;) {
+      const hipError_t e = hipStreamQuery(stream);
+      if (e == hipSuccess) return;
+      if (e != hipErrorNotReady) { (void)hipGetLastError(); fail(PFP_EHIP, "rank %d: stream: %s", rank, hipGetErrorString(e)); }
+      if (S.aborted.load()) fail(PFP_EHIP, "another rank left the chain");
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+  // a group that was opened is closed on the way out of an error, or the communicator stays in group mode
+  struct Group {
+    Rccl &R; bool open = false;
+    explicit Group(Rccl &r) : R(r) {}
+    ~Group() { if (open) (void)R.GroupEnd(); }
+  };
   // RCCL: piece r of d_send (send[r] bytes, back to back) goes to rank r; recv[s] bytes arrive from rank s, back to back
   void exchange(const void *d_send, const std::vector<uint64_t> &send, void *d_recv, const std::vector<uint64_t> &recv) {
     Rccl &R = *S.rccl;
-    nccl_check(R.GroupStart(), "group start");
+    Group g(R);
+    nccl_check(R.GroupStart(), "group start"); g.open = true;
     uint64_t so = 0, ro = 0;
     for (int r = 0; r < size; r++) {
       if (send[r]) nccl_check(R.Send((const uint8_t *)d_send + so, send[r], kNcclUint8, r, S.comms[rank], stream), "send");
       if (recv[r]) nccl_check(R.Recv((uint8_t *)d_recv + ro, recv[r], kNcclUint8, r, S.comms[rank], stream), "recv");
       so += send[r]; ro += recv[r];
     }
+    g.open = false;
     nccl_check(R.GroupEnd(), "group end");
   }
-  // RCCL: the same `bytes` of d_send to every rank
-  void exchange_same(const void *d_send, uint64_t bytes, void *d_recv, const std::vector<uint64_t> &recv) {
+  // RCCL: the same `bytes` of d_send to every rank.  ONE collective where that costs little: ncclAllGather when every rank
+  // brings the same number of bytes, and - counts within a quarter of each other - ncclAllGather of pieces padded to the
+  // largest, closed up by device copies; grouped send / recv for the rest (a rank that brings nothing next to one that brings much)
+  void exchange_same(const void *d_send, uint64_t bytes, Dev &out, const std::vector<uint64_t> &recv) {
     Rccl &R = *S.rccl;
-    nccl_check(R.GroupStart(), "group start");
+    uint64_t mx = 0, total = 0;
+    for (uint64_t c : recv) { mx = std::max(mx, c); total += c; }
+    if (!total) return;
+    bool equal = true;
+    for (uint64_t c : recv) equal = equal && c == mx;
+    if (equal && !force_grouped) {
+      nccl_check(R.AllGather(d_send, out.p, mx, kNcclUint8, S.comms[rank], stream), "all-gather");
+      return;
+    }
+    if (!force_grouped && (uint64_t)size * mx <= total + total / 4) {
+      // (every rank takes this branch or none: the counts are the same everywhere)
+      Dev pad(mx + 16), all((uint64_t)size * mx + 16);
+      if (bytes) MG_HIP(hipMemcpyAsync(pad.p, d_send, bytes, hipMemcpyDeviceToDevice, stream));
+      nccl_check(R.AllGather(pad.p, all.p, mx, kNcclUint8, S.comms[rank], stream), "all-gather");
+      uint64_t ro = 0;
+      for (int r = 0; r < size; r++) {
+        if (recv[r]) MG_HIP(hipMemcpyAsync(out.u8() + ro, all.u8() + (uint64_t)r * mx, recv[r], hipMemcpyDeviceToDevice, stream));
+        ro += recv[r];
+      }
+      wait_stream();      // (pad / all go out of scope)
+      return;
+    }
+    Group g(R);
+    nccl_check(R.GroupStart(), "group start"); g.open = true;
     uint64_t ro = 0;
     for (int r = 0; r < size; r++) {
       if (bytes) nccl_check(R.Send(d_send, bytes, kNcclUint8, r, S.comms[rank], stream), "send");
-      if (recv[r]) nccl_check(R.Recv((uint8_t *)d_recv + ro, recv[r], kNcclUint8, r, S.comms[rank], stream), "recv");
+      if (recv[r]) nccl_check(R.Recv((uint8_t *)out.p + ro, recv[r], kNcclUint8, r, S.comms[rank], stream), "recv");
       ro += recv[r];
     }
+    g.open = false;
     nccl_check(R.GroupEnd(), "group end");
   }
 };
@@ -451,10 +520,16 @@ void run_rank(Shared &S, int rank, int device, const Job &J, RankResult &res) {
         return pfp_dist_parse_sort(ctx, sym_all.p, P_total, (uint32_t)rank, (uint32_t)size, share.p, pinfo);
       });
       std::vector<uint64_t> pst;
-      { uint64_t v[2] = {st.rc == PFP_OK && pinfo[2] ? pinfo[0] : 0ull, st.rc == PFP_OK && pinfo[2] ? 1ull : 0ull}; agree(C, st, "parse suffix sort", ctx, v, 2, &pst); }
+      { uint64_t v[3] = {st.rc == PFP_OK && pinfo[2] ? pinfo[0] : 0ull, st.rc == PFP_OK && pinfo[2] ? 1ull : 0ull, pinfo[1]};
+        agree(C, st, "parse suffix sort", ctx, v, 3, &pst); }
       bool all_ok = true;
       uint64_t entries = 0;
-      for (int r = 0; r < size; r++) { if (!pst[(size_t)r * 3 + 2]) all_ok = false; entries += pst[(size_t)r * 3 + 1]; }
+      for (int r = 0; r < size; r++) {
+        if (!pst[(size_t)r * 4 + 2]) all_ok = false;
+        // every share must start where the shares before it end (a gap in one and an overlap in another could cancel in the sum)
+        if (pst[(size_t)r * 4 + 3] != entries) all_ok = false;
+        entries += pst[(size_t)r * 4 + 1];
+      }
       if (all_ok && entries == P_total + 1) {
         std::vector<uint64_t> sc;
         Dev sa_parse = C.allgatherv(share.p, pinfo[0] * 4, sc);
@@ -555,10 +630,10 @@ void run_rank(Shared &S, int rank, int device, const Job &J, RankResult &res) {
     res.st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   } catch (const Failure &f) {
     res.code = f.code; res.msg = f.msg;
-    S.bar.abort();
+    S.abort_all();
   } catch (const std::exception &e) {
     res.code = PFP_EHIP; res.msg = e.what();
-    S.bar.abort();
+    S.abort_all();
   }
   if (ctx) pfp_ctx_destroy(ctx);
 }
@@ -599,7 +674,7 @@ extern "C" int pfp_bigbwt_files_multi(int n_dev, const int *devices, const uint8
   std::vector<std::thread> th;
   for (int r = 0; r < n_dev; r++) th.emplace_back([&, r] { run_rank(S, r, dev[r], J, res[r]); });
   for (auto &t : th) t.join();
-  if (!loopback) for (auto c : S.comms) if (c) rccl.CommDestroy(c);
+  if (!loopback && !S.comms_gone) for (auto c : S.comms) if (c) rccl.CommDestroy(c);
   int code = PFP_OK;
   for (int r = 0; r < n_dev; r++)
     if (res[r].code != PFP_OK) {
@@ -607,5 +682,53 @@ extern "C" int pfp_bigbwt_files_multi(int n_dev, const int *devices, const uint8
       if (code == PFP_OK || res[r].msg.rfind("rank ", 0) == 0) { code = res[r].code; say(res[r].msg); }
     }
   if (code == PFP_OK && stats) *stats = res[0].st;
+  return code;
+}
+
+// One-GPU check of the RCCL transport (tests): the dlopen'ed table, the enum values and the group semantics, with a communicator
+// over ONE device - every exchange shape of the chain as a self send / recv, and the one-collective all-gather.
+extern "C" int pfp_multi_rccl_selftest(int device, char *errbuf, uint64_t errbuf_len) {
+  using namespace pfp;
+  auto say = [&](const std::string &m) { if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", m.c_str()); };
+  int have = 0;
+  if (hipGetDeviceCount(&have) != hipSuccess || device < 0 || device >= have) { say("no such HIP device"); return PFP_ENODEV; }
+  static Rccl rccl;
+  std::string err;
+  if (!rccl.load(err)) { say(err); return PFP_ENODEV; }
+  Shared S(1, false);
+  S.rccl = &rccl;
+  S.comms.assign(1, nullptr);
+  if (hipSetDevice(device) != hipSuccess) { say("hipSetDevice"); return PFP_EHIP; }
+  int rc = rccl.CommInitAll(S.comms.data(), 1, &device);
+  if (rc != 0) { say(std::string("ncclCommInitAll: ") + rccl.GetErrorString(rc)); return PFP_EHIP; }
+  int code = PFP_OK;
+  hipStream_t stream = nullptr;
+  try {
+    MG_HIP(hipStreamCreate(&stream));
+    Coll C(S, 0, stream);
+    const uint64_t n = (1u << 20) + 123;
+    std::vector<uint8_t> h(n), back(n);
+    for (uint64_t i = 0; i < n; i++) h[i] = (uint8_t)(i * 2654435761u >> 13);
+    Dev src(n + 16);
+    MG_HIP(hipMemcpy(src.p, h.data(), n, hipMemcpyHostToDevice));
+    auto same = [&](const Dev &d, uint64_t bytes, const char *what) {
+      MG_HIP(hipMemcpy(back.data(), d.p, bytes, hipMemcpyDeviceToHost));
+      if (memcmp(back.data(), h.data(), bytes) != 0) fail(PFP_EHIP, "RCCL self test: %s returned other bytes", what);
+    };
+    std::vector<uint64_t> counts;
+    for (int grouped = 0; grouped < 2; grouped++) {
+      C.force_grouped = grouped != 0;
+      { Dev out = C.allgatherv(src.p, n, counts); if (counts.size() != 1 || counts[0] != n) fail(PFP_EHIP, "RCCL self test: counts"); same(out, n, grouped ? "grouped all-gather" : "ncclAllGather"); }
+      { Dev out = C.allgatherv(src.p, 0, counts); (void)out; }      // an empty contribution
+    }
+    C.force_grouped = false;
+    { std::vector<uint64_t> send(1, n), recv; Dev out = C.alltoallv(src.p, send, recv); if (recv.size() != 1 || recv[0] != n) fail(PFP_EHIP, "RCCL self test: all-to-all counts"); same(out, n, "all-to-all"); }
+    { std::vector<uint64_t> send(1, 0), recv; Dev out = C.alltoallv(src.p, send, recv); (void)out; }
+  } catch (const Failure &f) {
+    code = f.code; say(f.msg);
+    S.abort_all();
+  }
+  if (stream) (void)hipStreamDestroy(stream);
+  if (!S.comms_gone) for (auto cm : S.comms) if (cm) rccl.CommDestroy(cm);
   return code;
 }

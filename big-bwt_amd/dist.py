@@ -291,9 +291,13 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
         torch.cuda.synchronize(dev)
         pinfo = step.run(lambda: ctx.dist_parse_sort(sym_all.data_ptr(), P_all, rank, size, share.data_ptr()))
         okp = pinfo is not None and pinfo["complete"]
-        pst = yield ("allgather", torch.tensor([pinfo["entries"] if okp else 0, 1 if okp else 0, int(step.status()[0])], dtype=torch.int64, device=dev))
+        pst = yield ("allgather", torch.tensor([pinfo["entries"] if okp else 0, 1 if okp else 0, int(step.status()[0]), pinfo["slot_base"] if okp else 0],
+                                               dtype=torch.int64, device=dev))
         step.check([t[2:3] for t in pst], "parse suffix sort")
-        if all(int(t[1]) for t in pst) and sum(int(t[0]) for t in pst) == P_all + 1:
+        # the shares must tile [0, P + 1): every one starts where those before it end (a gap in one and an overlap in another of
+        # the same size would pass a check of the sum alone)
+        starts_ok = all(int(t[3]) == sum(int(u[0]) for u in pst[:r]) for r, t in enumerate(pst))
+        if all(int(t[1]) for t in pst) and starts_ok and sum(int(t[0]) for t in pst) == P_all + 1:
             pieces = yield ("allgather", share[: pinfo["entries"]].contiguous())
             sa_parse = torch.cat(pieces).contiguous()
             torch.cuda.synchronize(dev)

@@ -193,6 +193,13 @@ int main(int argc, char **argv) {
     return 0;
   }
   if (gpus == 0) {   /* -G 0: every GPU this process can see */
+    /* (the Python ranks are started by fork + exec: this process must not have touched HIP before that - pfp_device_count
+     *  initialises it - so with PFP_MULTI_PYTHON the count has to be given) */
+    const char *py = getenv("PFP_MULTI_PYTHON");
+    if (py && atoi(py) != 0) {
+      fprintf(stderr, "-G 0 counts the devices through HIP, which the launcher of the Python ranks (PFP_MULTI_PYTHON=1) must not have initialised: pass -G N\n");
+      return 2;
+    }
     gpus = pfp_device_count() - device;
     if (gpus < 1) { fprintf(stderr, "Cannot initialise the GPU (no device %d): this tool has no CPU path\n", device); return 1; }
   }

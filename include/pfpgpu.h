@@ -359,6 +359,11 @@ typedef struct {
 int pfp_bigbwt_files_multi(int n_dev, const int *devices, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags,
                            uint64_t halo, const char *out_base, pfp_multi_stats *stats, char *errbuf, uint64_t errbuf_len);
 
+/* The RCCL transport of pfp_bigbwt_files_multi on ONE device (tests on a one-GPU box): librccl resolved with dlopen, a communicator
+ * from ncclCommInitAll over `device`, every exchange shape of the chain as a self send / recv inside a group, and the one-collective
+ * all-gather; returns PFP_OK when every byte came back. */
+int pfp_multi_rccl_selftest(int device, char *errbuf, uint64_t errbuf_len);
+
 /* ---- micro entry points used by bench.py's roofline leg and by the parity tests ---- */
 /* copy a device-resident text into the ctx's padded staging buffer (T' = Dollar.T.Dollar^w) */
 int pfp_stage_text_dev(pfp_ctx *ctx, const void *d_text, uint64_t n, int w);

@@ -511,6 +511,27 @@ def test_c_driver_multi_gpu_over_rccl(golden, O, tmp_path):
 
 
 @pytest.mark.gpu
+def test_rccl_transport_on_one_device(pkg):
+    """the native host's RCCL transport where only one GPU exists: librccl through the library's own dlopen table, a communicator
+    from ncclCommInitAll over cuda:0, and every exchange shape of the chain as a self send / recv - the grouped all-to-all, the
+    all-gather as ONE ncclAllGather and in its grouped send / recv form, empty contributions.  (What two GPUs add is the wire;
+    symbols, enum values and group semantics are settled here.)"""
+    import importlib
+    pfpmod = importlib.import_module("bigbwt_amd.pfp")
+    pfpmod.multi_rccl_selftest(0)
+
+
+def test_launcher_of_the_python_ranks_never_counts_devices(tmp_path):
+    """`bigbwt -G 0` counts the devices through HIP; under PFP_MULTI_PYTHON=1 the driver forks and execs the rank processes and
+    must not have initialised HIP before that, so the combination is refused before anything touches the GPU (CPU test)"""
+    import subprocess
+    f = tmp_path / "t.fa"
+    f.write_bytes(b"ACGT" * 1000)
+    out = subprocess.run([EXE, "-G", "0", str(f)], capture_output=True, text=True, timeout=120, env=dict(os.environ, PFP_MULTI_PYTHON="1"))
+    assert out.returncode == 2 and "pass -G N" in out.stderr, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
 def test_c_driver_python_ranks(golden, O, tmp_path):
     """PFP_MULTI_PYTHON=1: the same through N processes of dist_main.py under torch.distributed (gloo, one GPU)"""
     import subprocess

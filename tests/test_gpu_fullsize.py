@@ -182,6 +182,107 @@ def test_north_star_12_6_gb_with_sampled_sa(pkg, ctx, synth, golden_full):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("name", ["c1", "c1_gen"])
+def test_baseline_configs0_with_the_sacak_check(O, pkg, ctx, synth, golden_full, name):
+    """BASELINE configs[0] (the yeast-sized plumbing case): `bigbwt -w 10 -p 100 --sum -c` - the C driver's own whole-text SACA-K
+    BWT (simplebwt.c:28-100 -> pfp_sacak) must equal the .bwt ("BWTs match", bigbwt:177-194) and both the reference's digest.
+    c1 = the synth-family text, c1_gen = BASELINE.md section 5's literal GEN(12.1e6,1,0,1)."""
+    import subprocess
+    g = golden_full[name]
+    assert g["check_bwts_match"]
+    text = synth.workload_text_np("c1") if name == "c1" else O.gen_fasta(12_100_000, 1, 0.0, 1)
+    assert len(text) == g["n"] and hashlib.sha256(text.tobytes()).hexdigest() == g["text_sha256"]
+    f = "/dev/shm/pfp_c1_%s_%d" % (name, os.getpid())
+    try:
+        with open(f, "wb") as fh:
+            fh.write(text.tobytes())
+        exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "big-bwt_amd", "bigbwt")
+        out = subprocess.run([exe, "-w", str(g["w"]), "-p", str(g["p"]), "--sum", "-c", f], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "BWTs match" in out.stdout and g["bwt_sha256"] in out.stdout, out.stdout
+        with open(f + ".bwt", "rb") as fh:
+            assert hashlib.sha256(fh.read()).hexdigest() == g["bwt_sha256"]
+    finally:
+        for ext in ("", ".bwt", ".Bwt", ".log"):
+            if os.path.exists(f + ext):
+                os.unlink(f + ext)
+
+
+def test_full_sa_with_values_beyond_4g(pkg, ctx, synth, golden_full):
+    """BASELINE configs[3]'s flag set (-w 10 -p 100 -S) where the 5-byte integers matter: 512 copies, 6.3 GB > 2^32 bytes, two
+    thousand million SA values with a non-zero fifth byte (utils.c:112-129).  The 31.5 GB .sa of pfp_bigbwt_formats_dev and the
+    .bwt against the digests of the reference's files (tests/golden/make_golden_huge.py big_S: 25 minutes of one core)."""
+    import torch
+    if "big_S" not in golden_full:
+        pytest.skip("no reference digest committed for this workload")
+    g = golden_full["big_S"]
+    assert g["sa_values_over_4g"] > 10**9 and g["sa_bytes"] == 5 * g["n"]
+    dev = torch.device("cuda", 0)
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 230 * (1 << 30):
+        pytest.skip("needs about 230 GB of free device memory")
+    ctx.pool_trim()
+    text = synth.workload_text_torch(dev, "big_S")
+    torch.cuda.empty_cache()
+    assert text.numel() == g["n"] and sha_dev(text) == g["text_sha256"]
+    try:
+        n = text.numel()
+        bwt = torch.empty(n + 17, dtype=torch.uint8, device=dev)
+        used, outs = ctx.bigbwt_formats_dev(text.data_ptr(), n, bwt.data_ptr(), g["w"], g["p"], g["flags"])
+        del text
+        assert used == n and set(outs) == {"sa"}
+        assert sha_dev(bwt[: n + 1]) == g["bwt_sha256"]
+        ptr, nbytes = outs["sa"]
+        assert nbytes == g["sa_bytes"]
+        h = hashlib.sha256()
+        top = 0
+        for off in range(0, nbytes, 5 << 26):          # (pieces of whole 5-byte values)
+            piece = ctx.fetch_dev(ptr + off, min(5 << 26, nbytes - off))
+            h.update(piece.tobytes())
+            top = max(top, int(piece[4::5].max()))
+        ctx.dev_free(ptr)
+        assert top == g["sa_top_byte_max"] and h.hexdigest() == g["sa_sha256"]
+    finally:
+        ctx.pool_trim()
+        torch.cuda.empty_cache()
+
+
+def test_full_sa_beyond_4g_on_8_ranks(pkg, ctx, synth, golden_full, monkeypatch):
+    """the same 6.3 GB -S job through the multi-GPU chain: 8 rank threads of pfp_bigbwt_files_multi on this card, every rank
+    packs and pwrites its range of the 31.5 GB .sa (values above 2^32 in most ranges)"""
+    import importlib
+    import torch
+    if "big_S" not in golden_full:
+        pytest.skip("no reference digest committed for this workload")
+    g = golden_full["big_S"]
+    dev = torch.device("cuda", 0)
+    free, _total = torch.cuda.mem_get_info(dev)
+    vfs = os.statvfs("/dev/shm")
+    if free < 230 * (1 << 30) or vfs.f_bavail * vfs.f_frsize < 48 * (1 << 30):
+        pytest.skip("needs about 230 GB of free device memory and 48 GB in /dev/shm")
+    ctx.pool_trim()
+    text = synth.workload_text_torch(dev, "big_S").cpu().numpy()
+    torch.cuda.empty_cache()
+    assert len(text) == g["n"]
+    monkeypatch.setenv("PFP_MULTI_LOOPBACK", "1")
+    pfpmod = importlib.import_module("bigbwt_amd.pfp")
+    base = "/dev/shm/pfp_multi_bigS_%d" % os.getpid()
+    try:
+        st = pfpmod.bigbwt_files_multi(text, base, [0] * 8, g["w"], g["p"], g["flags"])
+        del text
+        assert st["ranks"] == 8 and st["n"] == g["n"]
+        for key, ext in (("bwt", ".bwt"), ("sa", ".sa")):
+            h = hashlib.sha256()
+            with open(base + ext, "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 26), b""):
+                    h.update(blk)
+            assert os.path.getsize(base + ext) == g[key + "_bytes"] and h.hexdigest() == g[key + "_sha256"], ext
+    finally:
+        for ext in (".bwt", ".sa"):
+            if os.path.exists(base + ext):
+                os.unlink(base + ext)
+
+
 def test_pack_and_sample_exports_on_slices(O, pkg, ctx):
     """pfp_pack5_dev / pfp_sample_runs_dev: slices with one halo byte on each side concatenate to the whole file"""
     import torch

@@ -25,15 +25,19 @@ for bits in (0, 64):
     if bits:
         ctx.set_index_bits(64)
     bwt = torch.empty(n + 1 + 16, dtype=torch.uint8, device=dev)
-    t0 = time.perf_counter()
-    used = ctx.bigbwt_dev(text.data_ptr(), n, bwt.data_ptr(), None, wl["w"], wl["p"], 0)
-    torch.cuda.synchronize()
+    secs = []
+    for call in range(2):          # the first call pays for the pool's driver allocations, the second runs on cached blocks
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        used = ctx.bigbwt_dev(text.data_ptr(), n, bwt.data_ptr(), None, wl["w"], wl["p"], 0)
+        torch.cuda.synchronize()
+        secs.append(round(time.perf_counter() - t0, 3))
     h = hashlib.sha256()
     for s in range(0, n + 1, 1 << 28):
         h.update(bwt[s:min(s + (1 << 28), n + 1)].cpu().numpy().tobytes())
     st = ctx.stats()
-    out[str(bits)] = dict(sha=h.hexdigest(), s=round(time.perf_counter() - t0, 3), index_bits=st["index_bits"], dict_bytes=st["dict_size"],
-                          peak=ctx.mem_stats()["peak"], used=used == n)
+    out[str(bits)] = dict(sha=h.hexdigest(), s_cold=secs[0], s_warm=secs[1], index_bits=st["index_bits"], dict_bytes=st["dict_size"],
+                          sa_rounds_dict=st["sa_rounds_dict"], ms_sa_dict=round(st["ms_sa_dict"], 1), peak=ctx.mem_stats()["peak"], used=used == n)
     del bwt
     ctx.close()
     torch.cuda.empty_cache()
