@@ -16,6 +16,7 @@ struct StagedText {
   const uint8_t *tbase() const { return buf.p + kFront; }        // T[i]
   const uint8_t *tprime() const { return buf.p + kFront - 1; }   // T'[x]
   void stage(pfp_ctx *c, const void *src, bool src_on_device, uint64_t n_, int w_);
+  void stage_fd(pfp_ctx *c, int fd, uint64_t file_off, uint64_t n_, int w_);      // host text read from an open file (parallel pread)
   void restage_tail(pfp_ctx *c, uint64_t new_n, int w_) const;    // Dollars at [new_n,new_n+w), zeros after
 };
 
@@ -80,6 +81,18 @@ template <> struct IdxTraits<uint64_t> { using DKey = unsigned __int128; static 
 // (the reference goes to its 64-bit build at 2^31 - 4 already, bigbwt:130; unsigned 32-bit positions reach twice as far, and
 // the wide build needs 8 bytes where this one needs 4)
 inline bool use_wide_index(const pfp_ctx *c, uint64_t dsize) { return c->force_wide || dsize >= 0xFFFFFFF0ull; }
+// Dictionaries of 2^31 .. 2^32 bytes on one GPU (round 4): 32-bit positions still fit, but not with the sorter's "settled" flag in
+// their top bit - the narrow build then has doubling rounds only (2.0 s for a 2.4 GB dictionary of 3 % variants); the wide build
+// keeps its pivot rounds (1.25 s) at ~96 bytes of device memory per dictionary byte.  Width by cost: wide where that much memory
+// is there (free on the device + cached in the pool), narrow otherwise.  profiles/r04_dictionary_2_to_4_gib.json
+inline bool prefer_wide_index(const pfp_ctx *c, uint64_t dsize) {
+  if (use_wide_index(c, dsize)) return true;
+  if (dsize < (1ull << 31) || c->force_narrow) return false;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const uint64_t avail = (uint64_t)free_b + (c->pool.total_bytes - c->pool.live_bytes);
+  return avail >= dsize * 100ull;
+}
 
 template <class I>
 struct SuffixOrderT {

@@ -1,6 +1,7 @@
 // pipeline.hip -- orchestration of the parse -> SA -> BWT chain and the extern "C" boundary
 // (include/pfpgpu.h).  The chain mirrors bigbwt:69-156 (newscan -> bwtparse -> pfbwt) but every
 // intermediate stays in HBM; the staged entry points ingest/emit the reference's file formats.
+#include <atomic>
 #include "kernels.hpp"
 #include "prims.hpp"
 #include "devutil.hpp"
@@ -9,6 +10,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <cerrno>
 #include <thread>
 #include <mutex>
@@ -36,9 +38,37 @@ static void par_memcpy(void *dst, const void *src, size_t len) {
   for (auto &t : th) t.join();
 }
 
+// the same from a file: a few threads pread their parts straight into the (pinned) destination - one copy out of the page
+// cache and no page-table work, where an mmap'ed source costs a fault per 4 KB page (12.6 GB in /dev/shm: 2 GB/s through the
+// mapping, an order of magnitude more through pread)
+static void par_pread(int fd, uint64_t file_off, void *dst, size_t len) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  static const size_t tmax = []() { const char *e = getenv("PFP_READ_THREADS"); return e ? (size_t)atoi(e) : (size_t)8; }();
+  const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(tmax, hw ? hw : 1), len >> 21));
+  std::atomic<int> bad{0};
+  auto work = [&](size_t off, size_t l) {
+    size_t done = 0;
+    while (done < l) {
+      const ssize_t r = pread(fd, (uint8_t *)dst + off + done, l - done, (off_t)(file_off + off + done));
+      if (r <= 0) { bad.store(r == 0 ? -1 : errno ? errno : -1); return; }
+      done += (size_t)r;
+    }
+  };
+  if (T <= 1) work(0, len);
+  else {
+    std::vector<std::thread> th;
+    const size_t part = (len / T + 4095) & ~size_t(4095);
+    for (size_t k = 0; k < T && k * part < len; k++) th.emplace_back(work, k * part, std::min(part, len - k * part));
+    for (auto &t : th) t.join();
+  }
+  PFP_REQUIRE(bad.load() == 0, PFP_EINVAL, bad.load() == -1 ? std::string("input file is shorter than announced") : std::string("reading the input: ") + strerror(bad.load()));
+}
+
 static void ensure_pinned(pfp_ctx *c) {
   for (int k = 0; k < 2; k++) {
-    if (!c->pin[k]) PFP_HIP(hipHostMalloc(&c->pin[k], pfp_ctx::kPinBytes, hipHostMallocDefault));
+    // (PFP_PIN_NONCOHERENT=1: host-cacheable staging buffers - the CPU fills them, the copy engine reads them)
+    static const unsigned pin_flags = getenv("PFP_PIN_NONCOHERENT") ? hipHostMallocNonCoherent : hipHostMallocDefault;
+    if (!c->pin[k]) PFP_HIP(hipHostMalloc(&c->pin[k], pfp_ctx::kPinBytes, pin_flags));
     if (!c->pin_ev[k]) PFP_HIP(hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming));
   }
 }
@@ -69,14 +99,25 @@ template <class Fill>
 static void stream_h2d(pfp_ctx *c, uint8_t *d_dst, uint64_t nbytes, Fill &&fill) {
   ensure_pinned(c);
   const uint64_t CH = pfp_ctx::kPinBytes;
+  static const bool trace_host = getenv("PFP_TRACE_HOST") != nullptr;
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  double t_wait = 0, t_fill = 0, t_issue = 0;
   int k = 0;
   for (uint64_t off = 0; off < nbytes; off += CH, k ^= 1) {
     const uint64_t len = std::min<uint64_t>(CH, nbytes - off);
+    const auto a0 = now();
     if (off >= 2 * CH) PFP_HIP(hipEventSynchronize(c->pin_ev[k]));      // the copy that last used this buffer is done
+    const auto a1 = now();
     fill((uint8_t *)c->pin[k], off, len);
+    const auto a2 = now();
     PFP_HIP(hipMemcpyAsync(d_dst + off, c->pin[k], len, hipMemcpyHostToDevice, c->stream));
     PFP_HIP(hipEventRecord(c->pin_ev[k], c->stream));
+    if (trace_host) { t_wait += secs(a0, a1); t_fill += secs(a1, a2); t_issue += secs(a2, now()); }
   }
+  if (trace_host && nbytes >= (64u << 20))
+    fprintf(stderr, "[pfp] host -> device, %.2f GB in %llu-MB pieces: filling the pinned buffers %.3f s, waiting for the copy engine %.3f s, issuing %.3f s\n",
+            nbytes / 1e9, (unsigned long long)(CH >> 20), t_fill, t_wait, t_issue);
 }
 
 void StagedText::stage(pfp_ctx *c, const void *src, bool src_on_device, uint64_t n_, int w_) {
@@ -88,6 +129,15 @@ void StagedText::stage(pfp_ctx *c, const void *src, bool src_on_device, uint64_t
   if (n && src_on_device) PFP_HIP(hipMemcpyAsync(buf.p + kFront, src, n, hipMemcpyDeviceToDevice, c->stream));
   if (n && !src_on_device)      // pageable host text (a caller's buffer, an mmap of the input file): chunks through pinned buffers
     stream_h2d(c, buf.p + kFront, n, [&](uint8_t *pin, uint64_t off, uint64_t len) { par_memcpy(pin, (const uint8_t *)src + off, len); });
+  restage_tail(c, n, w);
+}
+void StagedText::stage_fd(pfp_ctx *c, int fd, uint64_t file_off, uint64_t n_, int w_) {
+  n = n_; w = w_;
+  size_t total = kFront + n + (size_t)w + kBack;
+  buf.alloc(c, total);
+  PFP_HIP(hipMemsetAsync(buf.p, 0, kFront - 1, c->stream));
+  PFP_HIP(hipMemsetAsync(buf.p + kFront - 1, kDollar, 1, c->stream));
+  if (n) stream_h2d(c, buf.p + kFront, n, [&](uint8_t *pin, uint64_t off, uint64_t len) { par_pread(fd, file_off + off, pin, len); });
   restage_tail(c, n, w);
 }
 void StagedText::restage_tail(pfp_ctx *c, uint64_t new_n, int w_) const {
@@ -221,7 +271,7 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
     // BWT only: the merge records ride in the spare bits of the first-round keys (SuffixOrder::paybits)
     const WordView wv = word_view(ch.D, ch.ix);
     const SlotPayloadSrc pay{wv, ch.D.wocc.p, w};
-    ch.ord.wide = use_wide_index(c, ch.D.dsize);      // 32- or 64-bit dictionary positions (bigbwt:130-151)
+    ch.ord.wide = prefer_wide_index(c, ch.D.dsize);      // 32- or 64-bit dictionary positions (bigbwt:130-151)
     with_width(ch.ord.wide, [&](auto tag) {
       using I = decltype(tag);
       auto &so = ch.ord.get<I>();
@@ -341,6 +391,19 @@ static void write_dev_file(pfp_ctx *c, const std::string &path, uint64_t file_of
   if (trunc && nbytes) (void)!ftruncate(fd, (off_t)(file_offset + nbytes));      // the final size at once: the writers only fill pages
   bool ok = true;
   std::string werr;
+  // (round 4, measured and dropped: a shared mapping of the output file filled by eight threads - buffered pwrite()s to one file
+  //  serialise on the inode - was SLOWER into /dev/shm, 2.9-3.3 s against 1.95 s for 13.7 GB: faulting fresh pages in through a
+  //  mapping costs more than the write path's own allocation.  gpurun_out/r4_cli_probe2.txt -> profiles/r04_cli_probe.txt)
+  try {
+        stream_d2h(c, d_src, nbytes, [&](const uint8_t *h, uint64_t off, uint64_t len) { par_memcpy((uint8_t *)m + skew + off, h, len); });
+      } catch (...) { munmap(m, nbytes + skew); close(fd); throw; }
+      sync(c);
+      munmap(m, nbytes + skew);
+      PFP_REQUIRE(close(fd) == 0, PFP_EINVAL, "error writing " + path);
+      return;
+    }
+    // (no mapping - a pipe, a filesystem without mmap: the pwrite path below)
+  }
   try {
     // a chunk can be written by several threads, each its own range at its own offset (PFP_PWRITE_THREADS; pfthreads.hpp:369-376
     // has every worker pwrite its range).  Default one: on tmpfs more writers only contend (1.1 GB: 172 ms with one
@@ -519,8 +582,9 @@ int pfp_get_kernel_trace(pfp_ctx *c, pfp_kernel_stat *out, int cap) {
 void pfp_set_max_phrase(pfp_ctx *c, uint64_t max_phrase) { if (c) c->max_phrase = max_phrase; }
 void pfp_set_window_hash(pfp_ctx *c, int fast) { if (c) c->fast_triggers = fast != 0; }
 int pfp_set_index_bits(pfp_ctx *c, int bits) {
-  if (!c || (bits != 0 && bits != 64)) return PFP_EINVAL;
+  if (!c || (bits != 0 && bits != 32 && bits != 64)) return PFP_EINVAL;
   c->force_wide = bits == 64;
+  c->force_narrow = bits == 32;
   return PFP_OK;
 }
 int pfp_get_stats(const pfp_ctx *c, pfp_stats *st) {
@@ -1080,9 +1144,9 @@ void pfp_dev_free(pfp_ctx *c, void *d_ptr) {
 
 // file to files: the host text (an mmap of the input works) is streamed in, the outputs are streamed from HBM
 // straight into <base>.bwt / .sa / .ssa / .esa - no host copy of any output is held
-int pfp_bigbwt_files(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags, const char *base,
-                     uint64_t out_bytes[4]) {
-  if (!c || (!text && n) || !base) return PFP_EINVAL;
+}  // extern "C"
+template <class Stage>
+static int bigbwt_to_files(pfp_ctx *c, uint64_t n, int w, uint64_t p, int flags, const char *base, uint64_t out_bytes[4], Stage &&stage) {
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
   check_args(w, p, flags);
@@ -1091,7 +1155,7 @@ int pfp_bigbwt_files(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t0 = now();
   Chain ch;
-  ch.tx.stage(c, text, false, n, w);
+  stage(ch.tx);
   if (trace_host) sync(c);
   const auto t1 = now();
   DBuf<uint8_t> d_bwt(c, n + 1 + 16);
@@ -1109,6 +1173,19 @@ int pfp_bigbwt_files(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_
   if (out_bytes) memcpy(out_bytes, sizes, sizeof sizes);
   return PFP_OK;
   PFP_CATCH(c)
+}
+extern "C" {
+int pfp_bigbwt_files(pfp_ctx *c, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags, const char *base,
+                     uint64_t out_bytes[4]) {
+  if (!c || (!text && n) || !base) return PFP_EINVAL;
+  return bigbwt_to_files(c, n, w, p, flags, base, out_bytes, [&](StagedText &tx) { tx.stage(c, text, false, n, w); });
+}
+// the same with the text read from bytes [file_offset, file_offset + n) of an open file (parallel pread into the pinned
+// staging buffers: what the C driver uses for a plain input file)
+int pfp_bigbwt_fd(pfp_ctx *c, int fd, uint64_t file_offset, uint64_t n, int w, uint64_t p, int flags, const char *base,
+                  uint64_t out_bytes[4]) {
+  if (!c || fd < 0 || !base) return PFP_EINVAL;
+  return bigbwt_to_files(c, n, w, p, flags, base, out_bytes, [&](StagedText &tx) { tx.stage_fd(c, fd, file_offset, n, w); });
 }
 
 }  // extern "C"

@@ -42,7 +42,6 @@ constexpr int kSub = kTh * kItems;            // 4096 elements ranked and staged
 constexpr int kSuper = 4;                     // sub-tiles per workgroup: one row of the count matrix per 16 K elements
 constexpr uint32_t kTile = kSub * kSuper;
 constexpr uint32_t kCap = 4096;               // elements a bucket sort holds in LDS
-constexpr uint32_t kOvfCap = 4096;            // oversize buckets remembered before the library takes the whole array
 
 struct Tiles {                                // device view of a pass's segments and tiles
   const uint64_t *seg_begin, *seg_end;        // [nseg] disjoint ranges of the array

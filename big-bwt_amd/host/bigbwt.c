@@ -152,6 +152,7 @@ static void usage(const char *argv0) {
 }
 
 int main(int argc, char **argv) {
+  const double t_main = now_s();
   int w = 10, th = 0, s = 0, e = 0, S = 0, keep = 0, verbose = 0, check = 0, fasta = 0, sum = 0, parsing = 0,
       compress = 0, device = 0, gpus = 1;
   unsigned long long p = 100, halo = 1ull << 20;
@@ -215,6 +216,7 @@ int main(int argc, char **argv) {
 
   uint64_t n = 0;
   const uint8_t *text = NULL;
+  int fd_in = -1;
   if (fasta) {      /* newscan.cpp:332-352: gzopen + kseq, sequences only */
     size_t raw_n = 0;
     uint8_t *raw = pfp_read_maybe_gz(input, &raw_n);
@@ -225,11 +227,12 @@ int main(int argc, char **argv) {
     free(raw);
     text = seq;
   } else {
-    int fd = open(input, O_RDONLY);
+    fd_in = open(input, O_RDONLY);
     struct stat sb;
-    if (fd < 0 || fstat(fd, &sb) != 0) { perror(input); return 1; }
+    if (fd_in < 0 || fstat(fd_in, &sb) != 0) { perror(input); return 1; }
     n = (uint64_t)sb.st_size;
-    text = n ? mmap(NULL, n, PROT_READ, MAP_PRIVATE, fd, 0) : (const uint8_t *)"";
+    /* (the mapping is what the staged entry points, -G N and -c read; the plain single-GPU run reads the file with pread) */
+    text = n ? mmap(NULL, n, PROT_READ, MAP_PRIVATE, fd_in, 0) : (const uint8_t *)"";
     if (text == MAP_FAILED) { perror("mmap"); return 1; }
   }
 
@@ -285,7 +288,9 @@ int main(int argc, char **argv) {
   }
 
   pfp_ctx *ctx = NULL;
+  const double t_ctx0 = now_s();
   int rc = pfp_ctx_create(&ctx, device);
+  if (getenv("PFP_TRACE_HOST")) fprintf(stderr, "[pfp] driver: context after %.3f s (pfp_ctx_create %.3f s)\n", now_s() - t_main, now_s() - t_ctx0);
   if (rc) {
     fprintf(stderr, "Cannot initialise the GPU (%s): this tool has no CPU path\n", pfp_strerror(rc));
     return 1;
@@ -369,7 +374,7 @@ int main(int argc, char **argv) {
      * into input.bwt / .sa / .ssa / .esa: no output is held in host memory */
     printf("==== Parsing, BWT of parsing, final BWT on the GPU. Command: pfp_bigbwt_files(%s, -w %d -p %llu%s%s%s)\n", input, w,
            p, s ? " -s" : "", e ? " -e" : "", S ? " -S" : "");
-    rc = pfp_bigbwt_files(ctx, text, n, w, p, flags, input, NULL);
+    rc = fd_in >= 0 ? pfp_bigbwt_fd(ctx, fd_in, 0, n, w, p, flags, input, NULL) : pfp_bigbwt_files(ctx, text, n, w, p, flags, input, NULL);
     if (rc) goto fail;
     pfp_stats st;
     pfp_get_stats(ctx, &st);
@@ -423,7 +428,11 @@ int main(int argc, char **argv) {
 done:
   printf("==== Done\n");
   fclose(logf);
-  pfp_ctx_destroy(ctx);
+  {
+    const double t_d0 = now_s();
+    pfp_ctx_destroy(ctx);
+    if (getenv("PFP_TRACE_HOST")) fprintf(stderr, "[pfp] driver: pfp_ctx_destroy %.3f s, main() %.3f s\n", now_s() - t_d0, now_s() - t_main);
+  }
   return status ? 1 : 0;
 fail:
   /* bigbwt:235-239 */

@@ -159,6 +159,12 @@ int pfp_bigbwt(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p,
  * written {bwt, sa, ssa, esa}. */
 int pfp_bigbwt_files(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags,
                      const char *base, uint64_t out_bytes[4]);
+/* The same with the text taken from bytes [file_offset, file_offset + n) of an open file descriptor instead of a host buffer:
+ * a few threads pread() straight into the pinned staging buffers (an mmap'ed input costs a page fault per 4 KB: 2 GB/s for a
+ * 12.6 GB file in /dev/shm, where this reads at the rate of the PCIe link).  What host/bigbwt.c calls for a plain input file
+ * (the reference's parsers read theirs with fread / getc: newscan.cpp:355-377). */
+int pfp_bigbwt_fd(pfp_ctx *ctx, int fd, uint64_t file_offset, uint64_t n, int w, uint64_t p, int flags, const char *out_base,
+                  uint64_t out_bytes[4]);
 
 /* Device-resident variant: d_text is a device pointer to n bytes; d_bwt must hold n+1 bytes.
  * Optional device outputs (may be NULL unless the flag is set):
@@ -245,7 +251,10 @@ void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
 void pfp_set_window_hash(pfp_ctx *ctx, int fast);
 /* Index width of dictionary positions and suffix-array slots: 0 = by size (32 bits below 4 GiB of dictionary /
  * text, 64 above: the reference's choice between its 32-bit and -DM64 executables, bigbwt:109-151), 64 = always
- * the wide build (what PFP_FORCE_IDX64=1 in the environment sets at pfp_ctx_create).  Outputs are identical. */
+ * the wide build (what PFP_FORCE_IDX64=1 in the environment sets at pfp_ctx_create), 32 = the narrow build wherever its positions
+ * fit.  By size means: narrow below 2^31 bytes of dictionary, wide from 2^32 - 16 on, and in between the wide build where ~96 bytes
+ * of device memory per dictionary byte are free (it keeps the sorter's pivot rounds there; the narrow build has no spare bit in a
+ * position for them), else the narrow one.  Outputs are identical. */
 int pfp_set_index_bits(pfp_ctx *ctx, int bits);
 
 /* ------------------------------------------------------------------------------------

@@ -339,6 +339,29 @@ def test_dictionary_over_4gib_takes_the_wide_build():
 
 
 @pytest.mark.gpu
+def test_dictionary_between_2_and_4_gib_on_one_gpu():
+    """200 copies at 3 % SNPs: a 2.4 GB dictionary (>= 2^31, < 2^32 bytes) on ONE GPU.  The narrow build has no spare bit in a
+    position for the sorter's settled flag there (doubling rounds only: 2.0 s); by size the chain now takes the wide build where
+    its ~96 bytes per dictionary byte are free (pivot rounds: 1.25 s) - the reference switches to its 64-bit executables at
+    2^31 - 4 too (bigbwt:130).  All three selections give the same BWT; the automatic one is bounded in time."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    free, _total = torch.cuda.mem_get_info(torch.device("cuda", 0))
+    if free < 250 * (1 << 30):
+        pytest.skip("needs about 250 GB of free device memory")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_width_agree.py"), "wide31"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    r = j["runs"]
+    assert j["agree"] and (1 << 31) <= r["0"]["dict_bytes"] < (1 << 32)
+    assert r["0"]["index_bits"] == 64 and r["32"]["index_bits"] == 32 and r["64"]["index_bits"] == 64
+    assert r["0"]["s_warm"] <= 1.6, r          # (1.25 s measured; the narrow build's doubling rounds take 2.0 s)
+
+
+@pytest.mark.gpu
 def test_union_dictionary_between_2_and_4_gib_across_ranks():
     """Multi-GPU chain, union dictionary of 2.4 GB (>= 2^31 bytes, < 2^32): the 32-bit build has no spare bit in a position for the
     sorter's settled flag there and a share of the suffix array cannot fall back on doubling rounds, so the shares take the wide

@@ -20,10 +20,10 @@ wl = synth.WORKLOADS[name]
 text = synth.workload_text_torch(dev, name)
 n = text.numel()
 out = {}
-for bits in (0, 64):
+for bits in (0, 32, 64):
     ctx = pkg.Context(0)
     if bits:
-        ctx.set_index_bits(64)
+        ctx.set_index_bits(bits)
     bwt = torch.empty(n + 1 + 16, dtype=torch.uint8, device=dev)
     secs = []
     for call in range(2):          # the first call pays for the pool's driver allocations, the second runs on cached blocks
@@ -41,6 +41,6 @@ for bits in (0, 64):
     del bwt
     ctx.close()
     torch.cuda.empty_cache()
-ok = out["0"]["sha"] == out["64"]["sha"]
+ok = out["0"]["sha"] == out["64"]["sha"] == out["32"]["sha"]
 print(json.dumps(dict(workload=name, n=n, agree=ok, runs=out)))
 sys.exit(0 if ok else 1)
