@@ -393,17 +393,7 @@ static void write_dev_file(pfp_ctx *c, const std::string &path, uint64_t file_of
   std::string werr;
   // (round 4, measured and dropped: a shared mapping of the output file filled by eight threads - buffered pwrite()s to one file
   //  serialise on the inode - was SLOWER into /dev/shm, 2.9-3.3 s against 1.95 s for 13.7 GB: faulting fresh pages in through a
-  //  mapping costs more than the write path's own allocation.  gpurun_out/r4_cli_probe2.txt -> profiles/r04_cli_probe.txt)
-  try {
-        stream_d2h(c, d_src, nbytes, [&](const uint8_t *h, uint64_t off, uint64_t len) { par_memcpy((uint8_t *)m + skew + off, h, len); });
-      } catch (...) { munmap(m, nbytes + skew); close(fd); throw; }
-      sync(c);
-      munmap(m, nbytes + skew);
-      PFP_REQUIRE(close(fd) == 0, PFP_EINVAL, "error writing " + path);
-      return;
-    }
-    // (no mapping - a pipe, a filesystem without mmap: the pwrite path below)
-  }
+  //  mapping costs more than the write path's own allocation.  profiles/r04_cli_probe_mmap_output.txt)
   try {
     // a chunk can be written by several threads, each its own range at its own offset (PFP_PWRITE_THREADS; pfthreads.hpp:369-376
     // has every worker pwrite its range).  Default one: on tmpfs more writers only contend (1.1 GB: 172 ms with one
