@@ -74,8 +74,11 @@ def pass_rows(st, w, flags, n_slice, P_merge, D_slots, R, t_hash, t_formats, ms_
     b_merge = n_slice + 12 * D_slots + 5 * (P_merge + 1) + 8 * H
     if flags & 1:
         b_merge += 10 * n_slice
+    b_merge_moved = b_merge
     if flags & 6:
         b_merge += 10 * (R.get("ssa", 0) + R.get("esa", 0)) + 5 * n_slice
+        # (8d's "5 n gathered from bwsai" is what a merge that computes every SA value reads; the sparse SA reads 16 bytes per RUN)
+        b_merge_moved += 10 * (R.get("ssa", 0) + R.get("esa", 0)) + 16 * max(R.get("ssa", 0), R.get("esa", 0))
     t_merge = st["ms_merge"] + t_formats
 
     def row(nbytes, ms):
@@ -86,6 +89,7 @@ def pass_rows(st, w, flags, n_slice, P_merge, D_slots, R, t_hash, t_formats, ms_
     passes = {"scan (K1+K2: n + 8P)": row(b_scan, st["ms_scan"]),
               "phrase hash (n + wP + 8P)": row(b_hash, t_hash),
               "merge ((n+1) + 12|D| + 5(P+1) + 8H [+ SA terms]; incl. run sampling / packing)": row(b_merge, t_merge),
+              "merge, counting only what the sparse SA moves (16 B per run instead of 8d's 5 n)": row(b_merge_moved, t_merge),
               "scan + merge": row(b_scan + b_merge, st["ms_scan"] + t_merge),
               "end to end floor (2n)": row(2 * nn, ms_per_step)}
     bad = [k for k, v in passes.items() if v and v["frac"] > 1.0]
@@ -212,8 +216,10 @@ def cli_leg(text, w, p, flags, gold, ctx=None):
                                  start_context_teardown_s=round(cli_s - ti - ch - fo, 3))
         return dict(MBps_process=round(n / cli_s / 1e6, 1), seconds_process=round(cli_s, 3),
                     seconds_construction=float(inner[0].split(":")[1]) if inner else None, outputs_ok=bool(ok), split=split,
-                    note="bigbwt (C driver), cold process, file in /dev/shm: mmap -> chunked pinned H2D -> chain -> outputs streamed from HBM into the files; "
-                         "fresh device memory costs ~30 ms per GB on this driver (tools/microbench/alloc.hip), which a one-shot process pays for its whole pool")
+                    note="bigbwt (C driver), cold process, file in /dev/shm: parallel pread into pinned chunks -> H2D -> chain -> outputs streamed from HBM "
+                         "into the files (one buffered writer per file: ~6-7 GB/s into a memory file system); device memory another process has just freed "
+                         "costs ~30 ms per GB when it is handed out again (tools/microbench/alloc.hip): on an idle card the 12.6 GB run takes 3.5 s "
+                         "(profiles/r04_cli_probe_knobs.txt)")
     finally:
         shutil.rmtree(tmpd, ignore_errors=True)
 
@@ -465,6 +471,8 @@ def main():
             cpu, ref = cpu_baseline(host, w, p, flags, O, threads)
             cpu["threads_passed"] = threads
             cpu["host_affinity_count"] = affinity
+            cpu["cores_note"] = (f"-t {threads} of the {affinity} hardware threads this process may run on (a one-GPU box shares its host: 16 cores per GPU); "
+                                 "with -s / -e the reference's last stage is single-threaded whatever -t says (bigbwt:132,141)")
             got = ctx.bigbwt(host, w, p, flags)           # the same sample through the HIP path: bit-exact?
             parity_sample = {k: bool(np.array_equal(got[k], ref[k])) for k in ref if k in got}
         out = {

@@ -1048,7 +1048,11 @@ __global__ __launch_bounds__(256) void hard_classify_kernel(MergeArgsT<I> a, con
   }
   // fallback (the kernels that rank every occurrence): no dominating char, a long minority list (its occurrences
   // would be ranked one after the other), too many distinct chars
-  const bool fb = many || minor * 4 > E || mm_max > 1024;
+  // ... or a minority that is cheap per occurrence but meets too many members: every minority occurrence is ranked against every
+  // member of the group (hard_minor_kernel: minor x k list checks), which is nothing for a phrase and its variants and quadratic
+  // for the words of a satellite array - 17 K near-identical monomers, 2 % of them with another preceding char: 0.02 k^2 = 6 M
+  // checks per group where ranking all k occurrences by sorting costs k log k (round 4, the c2r workload: 200 ms -> 3 ms)
+  const bool fb = many || minor * 4 > E || mm_max > 1024 || minor * k > 16 * E + 4096;
   const bool in_slice = !(base + E <= a.out_lo || base >= a.out_hi);
   fallback[h] = (fb && in_slice) ? 1 : 0;
   gmaj[g] = fb ? 0 : (uint8_t)mc;

@@ -485,6 +485,7 @@ int pfp_ctx_create(pfp_ctx **out, int device) {
     c->debug = dbg && dbg[0] && dbg[0] != '0';
     { const char *fw = getenv("PFP_FORCE_IDX64"); c->force_wide = fw && fw[0] && fw[0] != '0'; }
     { const char *wh = getenv("PFP_WINDOW_HASH"); if (wh && !strcmp(wh, "kr")) c->fast_triggers = false; }
+    { const char *pd = getenv("PFP_PARSE_DENSITY"); if (pd && atof(pd) >= 0.01 && atof(pd) <= 64.0) c->parse_density = atof(pd); }
     (void)hipGetLastError();
   } catch (const pfp::Error &e) {
     (void)hipGetLastError();
@@ -571,6 +572,11 @@ int pfp_get_kernel_trace(pfp_ctx *c, pfp_kernel_stat *out, int cap) {
 }
 void pfp_set_max_phrase(pfp_ctx *c, uint64_t max_phrase) { if (c) c->max_phrase = max_phrase; }
 void pfp_set_window_hash(pfp_ctx *c, int fast) { if (c) c->fast_triggers = fast != 0; }
+int pfp_set_parse_density(pfp_ctx *c, double density) {
+  if (!c || !(density >= 0.01 && density <= 64.0)) return PFP_EINVAL;
+  c->parse_density = density;
+  return PFP_OK;
+}
 int pfp_set_index_bits(pfp_ctx *c, int bits) {
   if (!c || (bits != 0 && bits != 32 && bits != 64)) return PFP_EINVAL;
   c->force_wide = bits == 64;

@@ -383,7 +383,10 @@ KRParams make_fast_params(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, u
   KRParams kp = make_kr_params(w, p);
   if (w < 4 || w > 17) return kp;          // (the register path of the scan kernel; wider windows keep Karp-Rabin)
   kp.fast = 1;
-  kp.fthr = p >= (1ull << 32) ? 0u : (uint32_t)((1ull << 32) / p);
+  // (pfp_set_parse_density: the fused chain may cut more or less often than 1 / p - opt-in, see pfpgpu.h)
+  const double dens = c->parse_density > 0 ? c->parse_density : 1.0;
+  const double thr = 4294967296.0 / (double)p * dens;
+  kp.fthr = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
   bool have_first = false, ref_first = false;
   uint8_t fw[32] = {0};
   if (n >= (uint64_t)w) {

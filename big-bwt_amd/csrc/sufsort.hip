@@ -1525,36 +1525,6 @@ __global__ void sample_keys_kernel(const uint8_t *__restrict__ s, uint64_t N, ui
   key[k] = i < N ? packed_key_at(s, i, kp.kbits, lut) : ~0ull;
   val[k] = k;
 }
-// flag the suffixes whose key lies in [klo, khi) (khi_open: no upper bound) and count those below klo
-// Also sums, over the suffixes of the range, the occurrences of their words (count.pos_word != null): the
-// number of BWT positions this range will emit, known before anything is sorted.
-__global__ __launch_bounds__(256) void range_flags_kernel(const uint8_t *__restrict__ s, uint64_t N, KeyCode kp,
-                                                          uint64_t klo, uint64_t khi,
-                                                          int khi_open, SlotPayloadSrc count, int want_count, uint8_t *__restrict__ flag,
-                                                          unsigned long long *__restrict__ tile_below,
-                                                          unsigned long long *__restrict__ tile_emits) {
-  __shared__ KeyStreamLds L;
-  __shared__ unsigned long long wsum[2][4];
-  if ((uint64_t)BID * kKeyPos >= N) return;      // a workgroup of the padded last grid row
-  const uint64_t B0 = (uint64_t)BID * kKeyPos;
-  uint32_t wd = 0;
-  const uint64_t k = want_count ? block_stream_key(L, s, N, kp, B0, &count.wv, &wd) : block_stream_key(L, s, N, kp, B0);
-  const uint64_t i = B0 + threadIdx.x;
-  unsigned long long cnt = 0, emits = 0;
-  if (threadIdx.x < kKeyPos && i < N) {
-    cnt = k < klo ? 1ull : 0ull;
-    const bool mine = k >= klo && (khi_open || k < khi);
-    flag[i] = mine ? 1 : 0;
-    if (mine && want_count && wd < count.wv.d && count.wv.wend[wd] - i > (uint64_t)count.w) emits = count.wocc[wd];
-  }
-  for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o, 64); emits += __shfl_down(emits, o, 64); }
-  if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = cnt; wsum[1][threadIdx.x >> 6] = emits; }
-  __syncthreads();
-  if (threadIdx.x == 0) {       // per-workgroup sums (one atomic per workgroup on one address would serialise 1.6 M of them)
-    tile_below[BID] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
-    tile_emits[BID] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
-  }
-}
 // The same selection without a key per position.  A share of the suffix array only has to be a contiguous range of the final
 // order, and "is this suffix below that one" is a string comparison: the suffix at i against the suffix at a boundary position,
 // 16 bytes at a time - decided at the first byte for three positions in four (DNA), never more than kRangeCmp bytes: a suffix that
@@ -1599,45 +1569,6 @@ __device__ __forceinline__ int cmp_head16(const uint4 xv, const uint4 yv, const 
     }
   }
   return cmp_suffix_boundary(s, i, b);      // (16 equal bytes: rare)
-}
-__global__ __launch_bounds__(256) void range_flags_cmp_kernel(const uint8_t *__restrict__ s, uint64_t N, uint64_t b_lo, int has_lo,
-                                                              uint64_t b_hi, int has_hi, SlotPayloadSrc count, int want_count,
-                                                              uint8_t *__restrict__ flag, unsigned long long *__restrict__ tile_below,
-                                                              unsigned long long *__restrict__ tile_emits) {
-  __shared__ unsigned long long wsum[2][4];
-  __shared__ uint32_t wt[4];
-  const uint64_t B0 = (uint64_t)BID * 256;
-  if (B0 >= N) return;      // a workgroup of the padded last grid row
-  const uint64_t i = B0 + threadIdx.x;
-  const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
-  const uint32_t ch = i < N ? (uint32_t)s[i] : 0xffu;
-  const unsigned long long tm = __ballot(ch == (uint32_t)kEndOfWord);
-  if (lane == 0) wt[wvi] = (uint32_t)__popcll(tm);
-  unsigned long long cnt = 0, emits = 0;
-  bool mine = false;
-  if (i < N) {
-    // one 16-byte load of the suffix's head against the two boundaries' heads (uniform: loaded once per wave); the full compare
-    // only where 16 bytes do not decide
-    const uint4 xv = ld16u(s + i);
-    const int cl = !has_lo ? 1 : cmp_head16(xv, ld16u(s + b_lo), s, i, b_lo);
-    cnt = cl < 0 ? 1ull : 0ull;
-    mine = cl >= 0 && (!has_hi || cmp_head16(xv, ld16u(s + b_hi), s, i, b_hi) < 0);
-    flag[i] = mine ? 1 : 0;
-  }
-  __syncthreads();
-  if (mine && want_count) {      // the position's word: the block's first (blocks start at multiples of 64) plus the terminators before it
-    uint32_t wd = count.wv.blk_word[B0 >> 6] + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
-    for (int q = 0; q < wvi; q++) wd += wt[q];
-    if (wd < count.wv.d && count.wv.wend[wd] - i > (uint64_t)count.w) emits = count.wocc[wd];
-  }
-  cnt = (unsigned long long)__popcll(__ballot(cnt != 0));      // (0 / 1 per lane: one ballot instead of a shuffle tree)
-  if (__ballot(emits != 0)) for (int o = 32; o > 0; o >>= 1) emits += __shfl_down(emits, o, 64);
-  if (lane == 0) { wsum[0][wvi] = cnt; wsum[1][wvi] = emits; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    tile_below[BID] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
-    tile_emits[BID] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
-  }
 }
 // the same with four consecutive positions per thread: their heads come out of five ALIGNED dwords (byte shifts) instead of four
 // unaligned 16-byte loads and four byte loads, the four flags leave as one dword - the one-position form is bound by its byte-wide
@@ -1782,9 +1713,8 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   KeyCode kc = dict_key_code(c, bytes, N, out.rep_hint);
   const int idx_bits = keysonly_bits<I>(N, out.rep_hint, kc);      // (before the splitters: every rank cuts the same keys)
   // splitters: every stride-th suffix's key, sorted; the same on every rank.  The share is cut by comparing every suffix with the
-  // boundary SUFFIXES (range_flags_cmp_kernel) - boundaries with distinct keys, so that they stand in the order they are used in;
-  // PFP_RANGE_BY_KEY=1: by computing every position's key and comparing keys (the first form, kept for comparison)
-  static const bool by_key = getenv("PFP_RANGE_BY_KEY") != nullptr;
+  // boundary SUFFIXES (range_flags_cmp4_kernel) - boundaries with distinct keys, so that they stand in the order they are used in
+  // (the two earlier forms - a first-round key per position, one position per thread - went with round 4)
   uint64_t klo = 0, khi = ~0ull, b_lo = 0, b_hi = 0;
   bool has_lo = false, has_hi = false;
   if (parts > 1) {
@@ -1818,25 +1748,12 @@ void sort_dict_suffixes_range(pfp_ctx *c, const uint8_t *bytes, uint64_t N, cons
   DBuf<uint8_t> flag(c, N);
   DBuf<unsigned long long> below(c, 2);
   below.zero();
-  if (by_key) {
-    const uint64_t nblk = cdiv64(N, kKeyPos);
+  {
+    const uint64_t nblk = cdiv64(N, 1024);
     DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
-    KScope ks(c, "pfp::range_flags_kernel", N * 2);
-    hipLaunchKernelGGL(range_flags_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, kc, klo, khi, khi_open,
-                       count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
-    hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, tb.p, te.p, nblk,
-                       below.p);
-  } else {
-    static const bool one_per_thread = getenv("PFP_RANGE_CMP1") != nullptr;      // (the first form of the comparison kernel)
-    const uint64_t nblk = cdiv64(N, one_per_thread ? 256 : 1024);
-    DBuf<unsigned long long> tb(c, nblk), te(c, nblk);
-    KScope ks(c, one_per_thread ? "pfp::range_flags_cmp_kernel" : "pfp::range_flags_cmp4_kernel", N * 2);
-    if (one_per_thread)
-      hipLaunchKernelGGL(range_flags_cmp_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, b_lo, has_lo ? 1 : 0, b_hi,
-                         has_hi ? 1 : 0, count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
-    else
-      hipLaunchKernelGGL(range_flags_cmp4_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, b_lo, has_lo ? 1 : 0, b_hi,
-                         has_hi ? 1 : 0, count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
+    KScope ks(c, "pfp::range_flags_cmp4_kernel", N * 2);
+    hipLaunchKernelGGL(range_flags_cmp4_kernel, gdim((unsigned)nblk), gdim(256), 0, c->stream, bytes, N, b_lo, has_lo ? 1 : 0, b_hi,
+                       has_hi ? 1 : 0, count ? *count : SlotPayloadSrc{}, count ? 1 : 0, flag.p, tb.p, te.p);
     hipLaunchKernelGGL(sum2_u64_kernel, gdim((int)std::min<uint64_t>(cdiv64(nblk, 256), 256)), gdim(256), 0, c->stream, tb.p, te.p, nblk,
                        below.p);
   }

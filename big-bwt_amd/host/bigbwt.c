@@ -147,6 +147,8 @@ static void usage(const char *argv0) {
          "  --compress       compress output of the parsing phase (.parse.txz of .parse and .dicz)\n"
          "  -P, --probing    accepted for compatibility (deduplication here is exact)\n"
          "  -G, --gpus N     one BWT on N GPUs of this node, devices --device .. --device + N - 1 (0: all; RCCL; not with -k / --parsing / --compress)\n"
+         "      --density D  single GPU without -k: cut the text with probability D / MOD instead of 1 / MOD (same outputs; shorter\n"
+         "                   phrases - D = 2 - suit collections of many near-identical copies; def. 1)\n"
          "      --halo H     -G: bytes of each byte range its right neighbour also reads (def. 1048576; must cover a phrase)\n",
          argv0);
 }
@@ -156,11 +158,13 @@ int main(int argc, char **argv) {
   int w = 10, th = 0, s = 0, e = 0, S = 0, keep = 0, verbose = 0, check = 0, fasta = 0, sum = 0, parsing = 0,
       compress = 0, device = 0, gpus = 1;
   unsigned long long p = 100, halo = 1ull << 20;
+  double density = 0;
   static struct option lo[] = {{"wsize", required_argument, 0, 'w'}, {"mod", required_argument, 0, 'p'},
                                {"sum", no_argument, 0, 1000},        {"parsing", no_argument, 0, 1001},
                                {"compress", no_argument, 0, 1002},   {"probing", no_argument, 0, 'P'},
                                {"device", required_argument, 0, 1003}, {"help", no_argument, 0, 'h'},
                                {"gpus", required_argument, 0, 'G'},  {"halo", required_argument, 0, 1004},
+                               {"density", required_argument, 0, 1005},
                                {0, 0, 0, 0}};
   int c;
   while ((c = getopt_long(argc, argv, "w:p:t:seSkvcfPhG:", lo, NULL)) != -1) {
@@ -181,6 +185,7 @@ int main(int argc, char **argv) {
       case 1002: compress = 1; break;
       case 1003: device = atoi(optarg); break;
       case 1004: halo = strtoull(optarg, NULL, 10); break;
+      case 1005: density = atof(optarg); break;
       case 'G': gpus = atoi(optarg); break;
       case 'h': usage(argv[0]); return 0;
       default: usage(argv[0]); return 2;
@@ -296,6 +301,7 @@ int main(int argc, char **argv) {
     return 1;
   }
   pfp_set_profiling(ctx, verbose);
+  if (density > 0 && pfp_set_parse_density(ctx, density) != 0) { fprintf(stderr, "--density must lie in [0.01, 64]\n"); return 2; }
 
   if (gpus > 1) {
     /* done above, by the ranks */

@@ -30,7 +30,7 @@ ERRORS = {0: "PFP_OK", -1: "PFP_EINVAL", -2: "PFP_ENODEV", -3: "PFP_EHIP", -4: "
 SYMBOLS = ["pfp_device_count", "pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror", "pfp_version", "pfp_ctx_stream",
            "pfp_free", "pfp_debug_check", "pfp_get_mem_stats", "pfp_get_pool_counters", "pfp_pool_trim", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak", "pfp_sacak_int64", "pfp_sacak64", "pfp_gsacak64", "pfp_gsacak_lcp_da", "pfp_gsacak_lcp_da64",
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_files", "pfp_bigbwt_dev", "pfp_bigbwt_formats_dev", "pfp_dev_free", "pfp_memcpy_d2h", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
-           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_window_hash", "pfp_debug_msd_sort", "pfp_bigbwt_fd", "pfp_multi_rccl_selftest", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
+           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_window_hash", "pfp_set_parse_density", "pfp_debug_msd_sort", "pfp_bigbwt_fd", "pfp_multi_rccl_selftest", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
            "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_partition_words", "pfp_dist_export_partition",
            "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_sample_runs", "pfp_dist_release", "pfp_bigbwt_files_multi", "pfp_dist_parse_sort", "pfp_dist_set_parse_sa"]
 
@@ -241,6 +241,10 @@ class Context:
         self._check(self.lib.pfp_debug_msd_sort(self._h, keys.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                 vals.ctypes.data_as(C.POINTER(C.c_uint32)) if vals is not None else None,
                                                 C.c_uint64(len(keys)), C.c_int(lo), C.c_int(hi)))
+
+    def set_parse_density(self, density):
+        """fused chain, opt-in: the window hash cuts with probability density / p (outputs unchanged, see pfpgpu.h)"""
+        self._check(self.lib.pfp_set_parse_density(self._h, C.c_double(density)))
 
     def set_index_bits(self, bits):
         """0: index width by size (32 bits below 4 GiB), 64: always the wide build (bigbwt:109-151)"""

@@ -249,6 +249,12 @@ void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
  * depend on the choice (quirk Q1 is reproduced either way); pfp_scan / pfp_parse / the stage executables
  * always cut exactly where the reference does.  With fast == 0 and max_phrase == 0 the fused chain parses like the reference. */
 void pfp_set_window_hash(pfp_ctx *ctx, int fast);
+/* Fused chain with the window hash only, opt-in (default 1.0; PFP_PARSE_DENSITY in the environment at pfp_ctx_create): cut with
+ * probability density / p instead of 1 / p.  The outputs do not depend on it; the work does - for c copies at mutation rate r the
+ * dictionary grows with the phrase length (about G (1 + c r L) bytes) while the parse shrinks (n / L phrases), so a collection of
+ * many near-identical copies is processed faster with shorter phrases (density 2 = what -p p/2 would parse like) and a single
+ * genome does not care.  The C driver exposes it as --density; nothing selects it automatically: -p means what the user said. */
+int pfp_set_parse_density(pfp_ctx *ctx, double density);
 /* Index width of dictionary positions and suffix-array slots: 0 = by size (32 bits below 4 GiB of dictionary /
  * text, 64 above: the reference's choice between its 32-bit and -DM64 executables, bigbwt:109-151), 64 = always
  * the wide build (what PFP_FORCE_IDX64=1 in the environment sets at pfp_ctx_create), 32 = the narrow build wherever its positions

@@ -36,6 +36,7 @@ def main():
         "c1": lambda: (synth.workload_text_np("c1"), dict(synth.WORKLOADS["c1"], check=True)),
         "c1_gen": lambda: (O.gen_fasta(12_100_000, 1, 0.0, 1), dict(w=10, p=100, flags=0, check=True, desc="BASELINE.md section 5 C1-syn: GEN(12.1e6,1,0,1), -w 10 -p 100 -c")),
         "c2": lambda: (synth.workload_text_np("c2"), synth.WORKLOADS["c2"]),
+        "c2r": lambda: (synth.workload_text_np("c2r"), synth.WORKLOADS["c2r"]),      # configs[1] with repeat families, satellites, microsatellites
         "c3": lambda: (synth.workload_text_np("c3"), synth.WORKLOADS["c3"]),
         "c4s": lambda: (synth.workload_text_np("c4s"), synth.WORKLOADS["c4s"]),
         "c5s": lambda: (synth.workload_text_np("c5s"), synth.WORKLOADS["c5s"]),

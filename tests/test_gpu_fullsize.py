@@ -69,10 +69,11 @@ def test_survey_gen16_digests(O, pkg, ctx, golden_full):
     check(run_dev(pkg, ctx, torch.from_numpy(text).cuda(), g["w"], g["p"], g["flags"]), g)
 
 
-@pytest.mark.parametrize("name", ["small", "c2", "c3", "c4s", "c5s"])
+@pytest.mark.parametrize("name", ["small", "c2", "c2r", "c3", "c4s", "c5s"])
 def test_benchmark_workloads_match_reference_digests(pkg, ctx, synth, golden_full, name):
     """BASELINE configs[1] (c2), configs[2] (c3, -s -e) at full size; configs[3]/[4] flag sets (-S; -w 12 -p 200 -s)
-    on 16-copy stand-ins"""
+    on 16-copy stand-ins; c2r = configs[1] with a chromosome's repeat structure (interspersed families, satellite arrays of
+    17 K near-identical monomers, microsatellites: word families in the thousands, round 4)"""
     import torch
     if name not in golden_full:
         pytest.skip("no reference digest committed for this workload")
@@ -86,7 +87,7 @@ def test_benchmark_workloads_match_reference_digests(pkg, ctx, synth, golden_ful
         check(got, g)
 
 
-@pytest.mark.parametrize("name,ranks", [("c4s", 4), ("c5s", 3), ("c3", 2), ("c2", 3)])
+@pytest.mark.parametrize("name,ranks", [("c4s", 4), ("c5s", 3), ("c3", 2), ("c2", 3), ("c2r", 2)])
 def test_benchmark_workloads_on_several_ranks(pkg, synth, golden_full, tmp_path, monkeypatch, name, ranks):
     """pfp_bigbwt_files_multi (the host of `bigbwt -G N`): BASELINE configs[3] / configs[4] flag sets on their 0.2 GB stand-ins and
     configs[2] and configs[1] (non-repetitive, an 18 Mb run of N across a rank boundary) at full size, split over rank threads that
@@ -102,8 +103,11 @@ def test_benchmark_workloads_on_several_ranks(pkg, synth, golden_full, tmp_path,
     base = "/dev/shm/pfp_multi_%s_%d" % (name, os.getpid())
     try:
         st = pfpmod.bigbwt_files_multi(text, base, [0] * ranks, g["w"], g["p"], g["flags"])
-        assert st["ranks"] == ranks and st["n"] == g["n"] and st["sa_shares"] == ranks
-        if name != "c2":          # (the copies of a collection: the parse's suffix array is sorted in shares too)
+        assert st["ranks"] == ranks and st["n"] == g["n"]
+        # (c2r: the satellite arrays' families outlast a share's pivot rounds - the range reports "needs doubling", every rank
+        #  then sorts the whole dictionary and the output is cut in equal slices: the fallback of DESIGN.md section 6)
+        assert st["sa_shares"] == (ranks if name != "c2r" else st["sa_shares"]) and st["sa_shares"] in (1, ranks)
+        if name not in ("c2", "c2r"):          # (the copies of a collection: the parse's suffix array is sorted in shares too)
             assert st["parse_shares"] == ranks
         for key, ext, bit in (("bwt", ".bwt", 0), ("sa", ".sa", 1), ("ssa", ".ssa", 2), ("esa", ".esa", 4)):
             if bit == 0 or g["flags"] & bit:
@@ -281,6 +285,36 @@ def test_full_sa_beyond_4g_on_8_ranks(pkg, ctx, synth, golden_full, monkeypatch)
         for ext in (".bwt", ".sa"):
             if os.path.exists(base + ext):
                 os.unlink(base + ext)
+
+
+def test_configs4_flag_set_on_12_6_gb(pkg, ctx, synth, golden_full):
+    """BASELINE configs[4]'s flag set (-w 12 -p 200 -s) at the north star's size: the 12.6 GB, 1024-copy text.  Longer phrases
+    make a 3.0 GB dictionary - beyond the reference's 32-bit merger (its digests come from pfbwtNT64.x: 33 minutes, 51 GB of host
+    memory) and, here, in the 2^31 .. 2^32 regime of one GPU.  .bwt and .ssa against those digests (they equal the -w 10 -p 100
+    ones: the outputs do not depend on the parse)."""
+    import torch
+    if "huge_w12" not in golden_full:
+        pytest.skip("no reference digest committed for this workload")
+    g = golden_full["huge_w12"]
+    assert g["w"] == 12 and g["p"] == 200 and g["bwt_sha256"] == golden_full["huge_s"]["bwt_sha256"]
+    dev = torch.device("cuda", 0)
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 260 * (1 << 30):
+        pytest.skip("needs about 260 GB of free device memory")
+    ctx.pool_trim()
+    text = synth.workload_text_torch(dev, "huge_w12")
+    torch.cuda.empty_cache()
+    assert text.numel() == g["n"] and sha_dev(text) == g["text_sha256"]
+    try:
+        got = run_formats(pkg, ctx, text, g["w"], g["p"], g["flags"])
+        assert set(got) == {"bwt", "ssa"}
+        check(got, g)
+        st = ctx.stats()
+        assert (1 << 31) <= st["dict_size"] < (1 << 32), st["dict_size"]
+    finally:
+        del text
+        ctx.pool_trim()
+        torch.cuda.empty_cache()
 
 
 def test_pack_and_sample_exports_on_slices(O, pkg, ctx):

@@ -18,6 +18,27 @@ def test_numpy_and_torch_evaluators_agree(synth):
     assert np.array_equal(synth.mix64_np(x).view(np.int64), synth.mix64_torch(torch.from_numpy(x.view(np.int64))).numpy())
 
 
+def test_repeat_structure_evaluators_agree(synth):
+    """the chromosome-like repeat structure of the c2r workload (interspersed families, microsatellites, satellite arrays): both
+    evaluators give the same bytes, the features are where the definition puts them"""
+    rep = dict(families=64, sat=[(600_000, 300_000), (1_800_000, 150_000)])
+    a = synth.collection_np(2_400_000, 2, 0.001, 2, [(1_200_000, 180_000)], repeats=rep)
+    b = synth.collection_torch("cpu", 2_400_000, 2, 0.001, 2, [(1_200_000, 180_000)], repeats=rep).numpy()
+    assert np.array_equal(a, b)
+    seq = a[len(synth.header(0)):][: 2_400_000 + 40_000]
+    seq = seq[seq != 10][: 2_400_000]          # the bases of copy 0 without the line ends
+    mono = seq[600_000:600_000 + 171 * 100].reshape(100, 171)
+    assert (mono != mono[0]).mean() < 0.05          # a satellite array: copies of one monomer, a few per cent apart
+    micro = seq[15_000:15_020]
+    assert any(np.array_equal(micro[u:], micro[:-u]) for u in range(1, 7))          # a microsatellite: a unit of 1-6 bases repeated
+    assert (seq[1_200_000:1_380_000] == ord("N")).all()
+    fam = {}
+    for j in range(0, 200):          # copies of the same family are ~9 % apart, different families ~75 %
+        fam.setdefault(j, seq[3000 * j:3000 * j + 300])
+    d = np.array([[(fam[x] != fam[y]).mean() for y in range(40)] for x in range(40)])
+    assert ((d > 0.01) & (d < 0.3)).sum() >= 10 and (d > 0.6).sum() > 1000
+
+
 def test_text_shape_and_mutation_rate(synth):
     t = synth.collection_np(60000, 4, 0.01, 3)
     lines = bytes(t).split(b"\n")
