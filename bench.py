@@ -163,6 +163,7 @@ def north_star_leg(pkg, synth, ctx, dev, steps=2, with_cli=True):
                outputs=["bwt"] + sorted(outs), outputs_match_reference_digests=digests, roofline_passes=passes,
                phases_ms={k: round(st[k], 2) for k in ("ms_scan", "ms_phrases", "ms_sa_dict", "ms_sa_parse", "ms_merge")},
                top_kernels_ms={k: round(v, 2) for k, v in top}, words=st["n_words"], dict_bytes=st["dict_size"], phrases=st["n_phrases"], runs=R,
+               parse_density=st.get("parse_density"),
                peak_device_bytes=mem["peak"], driver_allocations_in_timed_steps=pc1["driver_allocs"] - pc0["driver_allocs"],
                text_generation_s=round(gen_s, 2))
     for ptr, _ in outs.values():
@@ -482,6 +483,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "name": wl_name, "bytes_per_gpu": n, "w": w, "p": p, "flags": flags,
                        "phrases": dstats["phrases_total"] if collection else st["n_phrases"], "words": st["n_words"], "dict_bytes": st["dict_size"],
+                       "parse_density": st.get("parse_density"),          # the fused chain cut with probability parse_density / p (pfpgpu.h: pfp_set_parse_density)
                        "outputs_in_timed_step": ["bwt"] + [k for k in ("sa", "ssa", "esa") if k in outbuf or (collection and ("sa5" if k == "sa" else k) in last.get("r", {}))],
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{world} shards of one collection over RCCL: halo allgather, hash-partitioned all-to-all phrase dedup, "

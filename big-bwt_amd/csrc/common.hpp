@@ -237,7 +237,7 @@ struct pfp_ctx {
   bool force_wide = false;        // PFP_FORCE_IDX64=1 / pfp_set_index_bits(ctx, 64): 64-bit dictionary positions whatever the size
   bool force_narrow = false;      // pfp_set_index_bits(ctx, 32): 32-bit positions wherever they fit (below 2^32 - 16 bytes of dictionary)
   uint64_t max_phrase = 1u << 15; // fused chain: split phrases longer than this with extra triggers (0 = off)
-  double parse_density = 1.0;     // pfp_set_parse_density: the window hash cuts with probability density / p (fused chain only)
+  double parse_density = 0.0;     // pfp_set_parse_density: the window hash cuts with probability density / p (fused chain only); 0 = chosen by repetitiveness
   bool fast_triggers = true;      // fused chain: cut the text by the cheap window hash of scan.hip (false / PFP_WINDOW_HASH=kr: Karp-Rabin)
   hipStream_t stream = nullptr;
   std::string err;

@@ -251,6 +251,7 @@ static void run_parse(pfp_ctx *c, Chain &ch, uint64_t n, int w, uint64_t p, bool
     uint32_t n_extra = 0;
     // the staged entry points parse exactly as the reference does (newscan.cpp:168-202, 363-377); the fused chain cuts by
     // its own window hash (pfp_set_window_hash) and splits giant phrases with extra triggers (pfp_set_max_phrase)
+    st.parse_density = 1.0;
     if (exact_reference_parse || (!c->max_phrase && !c->fast_triggers)) ch.n_ends = scan_text(c, ch.tx, n, w, p, ch.ends, &ch.n_used);
     else ch.n_ends = scan_text_adaptive(c, ch.tx, n, w, p, c->max_phrase, ch.ends, &ch.n_used, &n_extra);
     st.extra_triggers = n_extra;
@@ -573,7 +574,7 @@ int pfp_get_kernel_trace(pfp_ctx *c, pfp_kernel_stat *out, int cap) {
 void pfp_set_max_phrase(pfp_ctx *c, uint64_t max_phrase) { if (c) c->max_phrase = max_phrase; }
 void pfp_set_window_hash(pfp_ctx *c, int fast) { if (c) c->fast_triggers = fast != 0; }
 int pfp_set_parse_density(pfp_ctx *c, double density) {
-  if (!c || !(density >= 0.01 && density <= 64.0)) return PFP_EINVAL;
+  if (!c || !(density == 0.0 || (density >= 0.01 && density <= 64.0))) return PFP_EINVAL;
   c->parse_density = density;
   return PFP_OK;
 }

@@ -383,10 +383,14 @@ KRParams make_fast_params(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, u
   KRParams kp = make_kr_params(w, p);
   if (w < 4 || w > 17) return kp;          // (the register path of the scan kernel; wider windows keep Karp-Rabin)
   kp.fast = 1;
-  // (pfp_set_parse_density: the fused chain may cut more or less often than 1 / p - opt-in, see pfpgpu.h)
-  const double dens = c->parse_density > 0 ? c->parse_density : 1.0;
-  const double thr = 4294967296.0 / (double)p * dens;
+  // pfp_set_parse_density: 0 (default) = the chain chooses between the nominal density 1 / p and twice that (see
+  // choose_parse_density below): the scan then cuts at 2 / p and remembers the nominal threshold; d > 0 = cut at d / p
+  const bool auto_density = !(c->parse_density > 0);
+  const double dens = auto_density ? 2.0 : c->parse_density;
+  const double thr_nom = 4294967296.0 / (double)p, thr = thr_nom * dens;
   kp.fthr = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+  kp.fthr_nom = auto_density ? (thr_nom >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr_nom) : kp.fthr;
+  kp.fauto = auto_density ? 1u : 0u;
   bool have_first = false, ref_first = false;
   uint8_t fw[32] = {0};
   if (n >= (uint64_t)w) {
@@ -399,9 +403,15 @@ KRParams make_fast_params(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, u
   }
   const uint32_t h_first = fast_hash_bytes(fw, w);      // (unseeded here: the loop below is what chooses the seed)
   auto fires = [&](uint32_t h, uint32_t seed) { return (uint32_t)((h + seed) * kFastK) < kp.fthr; };
+  // (the first window must decide like the reference's hash at whichever density is taken in the end: inside the nominal
+  //  threshold if the reference cuts there, outside the scan's threshold if it does not)
+  auto first_ok = [&](uint32_t seed) {
+    const uint32_t x = (uint32_t)((h_first + seed) * kFastK);
+    return ref_first ? x < kp.fthr_nom : x >= kp.fthr;
+  };
   uint32_t best = 0;
   for (uint32_t seed = 0; seed < (1u << 20); seed++) {
-    if (have_first && fires(h_first, seed) != ref_first) continue;
+    if (have_first && !first_ok(seed)) continue;
     best = seed;
     bool crumbs = false;
     if (p >= 32)
@@ -612,14 +622,97 @@ uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_use
   return added;
 }
 
+// ---------------------------------------------------------------- phrase length by repetitiveness (round 4)
+//
+// For c copies of a genome at mutation rate r the dictionary grows with the phrase length L (about G (1 + c r L) bytes: every
+// mutation makes a new word of length ~L) while the parse shrinks (n / L phrases), and the dictionary's suffix sort and merge are
+// what the chain spends its time on: twice the trigger density takes configs[2] from 37.9 to 32.6 ms and halves the peak memory
+// (12.6 GB: 141 -> 78 GB); a single genome, whose dictionary is the text whatever L is, only pays for the longer parse.  The
+// outputs do not depend on the choice.  So the fused chain scans ONCE at twice the nominal density -
+// `x < 2 thr` contains `x < thr` - looks at a content-defined sample of the cuts (x < thr / 16: the same loci in every copy) and
+// counts how many of the 64-byte contexts before them are distinct: mean multiplicity >= 8 means a collection of near-identical
+// copies and all cuts are kept, else the cuts outside the nominal threshold are dropped again and the parse is the one -p asks for.
+// pfp_set_parse_density(ctx, 1) / PFP_PARSE_DENSITY=1 pins the nominal density; pfp_stats.parse_density reports what was used.
+__global__ void classify_ends_kernel(const uint8_t *__restrict__ tbase, const uint64_t *__restrict__ ends, uint64_t ne, int w,
+                                     uint32_t seed, uint32_t thr_nom, uint32_t thr_sample, uint8_t *__restrict__ nominal,
+                                     uint8_t *__restrict__ sample) {
+  const uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (k >= ne) return;
+  const uint64_t e = ends[k];
+  const uint32_t x = (fast_hash_bytes(tbase + e - (uint64_t)(w - 1), w) + seed) * kFastK;
+  nominal[k] = x < thr_nom ? 1 : 0;
+  sample[k] = x < thr_sample ? 1 : 0;
+}
+__global__ void context_hash_kernel(const uint8_t *__restrict__ tbase, const uint64_t *__restrict__ ends, const uint32_t *__restrict__ idx,
+                                    uint64_t ns, uint64_t *__restrict__ out) {
+  const uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (k >= ns) return;
+  const uint8_t *q = tbase + ends[idx[k]] - 63;      // the 64 bytes that end with the window (the staging buffer has 64 bytes of front padding)
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+  for (int j = 0; j < 8; j++) h = fmix64(h ^ ld8u(q + 8 * j)) + 0x632BE59BD9B4E019ull * (uint64_t)(j + 1);
+  out[k] = h;
+}
+__global__ void count_distinct_kernel(const uint64_t *__restrict__ sorted, uint64_t ns, unsigned long long *__restrict__ out) {
+  const uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
+  const bool head = k < ns && (k == 0 || sorted[k] != sorted[k - 1]);
+  const unsigned long long m = __ballot(head);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+__global__ void gather_ends_kernel(const uint64_t *__restrict__ ends, const uint32_t *__restrict__ idx, uint64_t cnt, uint64_t *__restrict__ out) {
+  const uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (k < cnt) out[k] = ends[idx[k]];
+}
+// the scan cut at kp.fthr = twice the nominal density: keep that (returns ne, *dense = true) or fall back to the nominal cuts
+// (d_ends compacted, kp.fthr lowered to the nominal threshold for every later rescan)
+static uint64_t choose_parse_density(pfp_ctx *c, const StagedText &tx, int w, DBuf<uint64_t> &d_ends, uint64_t ne, KRParams &kp, bool *dense) {
+  *dense = false;
+  PFP_REQUIRE(ne < 0xFFFFFFFFull, PFP_ELIMIT, "more than 2^32 - 2 phrases (bwtparse.c:93)");
+  DBuf<uint8_t> nominal(c, ne + 16), sample(c, ne + 16);
+  PFP_HIP(hipMemsetAsync(nominal.p + ne, 0, 16, c->stream));
+  PFP_HIP(hipMemsetAsync(sample.p + ne, 0, 16, c->stream));
+  hipLaunchKernelGGL(classify_ends_kernel, gdim(cdiv(ne, 256)), gdim(256), 0, c->stream, tx.tbase(), d_ends.p, ne, w, kp.fseed, kp.fthr_nom,
+                     kp.fthr_nom / 16u, nominal.p, sample.p);
+  const uint64_t ns = count_flags(c, sample.p, ne);
+  if (ns >= 1024) {
+    DBuf<uint32_t> idx(c, ns);
+    DBuf<uint64_t> cnt(c, 1), h(c, ns), hs(c, ns);
+    DBuf<unsigned long long> nd(c, 1);
+    select_index<uint32_t>(c, sample.p, idx.p, cnt.p, ne);
+    hipLaunchKernelGGL(context_hash_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, tx.tbase(), d_ends.p, idx.p, ns, h.p);
+    sort_keys_raw(c, h.p, hs.p, ns, 0, 64);
+    nd.zero();
+    hipLaunchKernelGGL(count_distinct_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, hs.p, ns, nd.p);
+    const uint64_t distinct = read_scalar(c, (const uint64_t *)nd.p);
+    *dense = distinct * 8 <= ns;          // mean multiplicity of a sampled context >= 8
+  }
+  if (*dense) return ne;
+  const uint64_t n1 = count_flags(c, nominal.p, ne);
+  DBuf<uint64_t> keep(c, n1 + 1), cnt(c, 1);
+  DBuf<uint32_t> idx(c, n1 + 1);
+  select_index<uint32_t>(c, nominal.p, idx.p, cnt.p, ne);
+  if (n1) hipLaunchKernelGGL(gather_ends_kernel, gdim(cdiv(n1, 256)), gdim(256), 0, c->stream, d_ends.p, idx.p, n1, keep.p);
+  PFP_HIP(hipGetLastError());
+  d_ends = std::move(keep);
+  kp.fthr = kp.fthr_nom;
+  return n1;
+}
+
 uint64_t scan_text_adaptive(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, uint64_t max_phrase,
                             DBuf<uint64_t> &d_ends, uint64_t *n_used, uint32_t *n_extra) {
   KRParams kp = c->fast_triggers ? make_fast_params(c, tx, n, w, p) : make_kr_params(w, p);
   *n_extra = 0;
   uint64_t ne = scan_text(c, tx, n, w, p, d_ends, n_used, &kp);
+  c->stats.parse_density = kp.fast ? (c->parse_density > 0 ? c->parse_density : 1.0) : 1.0;
+  if (kp.fast && kp.fauto && ne > 0) {
+    bool dense = false;
+    ne = choose_parse_density(c, tx, w, d_ends, ne, kp, &dense);
+    c->stats.parse_density = dense ? 2.0 : 1.0;
+  }
   if (kp.fast && ne == 0) {      // no cut at all: the reference's own hash decides whether this text has a parse (bwtparse.c:244)
     kp = make_kr_params(w, p);
     ne = scan_text(c, tx, n, w, p, d_ends, n_used, &kp);
+    c->stats.parse_density = 1.0;
   }
   for (int iter = 0; iter < 4 && max_phrase; iter++) {
     if (!propose_extra_triggers(c, tx, *n_used, w, max_phrase, d_ends, ne, kp)) break;

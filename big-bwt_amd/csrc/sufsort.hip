@@ -540,10 +540,27 @@ __global__ void ipivot_keys_kernel(uint64_t m, uint64_t N, uint64_t h, uint32_t 
   const uint64_t piv = act_i[0xFFFFFFFFu - (uint32_t)(best[act_grp[a]] & 0xFFFFFFFFull)];
   uint64_t k = (uint64_t)(cap + 1) << 32;      // the pivot itself, and whoever equals it for cap symbols
   if (i != piv) {
-    for (uint32_t q = 0; q < cap; q++) {
+    // four symbols a step (two unaligned 16-byte loads; round 4: one symbol a step was a chain of ~20 dependent 4-byte loads per
+    // member - 52 ms of the 12.6 GB chain once the phrases got shorter); the last steps before the end of the string one by one
+    bool done = false;
+    for (uint32_t q = 0; q < cap && !done; q += 4) {
       const uint64_t pi = i + h + q, pp = piv + h + q;
-      const uint32_t x = pi < N ? sym[pi] : 0u, y = pp < N ? sym[pp] : 0u;
-      if (x != y) { k = ((uint64_t)(x < y ? q : 2 * cap + 2 - q) << 32) | x; break; }
+      uint32_t x[4], y[4];
+      if (pi + 4 <= N && pp + 4 <= N) {
+        const uint4 X = ld16u(reinterpret_cast<const uint8_t *>(sym + pi)), Y = ld16u(reinterpret_cast<const uint8_t *>(sym + pp));
+        if (X.x == Y.x && X.y == Y.y && X.z == Y.z && X.w == Y.w) continue;
+        x[0] = X.x; x[1] = X.y; x[2] = X.z; x[3] = X.w; y[0] = Y.x; y[1] = Y.y; y[2] = Y.z; y[3] = Y.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { x[j] = pi + j < N ? sym[pi + j] : 0u; y[j] = pp + j < N ? sym[pp + j] : 0u; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (!done && q + j < cap && x[j] != y[j]) {
+          const uint32_t qq = q + (uint32_t)j;
+          k = ((uint64_t)(x[j] < y[j] ? qq : 2 * cap + 2 - qq) << 32) | x[j];
+          done = true;
+        }
     }
   }
   key[a] = k;

@@ -68,7 +68,7 @@ class Stats(C.Structure):
                 ("extra_triggers", C.c_uint64), ("index_bits", C.c_uint64),
                 ("hard_minor_groups", C.c_uint64), ("hard_minor_chars", C.c_uint64),
                 ("ms_scan", C.c_double), ("ms_phrases", C.c_double), ("ms_sa_dict", C.c_double),
-                ("ms_sa_parse", C.c_double), ("ms_merge", C.c_double), ("ms_total", C.c_double)]
+                ("ms_sa_parse", C.c_double), ("ms_merge", C.c_double), ("ms_total", C.c_double), ("parse_density", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

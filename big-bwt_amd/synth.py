@@ -238,7 +238,7 @@ WORKLOADS = {
     "big_S": dict(G=12_100_020, C=512, r=1e-3, nblocks=[], w=10, p=100, flags=1, seed=3,
                   desc="BASELINE configs[3] flag set (-w 10 -p 100 -S, full SA in 5-byte integers) on 512 copies (~6.3 GB > 2^32 bytes: SA values above 4 G)"),
     "big_w12": dict(G=12_100_020, C=512, r=1e-3, nblocks=[], w=12, p=200, flags=2, seed=3,
-                    desc="BASELINE configs[4] flag set (-w 12 -p 200 -s) on 512 copies (~6.3 GB, 1.5 GB dictionary): the largest size of that flag set one GPU holds"),
+                    desc="BASELINE configs[4] flag set (-w 12 -p 200 -s) on 512 copies (~6.3 GB; 1.5 GB dictionary when parsed as -p 200 says)"),
     "huge_w12": dict(G=12_100_020, C=1024, r=1e-3, nblocks=[], w=12, p=200, flags=2, seed=3,
                      desc="BASELINE configs[4] flag set (-w 12 -p 200 -s) on the 12.6 GB, 1024-copy text"),
     "wide": dict(G=4_260_000_000, C=1, r=0.0, nblocks=[], w=10, p=100, flags=0, seed=3,

@@ -222,6 +222,7 @@ typedef struct {
   uint64_t index_bits;       /* 32 or 64: width of dictionary positions / suffix-array slots used (bigbwt:130-151) */
   uint64_t hard_minor_groups, hard_minor_chars; /* hard groups done by majority fill; occurrences ranked for them */
   double ms_scan, ms_phrases, ms_sa_dict, ms_sa_parse, ms_merge, ms_total; /* host wall, synced */
+  double parse_density;      /* fused chain: the text was cut with probability parse_density / p (pfp_set_parse_density) */
 } pfp_stats;
 int pfp_get_stats(const pfp_ctx *ctx, pfp_stats *st);
 /* when set (default 0) every pipeline phase is bracketed by a stream sync so ms_* are filled */
@@ -249,11 +250,14 @@ void pfp_set_max_phrase(pfp_ctx *ctx, uint64_t max_phrase);
  * depend on the choice (quirk Q1 is reproduced either way); pfp_scan / pfp_parse / the stage executables
  * always cut exactly where the reference does.  With fast == 0 and max_phrase == 0 the fused chain parses like the reference. */
 void pfp_set_window_hash(pfp_ctx *ctx, int fast);
-/* Fused chain with the window hash only, opt-in (default 1.0; PFP_PARSE_DENSITY in the environment at pfp_ctx_create): cut with
- * probability density / p instead of 1 / p.  The outputs do not depend on it; the work does - for c copies at mutation rate r the
- * dictionary grows with the phrase length (about G (1 + c r L) bytes) while the parse shrinks (n / L phrases), so a collection of
- * many near-identical copies is processed faster with shorter phrases (density 2 = what -p p/2 would parse like) and a single
- * genome does not care.  The C driver exposes it as --density; nothing selects it automatically: -p means what the user said. */
+/* Fused chain with the window hash only: cut with probability density / p instead of 1 / p.  The outputs do not depend on it; the
+ * work does - for c copies at mutation rate r the dictionary grows with the phrase length (about G (1 + c r L) bytes) while the
+ * parse shrinks (n / L phrases), so a collection of many near-identical copies is processed faster, and in half the memory, with
+ * shorter phrases (density 2 = what -p p/2 would parse like), and a single genome is not.  density = 0 (default; PFP_PARSE_DENSITY
+ * in the environment at pfp_ctx_create sets another): the chain decides between 1 and 2 itself - one scan at 2 / p, a
+ * content-defined sample of the cuts, all cuts kept if the sampled 64-byte contexts occur 8 times each on average, else the cuts
+ * beyond 1 / p dropped again (scan.hip: choose_parse_density).  density = 1 pins what -p says; the staged entry points and the stage
+ * executables always parse exactly like the reference.  pfp_stats.parse_density tells what a call used; `bigbwt --density D`. */
 int pfp_set_parse_density(pfp_ctx *ctx, double density);
 /* Index width of dictionary positions and suffix-array slots: 0 = by size (32 bits below 4 GiB of dictionary /
  * text, 64 above: the reference's choice between its 32-bit and -DM64 executables, bigbwt:109-151), 64 = always

@@ -287,22 +287,24 @@ def test_full_sa_beyond_4g_on_8_ranks(pkg, ctx, synth, golden_full, monkeypatch)
                 os.unlink(base + ext)
 
 
-def test_configs4_flag_set_on_12_6_gb(pkg, ctx, synth, golden_full):
-    """BASELINE configs[4]'s flag set (-w 12 -p 200 -s) at the north star's size: the 12.6 GB, 1024-copy text.  Longer phrases
-    make a 3.0 GB dictionary - beyond the reference's 32-bit merger (its digests come from pfbwtNT64.x: 33 minutes, 51 GB of host
-    memory) and, here, in the 2^31 .. 2^32 regime of one GPU.  .bwt and .ssa against those digests (they equal the -w 10 -p 100
-    ones: the outputs do not depend on the parse)."""
+@pytest.mark.parametrize("name", ["big_w12", "huge_w12"])
+def test_configs4_flag_set_on_12_6_gb(pkg, ctx, synth, golden_full, name):
+    """BASELINE configs[4]'s flag set (-w 12 -p 200 -s) at the north star's size: the 12.6 GB, 1024-copy text.  Parsed as -p 200
+    says, its dictionary is 3.0 GB - beyond the reference's 32-bit merger (its digests come from pfbwtNT64.x: 33 minutes, 51 GB of
+    host memory) and beyond what one GPU holds (PFP_ENOMEM in round 4's first attempt).  The fused chain halves the phrase length of
+    such a collection by itself (pfp_set_parse_density: 1.7 GB of dictionary) and fits.  .bwt and .ssa against the reference's
+    digests (they equal the -w 10 -p 100 ones: the outputs do not depend on the parse)."""
     import torch
-    if "huge_w12" not in golden_full:
+    if name not in golden_full:
         pytest.skip("no reference digest committed for this workload")
-    g = golden_full["huge_w12"]
-    assert g["w"] == 12 and g["p"] == 200 and g["bwt_sha256"] == golden_full["huge_s"]["bwt_sha256"]
+    g = golden_full[name]          # (big_w12: the same flag set on 512 copies, 6.3 GB - the reference's 32-bit merger, 21 minutes)
+    assert g["w"] == 12 and g["p"] == 200 and g["bwt_sha256"] == golden_full["huge_s" if name == "huge_w12" else "big_S"]["bwt_sha256"]
     dev = torch.device("cuda", 0)
     free, _total = torch.cuda.mem_get_info(dev)
     if free < 260 * (1 << 30):
         pytest.skip("needs about 260 GB of free device memory")
     ctx.pool_trim()
-    text = synth.workload_text_torch(dev, "huge_w12")
+    text = synth.workload_text_torch(dev, name)
     torch.cuda.empty_cache()
     assert text.numel() == g["n"] and sha_dev(text) == g["text_sha256"]
     try:
@@ -310,7 +312,7 @@ def test_configs4_flag_set_on_12_6_gb(pkg, ctx, synth, golden_full):
         assert set(got) == {"bwt", "ssa"}
         check(got, g)
         st = ctx.stats()
-        assert (1 << 31) <= st["dict_size"] < (1 << 32), st["dict_size"]
+        assert st["parse_density"] == 2.0 and st["dict_size"] < (1 << 31), st
     finally:
         del text
         ctx.pool_trim()

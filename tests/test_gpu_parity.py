@@ -93,6 +93,35 @@ def test_outputs_do_not_depend_on_the_parse(golden, O, pkg, ctx, max_phrase, fas
         ctx.set_window_hash(True)
 
 
+def test_phrase_length_follows_repetitiveness(O, pkg, ctx):
+    """pfp_set_parse_density(0), the default: the fused chain cuts a collection of many near-identical copies twice as often as
+    -p says (shorter phrases: a smaller dictionary, the outputs unchanged) and a single genome exactly as often; 1 pins -p"""
+    coll = O.gen_fasta(120000, 40, 0.002, 31)         # 40 copies, 4.9 MB (the choice wants a thousand sampled cuts)
+    single = O.gen_fasta(800000, 1, 0.0, 32)
+    want_coll, want_single = O.bigbwt(coll, 10, 100, O.FLAG_SSA | O.FLAG_ESA), O.bigbwt(single, 10, 100, 0)
+    try:
+        seen = {}
+        for dens in (0.0, 1.0, 2.0, 0.5):
+            ctx.set_parse_density(dens)
+            got = ctx.bigbwt(coll, 10, 100, pkg.FLAG_SSA | pkg.FLAG_ESA)
+            st = ctx.stats()
+            seen[dens] = (st["parse_density"], st["n_phrases"])
+            assert np.array_equal(got["bwt"], want_coll["bwt"]), dens
+            assert np.array_equal(pkg.unpack5(got["ssa"]).reshape(-1, 2), want_coll["ssa"]), dens
+            assert np.array_equal(pkg.unpack5(got["esa"]).reshape(-1, 2), want_coll["esa"]), dens
+        assert seen[0.0][0] == 2.0 and seen[1.0][0] == 1.0 and seen[2.0][0] == 2.0 and seen[0.5][0] == 0.5
+        assert seen[0.0][1] == seen[2.0][1] and 1.6 < seen[2.0][1] / seen[1.0][1] < 2.4 and seen[0.5][1] < seen[1.0][1]
+        ctx.set_parse_density(0.0)
+        got = ctx.bigbwt(single, 10, 100, 0)
+        st = ctx.stats()
+        assert st["parse_density"] == 1.0 and np.array_equal(got["bwt"], want_single["bwt"])
+        ctx.set_parse_density(1.0)
+        ctx.bigbwt(single, 10, 100, 0)
+        assert ctx.stats()["n_phrases"] == st["n_phrases"]          # the nominal cuts of the doubled scan ARE the scan at 1 / p
+    finally:
+        ctx.set_parse_density(0.0)
+
+
 def test_window_hash_parses_differently_but_as_densely(O, ctx):
     """the fused chain's window hash is not Karp-Rabin (different phrases) and cuts about as often (1 / p)"""
     text = O.gen_fasta(400000, 3, 0.001, 9)
