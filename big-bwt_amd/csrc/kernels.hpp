@@ -24,6 +24,7 @@ struct StagedText {
 struct KRParams {
   static constexpr uint32_t kMaxExtra = 32;
   uint32_t negpw, pinv, pshift, plimit;
+  float fdens = 1.0f;                          // the density the scan cuts at (x nominal)
   uint32_t fthr_nom = 0, fauto = 0;            // nominal threshold (density 1 / p); fauto: the chain chooses between fthr_nom and fthr = twice that
   uint32_t fast = 0, fseed = 0, fthr = 0;      // fused chain only (round 4): the cheap window hash of scan.hip instead of Karp-Rabin
   uint32_t nextra;            // extra trigger hashes (fused chain only), 0 in the reference-exact scan

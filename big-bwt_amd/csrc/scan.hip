@@ -386,11 +386,15 @@ KRParams make_fast_params(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, u
   // pfp_set_parse_density: 0 (default) = the chain chooses between the nominal density 1 / p and twice that (see
   // choose_parse_density below): the scan then cuts at 2 / p and remembers the nominal threshold; d > 0 = cut at d / p
   const bool auto_density = !(c->parse_density > 0);
-  const double dens = auto_density ? 2.0 : c->parse_density;
+  // (the dense candidate aims at phrases of ~48 bytes: measured optimum for collections at 10^-3 mutations per base, -p 100: 2-2.5
+  //  times the nominal density, -p 200: 4 times)
+  const double dens_auto = std::min(8.0, std::max(1.0, (double)p / 48.0));
+  const double dens = auto_density ? dens_auto : c->parse_density;
+  kp.fdens = (float)dens;
   const double thr_nom = 4294967296.0 / (double)p, thr = thr_nom * dens;
   kp.fthr = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
   kp.fthr_nom = auto_density ? (thr_nom >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr_nom) : kp.fthr;
-  kp.fauto = auto_density ? 1u : 0u;
+  kp.fauto = (auto_density && dens > 1.0) ? 1u : 0u;
   bool have_first = false, ref_first = false;
   uint8_t fw[32] = {0};
   if (n >= (uint64_t)w) {
@@ -477,7 +481,7 @@ uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t
       // one pass: masks, counts, look-back and placement in one kernel (kr_scan_kernel)
       const KRParams kp = kp_override ? *kp_override : make_kr_params(w, p);
       const uint64_t ntiles = cdiv64((uint64_t)nblocks, kScanChunks);
-      const uint64_t expect = cur_n / (p ? p : 1);
+      const uint64_t expect = (uint64_t)((double)(cur_n / (p ? p : 1)) * (kp.fast && kp.fdens > 1.0f ? (double)kp.fdens : 1.0));
       const uint64_t cap = cap_hint ? cap_hint : std::min<uint64_t>(cur_n, expect * 4 + 65536);
       d_ends.alloc(c, cap + 1);
       DBuf<unsigned long long> state(c, ntiles);
@@ -628,10 +632,11 @@ uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_use
 // mutation makes a new word of length ~L) while the parse shrinks (n / L phrases), and the dictionary's suffix sort and merge are
 // what the chain spends its time on: twice the trigger density takes configs[2] from 37.9 to 32.6 ms and halves the peak memory
 // (12.6 GB: 141 -> 78 GB); a single genome, whose dictionary is the text whatever L is, only pays for the longer parse.  The
-// outputs do not depend on the choice.  So the fused chain scans ONCE at twice the nominal density -
-// `x < 2 thr` contains `x < thr` - looks at a content-defined sample of the cuts (x < thr / 16: the same loci in every copy) and
-// counts how many of the 64-byte contexts before them are distinct: mean multiplicity >= 8 means a collection of near-identical
-// copies and all cuts are kept, else the cuts outside the nominal threshold are dropped again and the parse is the one -p asks for.
+// outputs do not depend on the choice.  So the fused chain scans ONCE at the dense candidate (phrases of ~48
+// bytes: p / 48 times the nominal density; `x < d thr` contains `x < thr`), looks at a content-defined sample of the cuts
+// (x < thr / 16: the same loci in every copy) and sorts the hashes of the 64-byte contexts before them: contexts seen at least
+// twice are loci, contexts seen once the variants around them; where the variants outweigh the loci all cuts are kept, else the
+// cuts outside the nominal threshold are dropped again and the parse is the one -p asks for.
 // pfp_set_parse_density(ctx, 1) / PFP_PARSE_DENSITY=1 pins the nominal density; pfp_stats.parse_density reports what was used.
 __global__ void classify_ends_kernel(const uint8_t *__restrict__ tbase, const uint64_t *__restrict__ ends, uint64_t ne, int w,
                                      uint32_t seed, uint32_t thr_nom, uint32_t thr_sample, uint8_t *__restrict__ nominal,
@@ -653,11 +658,13 @@ __global__ void context_hash_kernel(const uint8_t *__restrict__ tbase, const uin
   for (int j = 0; j < 8; j++) h = fmix64(h ^ ld8u(q + 8 * j)) + 0x632BE59BD9B4E019ull * (uint64_t)(j + 1);
   out[k] = h;
 }
+// out[0] = distinct values, out[1] = values that occur exactly once
 __global__ void count_distinct_kernel(const uint64_t *__restrict__ sorted, uint64_t ns, unsigned long long *__restrict__ out) {
   const uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
   const bool head = k < ns && (k == 0 || sorted[k] != sorted[k - 1]);
-  const unsigned long long m = __ballot(head);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+  const bool single = head && (k + 1 == ns || sorted[k + 1] != sorted[k]);
+  const unsigned long long m = __ballot(head), m1 = __ballot(single);
+  if ((threadIdx.x & 63) == 0 && m) { atomicAdd(out, (unsigned long long)__popcll(m)); if (m1) atomicAdd(out + 1, (unsigned long long)__popcll(m1)); }
 }
 __global__ void gather_ends_kernel(const uint64_t *__restrict__ ends, const uint32_t *__restrict__ idx, uint64_t cnt, uint64_t *__restrict__ out) {
   const uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
@@ -665,7 +672,7 @@ __global__ void gather_ends_kernel(const uint64_t *__restrict__ ends, const uint
 }
 // the scan cut at kp.fthr = twice the nominal density: keep that (returns ne, *dense = true) or fall back to the nominal cuts
 // (d_ends compacted, kp.fthr lowered to the nominal threshold for every later rescan)
-static uint64_t choose_parse_density(pfp_ctx *c, const StagedText &tx, int w, DBuf<uint64_t> &d_ends, uint64_t ne, KRParams &kp, bool *dense) {
+static uint64_t choose_parse_density(pfp_ctx *c, const StagedText &tx, int w, uint64_t p, DBuf<uint64_t> &d_ends, uint64_t ne, KRParams &kp, bool *dense) {
   *dense = false;
   PFP_REQUIRE(ne < 0xFFFFFFFFull, PFP_ELIMIT, "more than 2^32 - 2 phrases (bwtparse.c:93)");
   DBuf<uint8_t> nominal(c, ne + 16), sample(c, ne + 16);
@@ -677,14 +684,21 @@ static uint64_t choose_parse_density(pfp_ctx *c, const StagedText &tx, int w, DB
   if (ns >= 1024) {
     DBuf<uint32_t> idx(c, ns);
     DBuf<uint64_t> cnt(c, 1), h(c, ns), hs(c, ns);
-    DBuf<unsigned long long> nd(c, 1);
+    DBuf<unsigned long long> nd(c, 2);
     select_index<uint32_t>(c, sample.p, idx.p, cnt.p, ne);
     hipLaunchKernelGGL(context_hash_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, tx.tbase(), d_ends.p, idx.p, ns, h.p);
     sort_keys_raw(c, h.p, hs.p, ns, 0, 64);
     nd.zero();
     hipLaunchKernelGGL(count_distinct_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, hs.p, ns, nd.p);
-    const uint64_t distinct = read_scalar(c, (const uint64_t *)nd.p);
-    *dense = distinct * 8 <= ns;          // mean multiplicity of a sampled context >= 8
+    PFP_HIP(hipMemcpyAsync(c->h_scalars, nd.p, 16, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    const uint64_t distinct = c->h_scalars[0], singles = c->h_scalars[1], loci = distinct - singles;
+    // contexts seen twice or more are the collection's loci, contexts seen once the variants around them: V / U = copies x 64 r, and
+    // what shorter phrases save is the variants' share of the dictionary, c r L = (V / U) (p / 64): worth it from about 1
+    // (16 copies at 10^-3: 1.5, measured -14 %; 64 copies at 10^-4: 0.6, left alone)
+    // - in a COLLECTION, that is: where most sampled contexts repeat at all.  (A single genome with satellite arrays and repeat
+    // families has loci too, and singles in plenty - its unique sequence: c2r lost 16 ms to shorter phrases before this condition.)
+    *dense = loci >= 64 && singles * 2 <= ns && singles * p >= loci * 64;
   }
   if (*dense) return ne;
   const uint64_t n1 = count_flags(c, nominal.p, ne);
@@ -706,8 +720,8 @@ uint64_t scan_text_adaptive(pfp_ctx *c, const StagedText &tx, uint64_t n, int w,
   c->stats.parse_density = kp.fast ? (c->parse_density > 0 ? c->parse_density : 1.0) : 1.0;
   if (kp.fast && kp.fauto && ne > 0) {
     bool dense = false;
-    ne = choose_parse_density(c, tx, w, d_ends, ne, kp, &dense);
-    c->stats.parse_density = dense ? 2.0 : 1.0;
+    ne = choose_parse_density(c, tx, w, p, d_ends, ne, kp, &dense);
+    c->stats.parse_density = dense ? (double)kp.fdens : 1.0;
   }
   if (kp.fast && ne == 0) {      // no cut at all: the reference's own hash decides whether this text has a parse (bwtparse.c:244)
     kp = make_kr_params(w, p);

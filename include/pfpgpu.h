@@ -254,9 +254,9 @@ void pfp_set_window_hash(pfp_ctx *ctx, int fast);
  * work does - for c copies at mutation rate r the dictionary grows with the phrase length (about G (1 + c r L) bytes) while the
  * parse shrinks (n / L phrases), so a collection of many near-identical copies is processed faster, and in half the memory, with
  * shorter phrases (density 2 = what -p p/2 would parse like), and a single genome is not.  density = 0 (default; PFP_PARSE_DENSITY
- * in the environment at pfp_ctx_create sets another): the chain decides between 1 and 2 itself - one scan at 2 / p, a
- * content-defined sample of the cuts, all cuts kept if the sampled 64-byte contexts occur 8 times each on average, else the cuts
- * beyond 1 / p dropped again (scan.hip: choose_parse_density).  density = 1 pins what -p says; the staged entry points and the stage
+ * in the environment at pfp_ctx_create sets another): the chain decides between 1 and p / 48 (phrases of ~48 bytes) itself - one
+ * scan at the higher density, a content-defined sample of the cuts, all cuts kept if the sampled 64-byte contexts show more
+ * variants than loci (weighted by the phrase length), else the cuts beyond 1 / p dropped again (scan.hip: choose_parse_density).  density = 1 pins what -p says; the staged entry points and the stage
  * executables always parse exactly like the reference.  pfp_stats.parse_density tells what a call used; `bigbwt --density D`. */
 int pfp_set_parse_density(pfp_ctx *ctx, double density);
 /* Index width of dictionary positions and suffix-array slots: 0 = by size (32 bits below 4 GiB of dictionary /

@@ -312,7 +312,7 @@ def test_configs4_flag_set_on_12_6_gb(pkg, ctx, synth, golden_full, name):
         assert set(got) == {"bwt", "ssa"}
         check(got, g)
         st = ctx.stats()
-        assert st["parse_density"] == 2.0 and st["dict_size"] < (1 << 31), st
+        assert st["parse_density"] > 2.0 and st["dict_size"] < (1 << 31), st
     finally:
         del text
         ctx.pool_trim()
