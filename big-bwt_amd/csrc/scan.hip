@@ -638,25 +638,40 @@ uint32_t propose_extra_triggers(pfp_ctx *c, const StagedText &tx, uint64_t n_use
 // twice are loci, contexts seen once the variants around them; where the variants outweigh the loci all cuts are kept, else the
 // cuts outside the nominal threshold are dropped again and the parse is the one -p asks for.
 // pfp_set_parse_density(ctx, 1) / PFP_PARSE_DENSITY=1 pins the nominal density; pfp_stats.parse_density reports what was used.
-__global__ void classify_ends_kernel(const uint8_t *__restrict__ tbase, const uint64_t *__restrict__ ends, uint64_t ne, int w,
-                                     uint32_t seed, uint32_t thr_nom, uint32_t thr_sample, uint8_t *__restrict__ nominal,
-                                     uint8_t *__restrict__ sample) {
+constexpr uint64_t kSampleSlots = 1024;
+// one pass over the cuts: is a cut inside the nominal threshold (nominal[k])?  is it one of the sample (x < thr_sample)? - then the
+// hash of the 64 bytes that end with its window goes on the sample list (wave-aggregated append: the list is sorted afterwards,
+// its order does not matter); sample_n counts every sampled cut, also those beyond the list's capacity
+__global__ __launch_bounds__(256) void classify_ends_kernel(const uint8_t *__restrict__ tbase, const uint64_t *__restrict__ ends, uint64_t ne,
+                                                            int w, uint32_t seed, uint32_t thr_nom, uint32_t thr_sample,
+                                                            uint8_t *__restrict__ nominal, uint64_t *__restrict__ sample_hash,
+                                                            uint64_t slot_cap, unsigned long long *__restrict__ slot_n) {
   const uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
-  if (k >= ne) return;
-  const uint64_t e = ends[k];
-  const uint32_t x = (fast_hash_bytes(tbase + e - (uint64_t)(w - 1), w) + seed) * kFastK;
-  nominal[k] = x < thr_nom ? 1 : 0;
-  sample[k] = x < thr_sample ? 1 : 0;
-}
-__global__ void context_hash_kernel(const uint8_t *__restrict__ tbase, const uint64_t *__restrict__ ends, const uint32_t *__restrict__ idx,
-                                    uint64_t ns, uint64_t *__restrict__ out) {
-  const uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
-  if (k >= ns) return;
-  const uint8_t *q = tbase + ends[idx[k]] - 63;      // the 64 bytes that end with the window (the staging buffer has 64 bytes of front padding)
+  bool smp = false;
+  uint64_t e = 0;
+  if (k < ne) {
+    e = ends[k];
+    const uint32_t x = (fast_hash_bytes(tbase + e - (uint64_t)(w - 1), w) + seed) * kFastK;
+    nominal[k] = x < thr_nom ? 1 : 0;
+    smp = x < thr_sample;
+  }
+  const unsigned long long m = __ballot(smp);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  // (kSampleSlots lists with a counter each: one counter for all waves was 2.3 ms of contended atomics on 16 M cuts)
+  const uint64_t slot = BID % kSampleSlots;
+  unsigned long long base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&slot_n[slot], (unsigned long long)__popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1, 64);
+  if (!smp) return;
+  uint64_t at = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (at >= slot_cap) return;
+  at += slot * slot_cap;
+  const uint8_t *q = tbase + e - 63;      // (the staging buffer has 64 bytes of front padding)
   uint64_t h = 0x9E3779B97F4A7C15ull;
 #pragma unroll
   for (int j = 0; j < 8; j++) h = fmix64(h ^ ld8u(q + 8 * j)) + 0x632BE59BD9B4E019ull * (uint64_t)(j + 1);
-  out[k] = h;
+  sample_hash[at] = h;
 }
 // out[0] = distinct values, out[1] = values that occur exactly once
 __global__ void count_distinct_kernel(const uint64_t *__restrict__ sorted, uint64_t ns, unsigned long long *__restrict__ out) {
@@ -675,19 +690,26 @@ __global__ void gather_ends_kernel(const uint64_t *__restrict__ ends, const uint
 static uint64_t choose_parse_density(pfp_ctx *c, const StagedText &tx, int w, uint64_t p, DBuf<uint64_t> &d_ends, uint64_t ne, KRParams &kp, bool *dense) {
   *dense = false;
   PFP_REQUIRE(ne < 0xFFFFFFFFull, PFP_ELIMIT, "more than 2^32 - 2 phrases (bwtparse.c:93)");
-  DBuf<uint8_t> nominal(c, ne + 16), sample(c, ne + 16);
+  DBuf<uint8_t> nominal(c, ne + 16);
   PFP_HIP(hipMemsetAsync(nominal.p + ne, 0, 16, c->stream));
-  PFP_HIP(hipMemsetAsync(sample.p + ne, 0, 16, c->stream));
+  // the sample (about 1 / (16 x density) of the cuts) is collected in kSampleSlots lists; unused places keep the all-ones filler,
+  // which sorts behind every hash
+  const uint64_t slot_cap = (ne / 8 + kSampleSlots - 1) / kSampleSlots + 64, scap = slot_cap * kSampleSlots;
+  DBuf<uint64_t> h(c, scap);
+  DBuf<unsigned long long> sn(c, kSampleSlots);
+  PFP_HIP(hipMemsetAsync(h.p, 0xff, scap * 8, c->stream));
+  sn.zero();
   hipLaunchKernelGGL(classify_ends_kernel, gdim(cdiv(ne, 256)), gdim(256), 0, c->stream, tx.tbase(), d_ends.p, ne, w, kp.fseed, kp.fthr_nom,
-                     kp.fthr_nom / 16u, nominal.p, sample.p);
-  const uint64_t ns = count_flags(c, sample.p, ne);
+                     kp.fthr_nom / 16u, nominal.p, h.p, slot_cap, sn.p);
+  std::vector<unsigned long long> hsn(kSampleSlots);
+  PFP_HIP(hipMemcpyAsync(hsn.data(), sn.p, kSampleSlots * 8, hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  uint64_t ns = 0;
+  for (unsigned long long v : hsn) ns += std::min<uint64_t>(v, slot_cap);
   if (ns >= 1024) {
-    DBuf<uint32_t> idx(c, ns);
-    DBuf<uint64_t> cnt(c, 1), h(c, ns), hs(c, ns);
+    DBuf<uint64_t> hs(c, scap);
     DBuf<unsigned long long> nd(c, 2);
-    select_index<uint32_t>(c, sample.p, idx.p, cnt.p, ne);
-    hipLaunchKernelGGL(context_hash_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, tx.tbase(), d_ends.p, idx.p, ns, h.p);
-    sort_keys_raw(c, h.p, hs.p, ns, 0, 64);
+    sort_keys_raw(c, h.p, hs.p, scap, 0, 64);
     nd.zero();
     hipLaunchKernelGGL(count_distinct_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, hs.p, ns, nd.p);
     PFP_HIP(hipMemcpyAsync(c->h_scalars, nd.p, 16, hipMemcpyDeviceToHost, c->stream));
