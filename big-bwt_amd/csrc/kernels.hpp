@@ -33,6 +33,15 @@ struct KRParams {
 };
 KRParams make_kr_params(int w, uint64_t p);
 KRParams make_fast_params(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p);
+KRParams make_fast_params_host(const uint8_t *first_window, int w, uint64_t p, double density_setting);
+// phrase length by repetitiveness (scan.hip): the pieces the single-GPU chain runs in one go and the multi-GPU chain with an
+// all-gather of the ranks' samples in between
+struct CutSample { DBuf<uint8_t> nominal; DBuf<uint64_t> hashes; uint64_t ns = 0; };
+void classify_cuts(pfp_ctx *c, const StagedText &tx, int w, const DBuf<uint64_t> &d_ends, uint64_t ne, const KRParams &kp, uint64_t min_end,
+                   CutSample &out);
+bool sample_says_dense(pfp_ctx *c, const uint64_t *d_sorted, uint64_t ns, uint64_t p);
+uint64_t keep_nominal_cuts(pfp_ctx *c, DBuf<uint64_t> &d_ends, uint64_t ne, const DBuf<uint8_t> &nominal);
+uint32_t window_hash_host(const uint8_t *win, int w, uint32_t seed);      // the seeded window hash of scan.hip, on the host
 void scan_flags(pfp_ctx *c, const uint8_t *tbase, uint64_t n, int w, uint64_t p, uint16_t *flags16,
                 uint32_t *block_counts, unsigned long long *first_bad, const KRParams *kp_override = nullptr);
 uint64_t scan_text(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, DBuf<uint64_t> &d_ends,

@@ -368,20 +368,43 @@ void run_rank(Shared &S, int rank, int device, const Job &J, RankResult &res) {
     // ---- one trigger set for all ranks (proposals for splitting giant phrases; rank 0 bans its first window's hash: it must
     //      not become an extra trigger)
     std::vector<uint32_t> extra;
+    // ---- the collection's parse plan (round 4): rank 0 holds the text's first window and makes the plan - which hash cuts the
+    //      text, with which seed, how densely - every rank receives it; a candidate density is settled from the ranks' samples
+    uint64_t plan[4] = {0, 0, 0, 0};
     {
+      uint64_t pv[5] = {0, 0, 0, 0, ~0ull};
+      if (rank == 0) st.run([&] { return pfp_dist_parse_plan(ctx, J.text, std::min<uint64_t>(n_shard, 32), w, p, (uint32_t)size, pv, &pv[4]); });
+      std::vector<uint64_t> plans;
+      agree(C, st, "parse plan", ctx, pv, 5, &plans);
+      for (int k = 0; k < 4; k++) plan[k] = plans[1 + k];      // (rank 0's row)
+      const uint64_t first_hash = plans[5];
+      if (plan[3]) {          // a candidate density: the ranks' samples of their cuts, gathered, settle it
+        const uint64_t scap = std::max<uint64_t>(4096, n_local / std::max<uint64_t>(p, 1) / 2 + 4096);
+        Dev smp;
+        uint64_t n_sample = 0;
+        st.run([&] {
+          smp.alloc(scap * 8 + 16);
+          uint32_t hashes[8]; uint32_t nh = 0;
+          return pfp_dist_propose_triggers2(ctx, d_local.p, n_local, left_len, w, p, plan, hashes, &nh, smp.p, scap, &n_sample);
+        });
+        agree(C, st, "sampling the cuts", ctx);
+        std::vector<uint64_t> sc;
+        Dev all = C.allgatherv(smp.p, n_sample * 8, sc);
+        uint64_t tot = 0;
+        for (uint64_t x : sc) tot += x;
+        st.run([&] { return pfp_dist_decide_density(ctx, all.p, tot / 8, p, plan); });
+        agree(C, st, "parse density", ctx);
+      }
       uint64_t prop[9];
       for (int k = 0; k < 9; k++) prop[k] = ~0ull;
       st.run([&] {
         uint32_t hashes[8]; uint32_t nh = 0;
-        const int rc = pfp_dist_propose_triggers(ctx, d_local.p, n_local, w, p, hashes, &nh);
+        uint64_t none = 0;
+        const int rc = pfp_dist_propose_triggers2(ctx, d_local.p, n_local, left_len, w, p, plan, hashes, &nh, nullptr, 0, &none);
         if (rc == PFP_OK) for (uint32_t k = 0; k < nh && k < 8; k++) prop[k] = hashes[k];
         return rc;
       });
-      if (rank == 0 && n_shard >= (uint64_t)w) {
-        uint64_t h0 = 0;
-        for (int k = 0; k < w; k++) h0 = (h0 * 256 + J.text[k]) % 1999999973ull;      // newscan.cpp:168-202
-        prop[8] = h0;
-      }
+      if (rank == 0) prop[8] = first_hash;
       std::vector<uint64_t> props;
       agree(C, st, "trigger proposal", ctx, prop, 9, &props);
       auto at = [&](int r, int q) { return props[(size_t)r * 10 + 1 + q]; };
@@ -403,8 +426,8 @@ void run_rank(Shared &S, int rank, int device, const Job &J, RankResult &res) {
     // ---- local parse
     uint64_t sizes[4] = {0, 0, 0, 0};
     st.run([&] {
-      const int rc = pfp_dist_local_parse(ctx, d_local.p, n_local, left_len, w, p, rank == 0, rank == size - 1, goff, flags,
-                                          extra.empty() ? nullptr : extra.data(), (uint32_t)extra.size(), sizes);
+      const int rc = pfp_dist_local_parse2(ctx, d_local.p, n_local, left_len, w, p, rank == 0, rank == size - 1, goff, flags, plan,
+                                           extra.empty() ? nullptr : extra.data(), (uint32_t)extra.size(), sizes);
       // the next rank re-derives this rank's last phrase boundary from the last tail_len bytes of the shard
       if (rc == PFP_OK && rank < size - 1 && (int64_t)sizes[3] - (int64_t)(w - 1) < (int64_t)(n_local - tail_len))
         fail(PFP_ELIMIT, "last phrase boundary lies outside the %llu-byte halo; raise --halo", (unsigned long long)tail_len);
@@ -627,6 +650,7 @@ void run_rank(Shared &S, int rank, int device, const Job &J, RankResult &res) {
     res.st.n = n_total; res.st.n_words = d_words; res.st.n_phrases = P_total; res.st.dict_size = info[1];
     res.st.index_bits = info[7]; res.st.sa_shares = parts; res.st.parse_shares = parse_shares; res.st.ranks = (uint64_t)size;
     res.st.ms_chain = ms_chain;
+    { double dens = 1.0; if (plan[0]) memcpy(&dens, &plan[2], 8); res.st.parse_density = dens; }
     res.st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   } catch (const Failure &f) {
     res.code = f.code; res.msg = f.msg;

@@ -1319,9 +1319,119 @@ int pfp_dist_propose_triggers(pfp_ctx *c, const void *d_text, uint64_t n, int w,
   PFP_CATCH(c)
 }
 
+// ---- the collection's parse plan (round 4): which hash cuts the text, with which seed, how densely
+// plan[0] 0 = the reference's Karp-Rabin hash, 1 = the window hash of scan.hip; plan[1] its seed; plan[2] the density (a double's
+// bits: the text is cut with probability density / p); plan[3] 1 while the density is a candidate the ranks still have to decide on
+static KRParams params_from_plan(int w, uint64_t p, const uint64_t plan[4]) {
+  KRParams kp = make_kr_params(w, p);
+  if (!plan || plan[0] == 0) return kp;
+  double dens;
+  memcpy(&dens, &plan[2], 8);
+  PFP_REQUIRE(w >= 4 && w <= 17 && dens >= 0.01 && dens <= 64.0, PFP_EINVAL, "bad parse plan");
+  const double thr_nom = 4294967296.0 / (double)p, thr = thr_nom * dens;
+  kp.fast = 1; kp.fseed = (uint32_t)plan[1]; kp.fdens = (float)dens; kp.fauto = 0;
+  kp.fthr = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+  kp.fthr_nom = thr_nom >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr_nom;
+  return kp;
+}
+// Rank 0 (which holds the text's first bytes) makes the plan; the hosts hand it to every rank.  first_hash: the hash of the text's
+// first window under the plan (it must not become an extra trigger: SURVEY.md 2.2-Q1), ~0 when the text is shorter than a window.
+int pfp_dist_parse_plan(pfp_ctx *c, const uint8_t *first_bytes, uint64_t n_bytes, int w, uint64_t p, uint32_t ranks, uint64_t plan[4],
+                        uint64_t *first_hash) {
+  if (!c || !plan || !first_hash || (!first_bytes && n_bytes)) return PFP_EINVAL;
+  PFP_TRY(c)
+  check_args(w, p, 0);
+  const bool have = n_bytes >= (uint64_t)w;
+  const double one = 1.0;
+  *first_hash = ~0ull;
+  if (!c->fast_triggers || w < 4 || w > 17) {
+    plan[0] = 0; plan[1] = 0; memcpy(&plan[2], &one, 8); plan[3] = 0;
+    if (have) { uint64_t h = 0; for (int k = 0; k < w; k++) h = (h * 256 + first_bytes[k]) % kPrime; *first_hash = h; }      // newscan.cpp:168-202
+    return PFP_OK;
+  }
+  // (the dictionary's work is shared between the ranks, the parse's is not - every rank's merge reads the whole parse: shorter
+  //  phrases pay on one or two ranks - 42.3 -> 35.8 and 51.1 -> 42.2 ms per rank - and no longer on eight, 71.9 -> 72.3; so the
+  //  density is a candidate only there, and nominal beyond)
+  const double setting = c->parse_density > 0 ? c->parse_density : (ranks > 2 ? 1.0 : 0.0);
+  const KRParams kp = make_fast_params_host(have ? first_bytes : nullptr, w, p, setting);
+  const double dens = (double)kp.fdens;
+  plan[0] = 1; plan[1] = kp.fseed; memcpy(&plan[2], &dens, 8); plan[3] = kp.fauto;
+  if (have) *first_hash = window_hash_host(first_bytes, w, kp.fseed);
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+// pfp_dist_propose_triggers under a plan; while the plan's density is a candidate (plan[3]) also this rank's sample of the cuts
+// at or after halo_len: at most sample_cap sorted context hashes in d_sample, *n_sample of them (the hosts all-gather the samples
+// and every rank decides alike: pfp_dist_decide_density)
+int pfp_dist_propose_triggers2(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p, const uint64_t plan[4],
+                               uint32_t out_hashes[8], uint32_t *n_hashes, void *d_sample, uint64_t sample_cap, uint64_t *n_sample) {
+  if (!c || (!d_text && n) || !out_hashes || !n_hashes || !plan || !n_sample || (sample_cap && !d_sample)) return PFP_EINVAL;
+  *n_hashes = 0; *n_sample = 0;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  check_args(w, p, 0);
+  if (!c->max_phrase && !plan[3]) return PFP_OK;
+  StagedText tx;
+  tx.stage(c, d_text, true, n, w);
+  DBuf<uint64_t> ends;
+  uint64_t used = 0;
+  KRParams kp = params_from_plan(w, p, plan);
+  const uint64_t ne = scan_text(c, tx, n, w, p, ends, &used, &kp);
+  // (proposals only under a SETTLED plan: a window of a periodic stretch may cut at the candidate density and not at the nominal
+  //  one - the stretch then looks harmless here and is one giant phrase in the parse; the hosts call this twice while plan[3] is set:
+  //  for the sample first, for the proposals after pfp_dist_decide_density)
+  if (c->max_phrase && !plan[3]) {
+    propose_extra_triggers(c, tx, used, w, c->max_phrase, ends, ne, kp);
+    for (uint32_t q = 0; q < kp.nextra && q < 8; q++) out_hashes[(*n_hashes)++] = kp.extra[q];
+  }
+  if (plan[3] && kp.fast && ne) {
+    CutSample cs;
+    classify_cuts(c, tx, w, ends, ne, kp, halo_len, cs);
+    const uint64_t take = std::min<uint64_t>(cs.ns, sample_cap);
+    if (take) PFP_HIP(hipMemcpyAsync(d_sample, cs.hashes.p, take * 8, hipMemcpyDeviceToDevice, c->stream));
+    sync(c);
+    *n_sample = take;
+  }
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+// the ranks' samples, gathered: every rank sorts them and settles the plan's density the same way (candidate kept or 1)
+int pfp_dist_decide_density(pfp_ctx *c, const void *d_samples, uint64_t count, uint64_t p, uint64_t plan[4]) {
+  if (!c || !plan || (count && !d_samples)) return PFP_EINVAL;
+  PFP_TRY(c)
+  PFP_HIP(hipSetDevice(c->device));
+  if (!plan[3]) return PFP_OK;
+  bool dense = false;
+  if (count >= 1024) {
+    DBuf<uint64_t> sorted(c, count);
+    sort_keys_raw(c, (const uint64_t *)d_samples, sorted.p, count, 0, 64);
+    dense = sample_says_dense(c, sorted.p, count, p);
+  }
+  const double one = 1.0;
+  if (!dense) memcpy(&plan[2], &one, 8);
+  plan[3] = 0;
+  return PFP_OK;
+  PFP_CATCH(c)
+}
+
+static int dist_local_parse_impl(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p, int is_first,
+                                 int is_last, uint64_t global_offset, int want_sai, const uint64_t *plan, const uint32_t *extra_hashes,
+                                 uint32_t n_extra, uint64_t out_sizes[4]);
 int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p, int is_first,
                          int is_last, uint64_t global_offset, int want_sai, const uint32_t *extra_hashes,
                          uint32_t n_extra, uint64_t out_sizes[4]) {
+  return dist_local_parse_impl(c, d_text, n, halo_len, w, p, is_first, is_last, global_offset, want_sai, nullptr, extra_hashes, n_extra, out_sizes);
+}
+// the same under a (decided) parse plan
+int pfp_dist_local_parse2(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p, int is_first,
+                          int is_last, uint64_t global_offset, int want_sai, const uint64_t plan[4], const uint32_t *extra_hashes,
+                          uint32_t n_extra, uint64_t out_sizes[4]) {
+  if (!plan || plan[3]) return PFP_EINVAL;
+  return dist_local_parse_impl(c, d_text, n, halo_len, w, p, is_first, is_last, global_offset, want_sai, plan, extra_hashes, n_extra, out_sizes);
+}
+static int dist_local_parse_impl(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p, int is_first,
+                                 int is_last, uint64_t global_offset, int want_sai, const uint64_t *plan, const uint32_t *extra_hashes,
+                                 uint32_t n_extra, uint64_t out_sizes[4]) {
   if (!c || (!d_text && n) || !out_sizes || (n_extra && !extra_hashes)) return PFP_EINVAL;
   PFP_TRY(c)
   PFP_HIP(hipSetDevice(c->device));
@@ -1336,7 +1446,8 @@ int pfp_dist_local_parse(pfp_ctx *c, const void *d_text, uint64_t n, uint64_t ha
   st = pfp_stats{};
   ds->tx.stage(c, d_text, true, n, w);
   uint64_t used = 0;
-  KRParams kp = make_kr_params(w, p);                              // one trigger set on all ranks
+  KRParams kp = params_from_plan(w, p, plan);                      // one trigger set on all ranks
+  st.parse_density = kp.fast ? (double)kp.fdens : 1.0;
   for (uint32_t q = 0; q < n_extra; q++) { kp.extra[kp.nextra++] = extra_hashes[q]; kp.bloom |= 1ull << (extra_hashes[q] & 63); }
   { PhaseTimer t(c, &st.ms_scan);
     ds->n_ends = scan_text(c, ds->tx, n, w, p, ds->ends, &used, &kp); }

@@ -379,17 +379,28 @@ KRParams make_kr_params(int w, uint64_t p) {
 }
 
 // the fused chain's trigger for a staged text (see fast_triggers): needs the text's first window for the seed
+uint32_t window_hash_host(const uint8_t *win, int w, uint32_t seed) { return fast_hash_bytes(win, w) + seed; }
 KRParams make_fast_params(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p) {
+  uint8_t fw[32] = {0};
+  const bool have = n >= (uint64_t)w && w <= 32;
+  if (have) {
+    PFP_HIP(hipMemcpyAsync(fw, tx.tbase(), (size_t)w, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+  }
+  return make_fast_params_host(have ? fw : nullptr, w, p, c->parse_density);
+}
+// the same from the window's bytes (host): what the multi-GPU hosts' rank 0 computes for everybody (pfp_dist_parse_plan)
+KRParams make_fast_params_host(const uint8_t *first_window, int w, uint64_t p, double density_setting) {
   KRParams kp = make_kr_params(w, p);
   if (w < 4 || w > 17) return kp;          // (the register path of the scan kernel; wider windows keep Karp-Rabin)
   kp.fast = 1;
   // pfp_set_parse_density: 0 (default) = the chain chooses between the nominal density 1 / p and twice that (see
   // choose_parse_density below): the scan then cuts at 2 / p and remembers the nominal threshold; d > 0 = cut at d / p
-  const bool auto_density = !(c->parse_density > 0);
+  const bool auto_density = !(density_setting > 0);
   // (the dense candidate aims at phrases of ~48 bytes: measured optimum for collections at 10^-3 mutations per base, -p 100: 2-2.5
   //  times the nominal density, -p 200: 4 times)
   const double dens_auto = std::min(8.0, std::max(1.0, (double)p / 48.0));
-  const double dens = auto_density ? dens_auto : c->parse_density;
+  const double dens = auto_density ? dens_auto : density_setting;
   kp.fdens = (float)dens;
   const double thr_nom = 4294967296.0 / (double)p, thr = thr_nom * dens;
   kp.fthr = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
@@ -397,9 +408,8 @@ KRParams make_fast_params(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, u
   kp.fauto = (auto_density && dens > 1.0) ? 1u : 0u;
   bool have_first = false, ref_first = false;
   uint8_t fw[32] = {0};
-  if (n >= (uint64_t)w) {
-    PFP_HIP(hipMemcpyAsync(fw, tx.tbase(), (size_t)w, hipMemcpyDeviceToHost, c->stream));
-    sync(c);
+  if (first_window) {
+    memcpy(fw, first_window, (size_t)w);
     uint64_t h = 0;
     for (int k = 0; k < w; k++) h = (h * 256 + fw[k]) % kPrime;      // newscan.cpp:168-202
     ref_first = h % p == 0;
@@ -643,7 +653,7 @@ constexpr uint64_t kSampleSlots = 1024;
 // hash of the 64 bytes that end with its window goes on the sample list (wave-aggregated append: the list is sorted afterwards,
 // its order does not matter); sample_n counts every sampled cut, also those beyond the list's capacity
 __global__ __launch_bounds__(256) void classify_ends_kernel(const uint8_t *__restrict__ tbase, const uint64_t *__restrict__ ends, uint64_t ne,
-                                                            int w, uint32_t seed, uint32_t thr_nom, uint32_t thr_sample,
+                                                            int w, uint32_t seed, uint32_t thr_nom, uint32_t thr_sample, uint64_t min_end,
                                                             uint8_t *__restrict__ nominal, uint64_t *__restrict__ sample_hash,
                                                             uint64_t slot_cap, unsigned long long *__restrict__ slot_n) {
   const uint64_t k = (uint64_t)BID * blockDim.x + threadIdx.x;
@@ -653,7 +663,7 @@ __global__ __launch_bounds__(256) void classify_ends_kernel(const uint8_t *__res
     e = ends[k];
     const uint32_t x = (fast_hash_bytes(tbase + e - (uint64_t)(w - 1), w) + seed) * kFastK;
     nominal[k] = x < thr_nom ? 1 : 0;
-    smp = x < thr_sample;
+    smp = x < thr_sample && e >= min_end;
   }
   const unsigned long long m = __ballot(smp);
   if (!m) return;
@@ -687,10 +697,13 @@ __global__ void gather_ends_kernel(const uint64_t *__restrict__ ends, const uint
 }
 // the scan cut at kp.fthr = twice the nominal density: keep that (returns ne, *dense = true) or fall back to the nominal cuts
 // (d_ends compacted, kp.fthr lowered to the nominal threshold for every later rescan)
-static uint64_t choose_parse_density(pfp_ctx *c, const StagedText &tx, int w, uint64_t p, DBuf<uint64_t> &d_ends, uint64_t ne, KRParams &kp, bool *dense) {
-  *dense = false;
+// classify the cuts of a scan at the dense candidate: out.nominal[k] = cut k lies inside the nominal threshold; out.hashes = the
+// context hashes of the sampled cuts at or after min_end, sorted, out.ns of them
+void classify_cuts(pfp_ctx *c, const StagedText &tx, int w, const DBuf<uint64_t> &d_ends, uint64_t ne, const KRParams &kp, uint64_t min_end,
+                   CutSample &out) {
   PFP_REQUIRE(ne < 0xFFFFFFFFull, PFP_ELIMIT, "more than 2^32 - 2 phrases (bwtparse.c:93)");
-  DBuf<uint8_t> nominal(c, ne + 16);
+  out.nominal.alloc(c, ne + 16);
+  DBuf<uint8_t> &nominal = out.nominal;
   PFP_HIP(hipMemsetAsync(nominal.p + ne, 0, 16, c->stream));
   // the sample (about 1 / (16 x density) of the cuts) is collected in kSampleSlots lists; unused places keep the all-ones filler,
   // which sorts behind every hash
@@ -700,29 +713,35 @@ static uint64_t choose_parse_density(pfp_ctx *c, const StagedText &tx, int w, ui
   PFP_HIP(hipMemsetAsync(h.p, 0xff, scap * 8, c->stream));
   sn.zero();
   hipLaunchKernelGGL(classify_ends_kernel, gdim(cdiv(ne, 256)), gdim(256), 0, c->stream, tx.tbase(), d_ends.p, ne, w, kp.fseed, kp.fthr_nom,
-                     kp.fthr_nom / 16u, nominal.p, h.p, slot_cap, sn.p);
+                     kp.fthr_nom / 16u, min_end, nominal.p, h.p, slot_cap, sn.p);
   std::vector<unsigned long long> hsn(kSampleSlots);
   PFP_HIP(hipMemcpyAsync(hsn.data(), sn.p, kSampleSlots * 8, hipMemcpyDeviceToHost, c->stream));
   sync(c);
   uint64_t ns = 0;
   for (unsigned long long v : hsn) ns += std::min<uint64_t>(v, slot_cap);
-  if (ns >= 1024) {
-    DBuf<uint64_t> hs(c, scap);
-    DBuf<unsigned long long> nd(c, 2);
-    sort_keys_raw(c, h.p, hs.p, scap, 0, 64);
-    nd.zero();
-    hipLaunchKernelGGL(count_distinct_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, hs.p, ns, nd.p);
-    PFP_HIP(hipMemcpyAsync(c->h_scalars, nd.p, 16, hipMemcpyDeviceToHost, c->stream));
-    sync(c);
-    const uint64_t distinct = c->h_scalars[0], singles = c->h_scalars[1], loci = distinct - singles;
-    // contexts seen twice or more are the collection's loci, contexts seen once the variants around them: V / U = copies x 64 r, and
-    // what shorter phrases save is the variants' share of the dictionary, c r L = (V / U) (p / 64): worth it from about 1
-    // (16 copies at 10^-3: 1.5, measured -14 %; 64 copies at 10^-4: 0.6, left alone)
-    // - in a COLLECTION, that is: where most sampled contexts repeat at all.  (A single genome with satellite arrays and repeat
-    // families has loci too, and singles in plenty - its unique sequence: c2r lost 16 ms to shorter phrases before this condition.)
-    *dense = loci >= 64 && singles * 2 <= ns && singles * p >= loci * 64;
-  }
-  if (*dense) return ne;
+  out.ns = ns;
+  out.hashes.alloc(c, scap);
+  sort_keys_raw(c, h.p, out.hashes.p, scap, 0, 64);      // (the valid hashes first: the filler is all ones)
+}
+// a sorted sample of context hashes (a rank's own, or the ranks' samples gathered and sorted again): does it show a collection
+// whose variants outweigh its loci?
+bool sample_says_dense(pfp_ctx *c, const uint64_t *d_sorted, uint64_t ns, uint64_t p) {
+  if (ns < 1024) return false;
+  DBuf<unsigned long long> nd(c, 2);
+  nd.zero();
+  hipLaunchKernelGGL(count_distinct_kernel, gdim(cdiv(ns, 256)), gdim(256), 0, c->stream, d_sorted, ns, nd.p);
+  PFP_HIP(hipMemcpyAsync(c->h_scalars, nd.p, 16, hipMemcpyDeviceToHost, c->stream));
+  sync(c);
+  const uint64_t distinct = c->h_scalars[0], singles = c->h_scalars[1], loci = distinct - singles;
+  // contexts seen twice or more are the collection's loci, contexts seen once the variants around them: V / U = copies x 64 r, and
+  // what shorter phrases save is the variants' share of the dictionary, c r L = (V / U) (p / 64): worth it from about 1
+  // (16 copies at 10^-3: 1.5, measured -14 %; 64 copies at 10^-4: 0.6, left alone)
+  // - in a COLLECTION, that is: where most sampled contexts repeat at all.  (A single genome with satellite arrays and repeat
+  // families has loci too, and singles in plenty - its unique sequence: c2r lost 16 ms to shorter phrases before this condition.)
+  return loci >= 64 && singles * 2 <= ns && singles * p >= loci * 64;
+}
+// drop the cuts outside the nominal threshold again; returns how many stay
+uint64_t keep_nominal_cuts(pfp_ctx *c, DBuf<uint64_t> &d_ends, uint64_t ne, const DBuf<uint8_t> &nominal) {
   const uint64_t n1 = count_flags(c, nominal.p, ne);
   DBuf<uint64_t> keep(c, n1 + 1), cnt(c, 1);
   DBuf<uint32_t> idx(c, n1 + 1);
@@ -730,8 +749,17 @@ static uint64_t choose_parse_density(pfp_ctx *c, const StagedText &tx, int w, ui
   if (n1) hipLaunchKernelGGL(gather_ends_kernel, gdim(cdiv(n1, 256)), gdim(256), 0, c->stream, d_ends.p, idx.p, n1, keep.p);
   PFP_HIP(hipGetLastError());
   d_ends = std::move(keep);
-  kp.fthr = kp.fthr_nom;
   return n1;
+}
+// the scan cut at kp.fthr = the dense candidate: keep that (returns ne, *dense = true) or fall back to the nominal cuts
+// (d_ends compacted, kp.fthr lowered to the nominal threshold for every later rescan)
+static uint64_t choose_parse_density(pfp_ctx *c, const StagedText &tx, int w, uint64_t p, DBuf<uint64_t> &d_ends, uint64_t ne, KRParams &kp, bool *dense) {
+  CutSample cs;
+  classify_cuts(c, tx, w, d_ends, ne, kp, 0, cs);
+  *dense = sample_says_dense(c, cs.hashes.p, cs.ns, p);
+  if (*dense) return ne;
+  kp.fthr = kp.fthr_nom;
+  return keep_nominal_cuts(c, d_ends, ne, cs.nominal);
 }
 
 uint64_t scan_text_adaptive(pfp_ctx *c, const StagedText &tx, uint64_t n, int w, uint64_t p, uint64_t max_phrase,

@@ -127,6 +127,12 @@ class _Step:
         raise pfp.PfpError(code, f"{what} failed on rank {r}; every rank stops here")
 
 
+def _s64(x):
+    """an unsigned 64-bit value as the int64 a tensor holds"""
+    x &= 0xFFFFFFFFFFFFFFFF
+    return x - (1 << 64) if x >> 63 else x
+
+
 # ----------------------------------------------------------------------------- the algorithm
 def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shard_sa=True, dedup="alltoall", shard_parse=True):
     """Generator.  `shard`: 1-D uint8 device tensor, this rank's byte range of the text.
@@ -155,19 +161,46 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
     left = tails[rank - 1] if rank > 0 else shard[:0]
     local = torch.cat([left, shard]).contiguous() if rank > 0 else shard.contiguous()
     torch.cuda.synchronize(dev)
-    # --- one trigger set for all ranks: the reference's plus the union of every rank's proposals for
-    #     splitting giant phrases (N runs); the outputs do not depend on the parse
-    mine = step.run(lambda: ctx.dist_propose_triggers(local.data_ptr(), local.numel(), w, p)) or []
+    # --- the collection's parse plan (round 4: the window hash and the phrase length by repetitiveness of the single-GPU chain,
+    #     agreed between the ranks): rank 0 holds the text's first window and makes the plan, everybody receives it
+    plan_t = torch.zeros(6, dtype=torch.int64, device=dev)          # plan[0..3], first window's hash under it, status
+    if rank == 0:
+        made = step.run(lambda: ctx.dist_parse_plan(bytes(shard[: min(n_shard, 32)].tolist()), w, p, size))
+        if made is not None:
+            pl, fh = made
+            plan_t[:5] = torch.tensor([_s64(x) for x in pl] + [_s64(fh)], dtype=torch.int64, device=dev)
+    plan_t[5] = step.status()[0]
+    plans = yield ("allgather", plan_t)
+    step.check([t[5:6] for t in plans], "parse plan")
+    plan = [int(v) & 0xFFFFFFFFFFFFFFFF for v in plans[0][:4].tolist()]
+    first_hash = int(plans[0][4]) & 0xFFFFFFFFFFFFFFFF
+    # --- one trigger set for all ranks: the plan's plus the union of every rank's proposals for splitting giant phrases (N runs);
+    #     with a candidate density in the plan also a sample of every rank's cuts: the samples are gathered and every rank settles
+    #     the density alike (the outputs do not depend on the parse)
+    if plan[3]:
+        scap = max(4096, local.numel() // max(1, p) // 2 + 4096)
+        d_sample = torch.empty(scap, dtype=torch.int64, device=dev)
+        got = step.run(lambda: ctx.dist_propose_triggers2(local.data_ptr(), local.numel(), left.numel(), w, p, plan, d_sample.data_ptr(), scap))
+        n_sample = got[1] if got is not None else 0
+        st = yield ("allgather", step.status())
+        step.check(st, "sampling the cuts")
+        samples = yield ("allgather", d_sample[:n_sample].contiguous())
+        allsmp = torch.cat(samples).contiguous()
+        torch.cuda.synchronize(dev)
+        settled = step.run(lambda: ctx.dist_decide_density(allsmp.data_ptr(), allsmp.numel(), p, plan))
+        st = yield ("allgather", step.status())
+        step.check(st, "parse density")
+        plan = settled
+        del samples, allsmp, d_sample
+    got = step.run(lambda: ctx.dist_propose_triggers2(local.data_ptr(), local.numel(), left.numel(), w, p, plan, 0, 0))
+    mine = got[0] if got is not None else []
     prop = torch.full((10,), -1, dtype=torch.int64, device=dev)
     if mine:
         prop[: len(mine)] = torch.tensor(mine, dtype=torch.int64, device=dev)
-    if rank == 0 and n_shard >= w:
+    if rank == 0 and first_hash != 0xFFFFFFFFFFFFFFFF:
         # the text's first window must not become an extra trigger (it would turn the end-of-string byte of
         # the BWT into the reference's first-window quirk): rank 0 announces its hash
-        h0 = 0
-        for b in shard[:w].tolist():
-            h0 = (h0 * 256 + b) % 1999999973          # newscan.cpp:168-202
-        prop[8] = h0
+        prop[8] = first_hash
     prop[9] = step.status()[0]
     props = yield ("allgather", prop)
     step.check([t[9:10] for t in props], "trigger proposal")
@@ -182,8 +215,8 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
     extra.sort()
 
     def local_parse():
-        info = ctx.dist_local_parse(local.data_ptr(), local.numel(), left.numel(), w, p, rank == 0, rank == size - 1, goff, flags,
-                                    extra)
+        info = ctx.dist_local_parse2(local.data_ptr(), local.numel(), left.numel(), w, p, rank == 0, rank == size - 1, goff, flags,
+                                     plan, extra)
         # the next rank re-derives my last phrase boundary from the last tail.numel() bytes of my shard
         if rank < size - 1 and info["last_trigger"] - (w - 1) < local.numel() - tail.numel():
             raise pfp.PfpError(-5, f"rank {rank}: last phrase boundary lies outside the {tail.numel()}-byte halo; raise `halo`")
@@ -372,6 +405,7 @@ def phases(ctx, shard, rank, size, w=10, p=100, flags=0, halo=DEFAULT_HALO, shar
                 out[key + "_off"] = 10 * sum(int(t[j]) for t in ks[:rank])
         out["sampled_total"] = {key: sum(int(t[j]) for t in ks) for j, key in enumerate(("ssa", "esa")) if key in out}
     out["stats"] = dict(local=info, glob=ginfo, phrases_total=int(sym_all.numel()), shard_bytes=n_shard, extra_triggers=len(extra),
+                        parse_density=(__import__("struct").unpack("<d", __import__("struct").pack("<Q", plan[2]))[0] if plan[0] else 1.0),
                         sa_shares=parts, parse_shares=parse_shares, dedup=dedup)
     return out
 

@@ -30,7 +30,7 @@ ERRORS = {0: "PFP_OK", -1: "PFP_EINVAL", -2: "PFP_ENODEV", -3: "PFP_EHIP", -4: "
 SYMBOLS = ["pfp_device_count", "pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror", "pfp_version", "pfp_ctx_stream",
            "pfp_free", "pfp_debug_check", "pfp_get_mem_stats", "pfp_get_pool_counters", "pfp_pool_trim", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak", "pfp_sacak_int64", "pfp_sacak64", "pfp_gsacak64", "pfp_gsacak_lcp_da", "pfp_gsacak_lcp_da64",
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_files", "pfp_bigbwt_dev", "pfp_bigbwt_formats_dev", "pfp_dev_free", "pfp_memcpy_d2h", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
-           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_window_hash", "pfp_set_parse_density", "pfp_debug_msd_sort", "pfp_bigbwt_fd", "pfp_multi_rccl_selftest", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
+           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_window_hash", "pfp_set_parse_density", "pfp_debug_msd_sort", "pfp_dist_parse_plan", "pfp_dist_propose_triggers2", "pfp_dist_decide_density", "pfp_dist_local_parse2", "pfp_bigbwt_fd", "pfp_multi_rccl_selftest", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
            "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_partition_words", "pfp_dist_export_partition",
            "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_sample_runs", "pfp_dist_release", "pfp_bigbwt_files_multi", "pfp_dist_parse_sort", "pfp_dist_set_parse_sa"]
 
@@ -434,6 +434,40 @@ class Context:
                                                   C.c_uint32(len(extra)), sizes))
         return dict(dict_bytes=int(sizes[0]), words=int(sizes[1]), phrases=int(sizes[2]), last_trigger=int(sizes[3]))
 
+    def dist_parse_plan(self, first_bytes, w, p, ranks=1):
+        """rank 0: (plan, first_hash) from the text's first bytes (pfp_dist_parse_plan); plan = four 64-bit integers"""
+        fb = np.ascontiguousarray(np.frombuffer(bytes(first_bytes), dtype=np.uint8))
+        plan = (C.c_uint64 * 4)()
+        fh = C.c_uint64()
+        self._check(self.lib.pfp_dist_parse_plan(self._h, fb.ctypes.data_as(C.POINTER(C.c_uint8)) if len(fb) else None, C.c_uint64(len(fb)),
+                                                 C.c_int(w), C.c_uint64(p), C.c_uint32(ranks), plan, C.byref(fh)))
+        return [int(x) for x in plan], int(fh.value)
+
+    def dist_propose_triggers2(self, d_text_ptr, n, halo_len, w, p, plan, d_sample_ptr, sample_cap):
+        hashes = (C.c_uint32 * 8)()
+        cnt = C.c_uint32()
+        ns = C.c_uint64()
+        pl = (C.c_uint64 * 4)(*plan)
+        self._check(self.lib.pfp_dist_propose_triggers2(self._h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_uint64(halo_len), C.c_int(w),
+                                                        C.c_uint64(p), pl, hashes, C.byref(cnt), C.c_void_p(d_sample_ptr) if sample_cap else None,
+                                                        C.c_uint64(sample_cap), C.byref(ns)))
+        return [int(hashes[i]) for i in range(cnt.value)], int(ns.value)
+
+    def dist_decide_density(self, d_samples_ptr, count, p, plan):
+        pl = (C.c_uint64 * 4)(*plan)
+        self._check(self.lib.pfp_dist_decide_density(self._h, C.c_void_p(d_samples_ptr) if count else None, C.c_uint64(count), C.c_uint64(p), pl))
+        return [int(x) for x in pl]
+
+    def dist_local_parse2(self, d_text_ptr, n, halo_len, w, p, is_first, is_last, global_offset, want_sai, plan, extra=()):
+        sizes = (C.c_uint64 * 4)()
+        ex = (C.c_uint32 * max(1, len(extra)))(*extra)
+        pl = (C.c_uint64 * 4)(*plan)
+        self._check(self.lib.pfp_dist_local_parse2(self._h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_uint64(halo_len),
+                                                   C.c_int(w), C.c_uint64(p), C.c_int(int(is_first)), C.c_int(int(is_last)),
+                                                   C.c_uint64(global_offset), C.c_int(int(want_sai)), pl, ex,
+                                                   C.c_uint32(len(extra)), sizes))
+        return dict(dict_bytes=int(sizes[0]), words=int(sizes[1]), phrases=int(sizes[2]), last_trigger=int(sizes[3]))
+
     def dist_export_local(self, d_dict=None, d_occ=None, d_last=None, d_sai=None):
         vp = lambda x: C.c_void_p(x) if x else None
         self._check(self.lib.pfp_dist_export_local(self._h, vp(d_dict), vp(d_occ), vp(d_last), vp(d_sai)))
@@ -527,7 +561,7 @@ def bigbwt_files_multi(text, base, devices, w=10, p=100, flags=0, halo=0):
 
     class MultiStats(C.Structure):
         _fields_ = [(k, C.c_uint64) for k in ("n", "n_words", "n_phrases", "dict_size", "index_bits", "ranks", "sa_shares", "parse_shares")] + \
-                   [("ms_chain", C.c_double), ("ms_total", C.c_double)]
+                   [("ms_chain", C.c_double), ("ms_total", C.c_double), ("parse_density", C.c_double)]
     text = _arr(text, np.uint8)
     st = MultiStats()
     err = C.create_string_buffer(1024)

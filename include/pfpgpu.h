@@ -309,6 +309,28 @@ int pfp_dist_propose_triggers(pfp_ctx *ctx, const void *d_text, uint64_t n, int 
 int pfp_dist_local_parse(pfp_ctx *ctx, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p,
                          int is_first, int is_last, uint64_t global_offset, int want_sai,
                          const uint32_t *extra_hashes, uint32_t n_extra, uint64_t out_sizes[4]);
+/* Round 4: the multi-GPU chain under a PARSE PLAN - the window hash and the phrase length by repetitiveness of the fused chain
+ * (pfp_set_window_hash, pfp_set_parse_density), agreed between the ranks.  plan[4]: [0] 0 = the reference's Karp-Rabin hash (what
+ * the two calls above cut by), 1 = the window hash; [1] its seed; [2] the density (the bits of a double: cuts with probability
+ * density / p); [3] 1 while that density is a candidate the ranks still have to decide on.
+ *   pfp_dist_parse_plan        rank 0, from the text's first bytes (host): the plan every rank gets, and the first window's hash
+ *                              under it (banned as an extra trigger: SURVEY.md 2.2-Q1).  The density is a candidate (p / 48) on one
+ *                              or two ranks and nominal beyond: every rank reads the whole parse, only the dictionary is shared
+ *   pfp_dist_propose_triggers2 with plan[3] set: this rank's sample of its cuts (sorted 64-bit context hashes of the cuts at or
+ *                              after halo_len, at most sample_cap, in d_sample) and no proposals
+ *   -- the hosts all-gather the samples --
+ *   pfp_dist_decide_density    on every rank, the same gathered samples: settles plan[2] (the candidate, or 1) and clears plan[3]
+ *   pfp_dist_propose_triggers2 under the settled plan: as pfp_dist_propose_triggers (the proposals are made at the density the parse
+ *                              will have: a window of a periodic stretch can cut at the candidate density and not at the nominal one)
+ *   pfp_dist_local_parse2      as pfp_dist_local_parse, under the settled plan (extra_hashes are hashes under the plan) */
+int pfp_dist_parse_plan(pfp_ctx *ctx, const uint8_t *first_bytes, uint64_t n_bytes, int w, uint64_t p, uint32_t ranks, uint64_t plan[4],
+                        uint64_t *first_hash);
+int pfp_dist_propose_triggers2(pfp_ctx *ctx, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p, const uint64_t plan[4],
+                               uint32_t out_hashes[8], uint32_t *n_hashes, void *d_sample, uint64_t sample_cap, uint64_t *n_sample);
+int pfp_dist_decide_density(pfp_ctx *ctx, const void *d_samples, uint64_t count, uint64_t p, uint64_t plan[4]);
+int pfp_dist_local_parse2(pfp_ctx *ctx, const void *d_text, uint64_t n, uint64_t halo_len, int w, uint64_t p,
+                          int is_first, int is_last, uint64_t global_offset, int want_sai, const uint64_t plan[4],
+                          const uint32_t *extra_hashes, uint32_t n_extra, uint64_t out_sizes[4]);
 int pfp_dist_export_local(pfp_ctx *ctx, void *d_dict, void *d_occ, void *d_last, void *d_sai);
 int pfp_dist_global(pfp_ctx *ctx, const void *d_union, uint64_t union_bytes, const void *d_union_occ,
                     uint64_t n_union, uint64_t my_word_base, void *d_sym_out, uint64_t out_info[3]);
@@ -374,6 +396,7 @@ typedef struct {
   uint64_t ranks, sa_shares;      /* sa_shares = 1: a key range could not finish alone, every rank sorted the whole dictionary */
   uint64_t parse_shares;          /* ranks when the parse's suffix array was sorted in key ranges too, 1 when every rank sorted all of it */
   double ms_chain, ms_total;      /* rank 0: upload to finished device outputs; + files */
+  double parse_density;           /* the plan's settled density (1 under the Karp-Rabin plan) */
 } pfp_multi_stats;
 int pfp_bigbwt_files_multi(int n_dev, const int *devices, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags,
                            uint64_t halo, const char *out_base, pfp_multi_stats *stats, char *errbuf, uint64_t errbuf_len);

@@ -174,7 +174,9 @@ def test_distributed_chain_matches_oracle(O, pkg, R, shard_sa, nblock):
             # sharded one the hash-partitioned all-to-all
             res = d.simulate(ctxs, shards, 10, 100, flags, halo=4096, shard_sa=shard_sa, dedup="alltoall" if shard_sa else "allgather")
             assert res[0]["stats"]["dedup"] == ("alltoall" if shard_sa else "allgather")
-            assert res[0]["stats"]["extra_triggers"] >= (1 if nblock else 0)
+            # (the N block is a giant phrase for the reference's hash - shared extra triggers; under the window hash one of its
+            #  line-break windows may cut it already, then nothing needs splitting: PFP_WINDOW_HASH=kr in the env matrix pins the first)
+            assert res[0]["stats"]["extra_triggers"] >= (1 if nblock and os.environ.get("PFP_WINDOW_HASH") == "kr" else 0)
             shares = {r["stats"]["sa_shares"] for r in res}
             # debugging switches that turn pivot rounds off make every range fall back to the replicated sort
             hobbled = any(os.environ.get(k) for k in ("PFP_NO_FINFLAG", "PFP_PIVOT_CAP"))
@@ -232,6 +234,8 @@ def test_many_ranks_on_a_tiny_dictionary(O, pkg, R):
     cuts = [len(t) * r // R for r in range(R + 1)]
     ctxs = [pkg.Context(0) for _ in range(R)]
     try:
+        for c in ctxs:
+            c.set_window_hash(False)          # (the shards of this 2.8 KB text are cut where the reference's hash cuts: under another hash one holds no complete phrase)
         shards = [torch.from_numpy(t[cuts[r]:cuts[r + 1]].copy()).cuda() for r in range(R)]
         res = d.simulate(ctxs, shards, 4, 11, pkg.FLAG_SA, halo=256)
         want = O.bigbwt(t, 4, 11, O.FLAG_SA)

@@ -40,7 +40,7 @@ def wrap(obj, meth):
     setattr(obj, meth, g)
 
 
-for m_ in ('dist_propose_triggers', 'dist_local_parse', 'dist_export_local', 'dist_partition_words', 'dist_export_partition',
+for m_ in ('dist_parse_plan', 'dist_propose_triggers2', 'dist_decide_density', 'dist_local_parse2', 'dist_export_local', 'dist_partition_words', 'dist_export_partition',
            'dist_owner_dedup', 'dist_export_owned', 'dist_global_sort', 'dist_global_sort_distinct', 'dist_global_finish', 'dist_merge',
            'pack5_dev', 'sample_runs_dev', 'dist_sample_runs', 'dist_parse_sort', 'dist_set_parse_sa'):
     wrap(ctxs[R - 1], m_)
@@ -57,7 +57,7 @@ ms_ = ctxs[R - 1].mem_stats()
 print('last rank device memory: peak in use %.2f GB (%.1f bytes per byte of its shard, %.1f per byte of the union dictionary)' % (
     ms_['peak'] / 1e9, ms_['peak'] / texts[R - 1].numel(), ms_['peak'] / max(res[R - 1]['stats']['glob']['dict_bytes'], 1)))
 st = res[R - 1]['stats']
-print('stats', {k: st[k] for k in ('phrases_total', 'shard_bytes', 'sa_shares', 'parse_shares', 'dedup')}, st['glob'])
+print('stats', {k: st[k] for k in ('phrases_total', 'shard_bytes', 'sa_shares', 'parse_shares', 'dedup', 'parse_density')}, st['glob'])
 kt = ctxs[R - 1].kernel_trace()
 rows = sorted(kt, key=lambda r: -r['total_ms'])
 for r in rows[:int(os.environ.get("SIMSCALE_ROWS", "12"))]:
