@@ -213,6 +213,7 @@ struct Coll {
 
  public:
   bool force_grouped = false;      // (self test: the send / recv form of the all-gather whatever the counts)
+  bool fail_in_group = false;      // (self test: an error between ncclGroupStart and ncclGroupEnd, after the first send was queued)
  private:
   void nccl_check(int rc, const char *what) { if (rc != 0) fail(PFP_EHIP, "rank %d: RCCL %s: %s", rank, what, S.rccl->GetErrorString(rc)); }
   // the stream's RCCL work is done - or some rank has given up (its abort_all ends the kernels this stream waits in)
@@ -239,6 +240,7 @@ struct Coll {
     uint64_t so = 0, ro = 0;
     for (int r = 0; r < size; r++) {
       if (send[r]) nccl_check(R.Send((const uint8_t *)d_send + so, send[r], kNcclUint8, r, S.comms[rank], stream), "send");
+      if (fail_in_group) fail(PFP_EHIP, "rank %d: injected failure inside a group", rank);
       if (recv[r]) nccl_check(R.Recv((uint8_t *)d_recv + ro, recv[r], kNcclUint8, r, S.comms[rank], stream), "recv");
       so += send[r]; ro += recv[r];
     }
@@ -711,7 +713,12 @@ extern "C" int pfp_bigbwt_files_multi(int n_dev, const int *devices, const uint8
 
 // One-GPU check of the RCCL transport (tests): the dlopen'ed table, the enum values and the group semantics, with a communicator
 // over ONE device - every exchange shape of the chain as a self send / recv, and the one-collective all-gather.
-extern "C" int pfp_multi_rccl_selftest(int device, char *errbuf, uint64_t errbuf_len) {
+// inject_failure != 0: after the exchanges, one more all-to-all that fails between ncclGroupStart and ncclGroupEnd with a send
+// already queued - the error path of a rank (group closed on the way out, abort_all: ncclCommAbort on every communicator) must come
+// back instead of hanging; PFP_OK then means "failed as intended and cleaned up".
+extern "C" int pfp_multi_rccl_selftest2(int device, int inject_failure, char *errbuf, uint64_t errbuf_len);
+extern "C" int pfp_multi_rccl_selftest(int device, char *errbuf, uint64_t errbuf_len) { return pfp_multi_rccl_selftest2(device, 0, errbuf, errbuf_len); }
+extern "C" int pfp_multi_rccl_selftest2(int device, int inject_failure, char *errbuf, uint64_t errbuf_len) {
   using namespace pfp;
   auto say = [&](const std::string &m) { if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", m.c_str()); };
   int have = 0;
@@ -748,6 +755,16 @@ extern "C" int pfp_multi_rccl_selftest(int device, char *errbuf, uint64_t errbuf
     C.force_grouped = false;
     { std::vector<uint64_t> send(1, n), recv; Dev out = C.alltoallv(src.p, send, recv); if (recv.size() != 1 || recv[0] != n) fail(PFP_EHIP, "RCCL self test: all-to-all counts"); same(out, n, "all-to-all"); }
     { std::vector<uint64_t> send(1, 0), recv; Dev out = C.alltoallv(src.p, send, recv); (void)out; }
+    if (inject_failure) {
+      bool failed = false;
+      C.fail_in_group = true;
+      try { std::vector<uint64_t> send(1, n), recv; Dev out = C.alltoallv(src.p, send, recv); (void)out; }
+      catch (const Failure &f) { failed = std::string(f.msg).find("injected") != std::string::npos; }
+      C.fail_in_group = false;
+      if (!failed) fail(PFP_EHIP, "RCCL self test: the injected failure did not surface");
+      S.abort_all();          // what run_rank's catch block does: the queued send must not keep anything waiting
+      if (!S.comms_gone) fail(PFP_EHIP, "RCCL self test: the communicators were not aborted");
+    }
   } catch (const Failure &f) {
     code = f.code; say(f.msg);
     S.abort_all();

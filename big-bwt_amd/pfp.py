@@ -30,7 +30,7 @@ ERRORS = {0: "PFP_OK", -1: "PFP_EINVAL", -2: "PFP_ENODEV", -3: "PFP_EHIP", -4: "
 SYMBOLS = ["pfp_device_count", "pfp_ctx_create", "pfp_ctx_destroy", "pfp_last_error", "pfp_strerror", "pfp_version", "pfp_ctx_stream",
            "pfp_free", "pfp_debug_check", "pfp_get_mem_stats", "pfp_get_pool_counters", "pfp_pool_trim", "pfp_scan", "pfp_parse", "pfp_parse_result_free", "pfp_sacak_int", "pfp_sacak", "pfp_gsacak", "pfp_sacak_int64", "pfp_sacak64", "pfp_gsacak64", "pfp_gsacak_lcp_da", "pfp_gsacak_lcp_da64",
            "pfp_bwtparse", "pfp_merge", "pfp_bwt_result_free", "pfp_bigbwt", "pfp_bigbwt_files", "pfp_bigbwt_dev", "pfp_bigbwt_formats_dev", "pfp_dev_free", "pfp_memcpy_d2h", "pfp_pack5_dev", "pfp_sample_runs_dev", "pfp_pwrite_dev", "pfp_get_stats",
-           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_window_hash", "pfp_set_parse_density", "pfp_debug_msd_sort", "pfp_dist_parse_plan", "pfp_dist_propose_triggers2", "pfp_dist_decide_density", "pfp_dist_local_parse2", "pfp_bigbwt_fd", "pfp_multi_rccl_selftest", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
+           "pfp_set_profiling", "pfp_set_kernel_trace", "pfp_get_kernel_trace", "pfp_set_max_phrase", "pfp_set_window_hash", "pfp_set_parse_density", "pfp_debug_msd_sort", "pfp_dist_parse_plan", "pfp_dist_propose_triggers2", "pfp_dist_decide_density", "pfp_dist_local_parse2", "pfp_bigbwt_fd", "pfp_multi_rccl_selftest", "pfp_multi_rccl_selftest2", "pfp_set_index_bits", "pfp_stage_text_dev", "pfp_scan_staged", "pfp_scan_k1_enqueue",
            "pfp_dist_propose_triggers", "pfp_dist_local_parse", "pfp_dist_export_local", "pfp_dist_global", "pfp_dist_global_sort", "pfp_dist_global_finish", "pfp_dist_partition_words", "pfp_dist_export_partition",
            "pfp_dist_owner_dedup", "pfp_dist_export_owned", "pfp_dist_global_sort_distinct", "pfp_dist_merge", "pfp_dist_sample_runs", "pfp_dist_release", "pfp_bigbwt_files_multi", "pfp_dist_parse_sort", "pfp_dist_set_parse_sa"]
 
@@ -574,10 +574,11 @@ def bigbwt_files_multi(text, base, devices, w=10, p=100, flags=0, halo=0):
     return {k: getattr(st, k) for k, _ in MultiStats._fields_}
 
 
-def multi_rccl_selftest(device=0):
-    """pfp_multi_rccl_selftest: the native multi-GPU host's RCCL transport over one device (raises PfpError with its message)"""
+def multi_rccl_selftest(device=0, inject_failure=False):
+    """pfp_multi_rccl_selftest2: the native multi-GPU host's RCCL transport over one device (raises PfpError with its message);
+    inject_failure: also the error path - a failure inside an open group, the communicators aborted"""
     lib = load_library()
     err = C.create_string_buffer(1024)
-    rc = lib.pfp_multi_rccl_selftest(C.c_int(device), err, C.c_uint64(len(err)))
+    rc = lib.pfp_multi_rccl_selftest2(C.c_int(device), C.c_int(1 if inject_failure else 0), err, C.c_uint64(len(err)))
     if rc:
         raise PfpError(rc, err.value.decode(errors="replace"))

@@ -405,6 +405,10 @@ int pfp_bigbwt_files_multi(int n_dev, const int *devices, const uint8_t *text, u
  * from ncclCommInitAll over `device`, every exchange shape of the chain as a self send / recv inside a group, and the one-collective
  * all-gather; returns PFP_OK when every byte came back. */
 int pfp_multi_rccl_selftest(int device, char *errbuf, uint64_t errbuf_len);
+/* the same, then (inject_failure != 0) an exchange that fails between ncclGroupStart and ncclGroupEnd with a send already queued:
+ * the group is closed on the way out and every communicator aborted (ncclCommAbort), as a failing rank of the chain does; PFP_OK =
+ * it failed as intended and came back */
+int pfp_multi_rccl_selftest2(int device, int inject_failure, char *errbuf, uint64_t errbuf_len);
 
 /* ---- micro entry points used by bench.py's roofline leg and by the parity tests ---- */
 /* copy a device-resident text into the ctx's padded staging buffer (T' = Dollar.T.Dollar^w) */

@@ -523,6 +523,10 @@ def test_rccl_transport_on_one_device(pkg):
     import importlib
     pfpmod = importlib.import_module("bigbwt_amd.pfp")
     pfpmod.multi_rccl_selftest(0)
+    # ... and a rank's error path: a failure between ncclGroupStart and ncclGroupEnd with a send already queued - the group is
+    # closed, every communicator aborted (ncclCommAbort), the call comes back (peers must not hang in a receive)
+    pfpmod.multi_rccl_selftest(0, inject_failure=True)
+    pfpmod.multi_rccl_selftest(0)          # a fresh communicator works afterwards
 
 
 def test_launcher_of_the_python_ranks_never_counts_devices(tmp_path):

@@ -87,7 +87,8 @@ def test_outputs_do_not_depend_on_the_parse(golden, O, pkg, ctx, max_phrase, fas
                     assert sha(got["ssa"]) == r["ssa_sha256"] and sha(got["esa"]) == r["esa_sha256"]
             ps = ctx.parse(text, c["w"], c["p"])
             assert sha(ps["dict"]) == c["runs"]["6"]["dict_sha256"]
-        assert (used > 0) == (max_phrase > 0)
+        if not os.environ.get("PFP_PARSE_DENSITY"):          # (at a pinned higher density no phrase of these texts reaches 700 bytes)
+            assert (used > 0) == (max_phrase > 0)
     finally:
         ctx.set_max_phrase(1 << 15)
         ctx.set_window_hash(True)
