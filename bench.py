@@ -422,9 +422,19 @@ def main():
         for rnd in ("r04",):          # (same round only: the kernels of earlier rounds are not this code)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{wl_name}_pmc_traffic.json")))
-                if world == 1 and dom["kernel"] in pmc["kernels"]:
-                    roofline["traffic"] = int(pmc["kernels"][dom["kernel"]]["hbm_bytes_per_chain_corrected"] / dom["launches_per_step"])
-                    roofline["traffic_source"] = f"profiles/{rnd}_{wl_name}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; 2*FETCH+WRITE)"
+                base = dom["kernel"].split(" [")[0]         # a library sort's label carries its call site: "... [what for]"
+                if world == 1 and base in pmc["kernels"]:
+                    tot = pmc["kernels"][base]["hbm_bytes_per_chain_corrected"]
+                    src = f"profiles/{rnd}_{wl_name}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; 2*FETCH+WRITE)"
+                    if base != dom["kernel"]:
+                        # the counters see the library's kernels of ALL call sites of this sort type: this site's part by its
+                        # share of the type's algorithmic bytes (every site moves n * 2 * (key + value) per digit pass)
+                        same = [x for x in rows if x["kernel"].split(" [")[0] == base]
+                        allb = sum(x["algo_bytes_per_launch"] * x["launches_per_step"] for x in same)
+                        tot *= dom["algo_bytes_per_launch"] * dom["launches_per_step"] / max(1, allb)
+                        src += "; the sort type's bytes apportioned to this call site by algorithmic bytes"
+                    roofline["traffic"] = int(tot / dom["launches_per_step"])
+                    roofline["traffic_source"] = src
                     break
             except Exception:
                 pass

@@ -9,6 +9,7 @@
 #include <vector>
 #include <chrono>
 #include <map>
+#include <thread>
 #include "../../include/pfpgpu.h"
 
 namespace pfp {
@@ -254,6 +255,7 @@ struct pfp_ctx {
   void *pin[2] = {nullptr, nullptr};
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   uint64_t n_syncs = 0;           // host waits on the stream (PFP_TRACE_HOST prints the count when the context goes)
+  std::vector<std::thread> background;      // host work that may outlive a call (unmapping an output file): joined by the next file call and by destroy
 };
 
 namespace pfp {

@@ -218,7 +218,7 @@ void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t 
   hipLaunchKernelGGL(parse_gather_kernel, gdim(cdiv(P + 1, TB)), gdim(TB), 0, c->stream, P, so.sa.p, sym.p, last, sai,
                      bwtp.p, out.bwlast.p, sai ? out.bwsai.p : (uint64_t *)nullptr, jidx.p);
   // bwtparse.c:281-303: positions grouped by symbol, ascending inside a group == stable sort
-  sort_pairs_u32_u32(c, bwtp.p, bwtp_s.p, jidx.p, out.ilist.p, P + 1, 0, bits_for(d));
+  { SortTag tag("inverted list"); sort_pairs_u32_u32(c, bwtp.p, bwtp_s.p, jidx.p, out.ilist.p, P + 1, 0, bits_for(d)); }
   PFP_HIP(hipGetLastError());
 }
 
@@ -1747,7 +1747,7 @@ void merge_bwt(pfp_ctx *c, const Dictionary &D, const DictIndex &ix, const Suffi
         DBuf<uint64_t> bk(c, cnt), bka(c, cnt), bv(c, cnt), bva(c, cnt);
         { KScope ks(c, "pfp::big_keys_kernel", cnt * 28);
           hipLaunchKernelGGL(big_keys_kernel<I>, gdim(cdiv(cnt, 256)), gdim(256), 0, c->stream, a, big.p, q0, q1, estart.p, cnt, bk.p, bv.p); }
-        sort_pairs_db<uint64_t, uint64_t>(c, bk, bka, bv, bva, cnt, 0, 32 + bits_for(q1 - q0));
+        { SortTag tag("large hard groups"); sort_pairs_db<uint64_t, uint64_t>(c, bk, bka, bv, bva, cnt, 0, 32 + bits_for(q1 - q0)); }
         { KScope ks(c, "pfp::big_place_kernel", cnt * (samode ? 34 : 18));
           hipLaunchKernelGGL(big_place_kernel<I>, gdim(cdiv(cnt, 256)), gdim(256), 0, c->stream, a, big.p, q0, estart.p, cnt, bk.p, bv.p); }
       }

@@ -316,7 +316,7 @@ static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, u
       const int b = test_bits < 0 ? -test_bits : test_bits;
       hipLaunchKernelGGL(mask_u64_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, hash.p, P, b >= 64 ? ~0ull : ((1ull << b) - 1ull));
     }
-    sort_pairs_u64_u32(c, hash.p, ks.p, iota.p, vs.p, P, 0, 64);
+    { SortTag tag("phrase hashes"); sort_pairs_u64_u32(c, hash.p, ks.p, iota.p, vs.p, P, 0, 64); }
     { KScope kscope(c, "pfp::dedup_verify_kernel", 2 * n + 16 * P);
     hipLaunchKernelGGL(dedup_verify_kernel, gdim(cdiv(P * 8, TB)), gdim(TB), 0, c->stream, tp, g, P, ks.p, vs.p, head.p,
                        counters.p + 1); }

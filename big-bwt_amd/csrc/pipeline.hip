@@ -11,6 +11,8 @@
 #include <unistd.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/vfs.h>
+#include <condition_variable>
 #include <cerrno>
 #include <thread>
 #include <mutex>
@@ -423,6 +425,157 @@ static void write_dev_file(pfp_ctx *c, const std::string &path, uint64_t file_of
   PFP_REQUIRE(close(fd) == 0 && ok, PFP_EINVAL, "error writing " + path + ": " + werr);
 }
 
+
+// An output file whose OWN pages are the target of the device -> host copy (round 4).  write_dev_file() above moves every byte
+// twice on the host side of PCIe - copy engine -> pinned buffer, pwrite() -> the file's pages - and a file takes one writer at a
+// time: ~6 GB/s into /dev/shm, 2.2 of the 3.5 s of the 12.6 GB command-line run.  The .bwt's size is known before the text is
+// read, so: create the file at its final size, map it, and - on helper threads, beside the text input and the chain - fault
+// its pages in and register the mapping with the runtime piece by piece; when the BWT exists it crosses PCIe once, at the copy
+// engine's rate, straight into the file (tools/microbench/regout.hip: 31 GB/s into a populated, registered mapping against
+// 4.1-4.7 for the pinned-buffer path).  Files in a memory file system only (anything else: the pwrite path); every failure on
+// the way - no mapping, a piece the runtime will not register - falls back to the pwrite path for the whole file.
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+struct MappedOut {
+  uint64_t kPiece = 128ull << 20;      // (a small file in smaller pieces: its first copy starts sooner)
+  std::string path;
+  int fd = -1, device = 0;
+  uint8_t *m = nullptr;
+  uint64_t bytes = 0, npieces = 0;
+  std::vector<int> state;                 // per piece: 0 pending, 1 registered, -1 failed (under mu)
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<bool> cancel{false};
+  std::vector<std::thread> workers;
+  hipStream_t cs = nullptr;               // the copies' own stream: the run sampling that follows the BWT overlaps them
+  hipEvent_t ev = nullptr;
+  bool copying = false, done = false;
+  std::chrono::steady_clock::time_point t_start;
+  double s_populate = 0, s_register = 0, s_ready = 0, s_waited = 0;      // PFP_TRACE_HOST (under mu)
+
+  static bool wanted(uint64_t nbytes) {
+    static const int mode = []() { const char *e = getenv("PFP_MAP_OUTPUT"); return e ? atoi(e) : -1; }();      // 0: never
+    static const uint64_t min_bytes = []() { const char *e = getenv("PFP_MAP_MIN_BYTES"); return e ? (uint64_t)atoll(e) : (64ull << 20); }();      // (tests: small files too)
+    return mode != 0 && nbytes >= std::max<uint64_t>(min_bytes, 1);
+  }
+  // false: this file is written the ordinary way
+  bool start(pfp_ctx *c, const std::string &path_, uint64_t nbytes) {
+    if (!wanted(nbytes)) return false;
+    path = path_; bytes = nbytes; device = c->device;
+    // (a disk file system tracks dirty pages through write faults, which a copy engine does not take: pwrite there)
+    struct statfs sf;
+    const size_t slash = path.rfind('/');
+    const std::string dir = slash == std::string::npos ? std::string(".") : (slash == 0 ? std::string("/") : path.substr(0, slash));
+    if (statfs(dir.c_str(), &sf) != 0 || (unsigned long)sf.f_type != 0x01021994ul /* tmpfs */) return false;
+    fd = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return false;      // (the ordinary path reports it)
+    if (fstatfs(fd, &sf) != 0 || (unsigned long)sf.f_type != 0x01021994ul || ftruncate(fd, (off_t)bytes) != 0) { close(fd); fd = -1; unlink(path.c_str()); return false; }
+    t_start = std::chrono::steady_clock::now();
+    void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (q == MAP_FAILED) { close(fd); fd = -1; unlink(path.c_str()); return false; }
+    m = (uint8_t *)q;
+    static const uint64_t piece_mb = []() { const char *e = getenv("PFP_MAP_PIECE_MB"); return e ? (uint64_t)atoll(e) : (uint64_t)32; }();
+    kPiece = std::min<uint64_t>(std::max<uint64_t>(piece_mb, 2) << 20, std::max<uint64_t>(2ull << 20, (bytes / 8 + (2u << 20) - 1) & ~uint64_t((2u << 20) - 1)));
+    npieces = (bytes + kPiece - 1) / kPiece;
+    state.assign(npieces, 0);
+    if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError(); abandon(true); return false;
+    }
+    workers.emplace_back([this]() { work(); });
+    return true;
+  }
+  // ONE helper: page allocation in one file does not scale over threads - 1.96 s for 12.6 GB from one thread, 3.0-3.2 s from
+  // 4-16, and an allocating thread beside a mapping one slows both (tools/microbench/regout.hip, profiles/r04_regout_*.txt).
+  // Per piece: its pages allocated by fallocate (19 GB/s; 6 when the registration's faults have to allocate them), then
+  // mapped and pinned by the registration.  Pieces of 32 MB: a registration in flight holds up the calling thread's own
+  // allocations and copies (text in 0.35 -> 0.9 s, cold chain 0.6 -> 0.9 s with 128 MB pieces), smaller ones cost the helper more.
+  void work() {
+    (void)hipSetDevice(device);
+    for (uint64_t i = 0; i < npieces && !cancel.load(); i++) {
+      const uint64_t off = i * kPiece, len = std::min(kPiece, bytes - off);
+      const auto a0 = std::chrono::steady_clock::now();
+      (void)!fallocate(fd, 0, (off_t)off, (off_t)len);
+      const auto a1 = std::chrono::steady_clock::now();
+      const hipError_t e = hipHostRegister(m + off, len, hipHostRegisterDefault);
+      if (e != hipSuccess) (void)hipGetLastError();
+      const auto a2 = std::chrono::steady_clock::now();
+      {
+        std::lock_guard<std::mutex> g(mu);
+        state[i] = e == hipSuccess ? 1 : -1;
+        s_populate += std::chrono::duration<double>(a1 - a0).count(); s_register += std::chrono::duration<double>(a2 - a1).count();
+        s_ready = std::chrono::duration<double>(a2 - t_start).count();
+      }
+      cv.notify_all();
+      if (e != hipSuccess) return;      // (the copy gives up at this piece)
+    }
+  }
+  // device bytes [0, nbytes) -> the file, behind what the context's stream holds; returns at once (finish() waits).
+  // false: a piece could not be registered - nothing usable was written, the caller takes the ordinary path.
+  bool write(pfp_ctx *c, const uint8_t *d_src, uint64_t nbytes) {
+    PFP_REQUIRE(nbytes <= bytes, PFP_EINVAL, "mapped output smaller than the result");
+    PFP_HIP(hipEventRecord(ev, c->stream));
+    PFP_HIP(hipStreamWaitEvent(cs, ev, 0));
+    copying = true;
+    for (uint64_t i = 0; i < npieces && i * kPiece < nbytes; i++) {
+      {
+        const auto a0 = std::chrono::steady_clock::now();
+        std::unique_lock<std::mutex> g(mu); cv.wait(g, [&]() { return state[i] != 0; });
+        s_waited += std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
+        if (state[i] < 0) return false;
+      }
+      const uint64_t off = i * kPiece, len = std::min(kPiece, nbytes - off);
+      PFP_HIP(hipMemcpyAsync(m + off, d_src + off, len, hipMemcpyDeviceToHost, cs));
+    }
+    return true;
+  }
+  void join_workers() { cancel.store(true); for (auto &t : workers) if (t.joinable()) t.join(); workers.clear(); }
+  void unregister_all() {
+    join_workers();
+    if (m) for (uint64_t i = 0; i < npieces; i++) if (state[i] == 1) { (void)hipHostUnregister(m + i * kPiece); state[i] = 0; }
+    if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    if (cs) { (void)hipStreamDestroy(cs); cs = nullptr; }
+  }
+  // waits for the copies, gives the file its final length and lets go of the mapping.  Taking 12.6 GB out of the page table
+  // costs a quarter of a second: on a thread the context joins later - the file is complete before that.  (Measured and
+  // dropped: unmapping every piece as soon as its copy has landed - the address space's lock, taken for every piece, held up
+  // this thread's own mappings and stream calls: files out 45 -> 125 ms at 0.79 GB.)
+  void finish(pfp_ctx *c, uint64_t final_bytes) {
+    const auto a0 = std::chrono::steady_clock::now();
+    if (copying) PFP_HIP(hipStreamSynchronize(cs));
+    copying = false;
+    const auto a1 = std::chrono::steady_clock::now();
+    unregister_all();
+    bool ok = final_bytes == bytes || ftruncate(fd, (off_t)final_bytes) == 0;
+    ok = (close(fd) == 0) && ok; fd = -1;
+    done = true;
+    if (getenv("PFP_TRACE_HOST"))
+      fprintf(stderr, "[pfp] %s, %.2f GB through its mapping: pages allocated %.3f s, mapped and registered %.3f s (%zu pieces), all ready %.3f s after the start; the copy waited %.3f s for pieces, %.3f s for the copy engine, %.3f s to unregister and close\n",
+              path.c_str(), bytes / 1e9, s_populate, s_register, (size_t)npieces, s_ready, s_waited, std::chrono::duration<double>(a1 - a0).count(),
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - a1).count());
+    uint8_t *mm = m; const uint64_t len = bytes; m = nullptr;
+    // (last: an unmapping in flight holds the address space's lock, and creating a thread or destroying a stream would wait for it)
+    c->background.emplace_back([mm, len]() { munmap(mm, len); });
+    PFP_REQUIRE(ok, PFP_EINVAL, "error writing " + path + ": " + strerror(errno));
+  }
+  // drop everything; the (incomplete) file goes too unless the ordinary path is about to rewrite it
+  void abandon(bool remove) {
+    if (copying && cs) (void)hipStreamSynchronize(cs);
+    copying = false;
+    unregister_all();
+    if (m) { munmap(m, bytes); m = nullptr; }
+    if (fd >= 0) { close(fd); fd = -1; if (remove) unlink(path.c_str()); }
+    (void)hipGetLastError();
+    done = true;
+  }
+  bool active() const { return m != nullptr && !done; }
+  ~MappedOut() { if (!done && (m || fd >= 0)) abandon(true); }
+};
+static void join_background(pfp_ctx *c) {
+  for (auto &t : c->background) if (t.joinable()) t.join();
+  c->background.clear();
+}
+
 }  // namespace pfp
 
 // ======================================================================== extern "C"
@@ -505,6 +658,7 @@ void pfp_ctx_destroy(pfp_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  join_background(c);
   pfp_dist_release(c);
   delete staged_of(c);
   delete reinterpret_cast<K1Scratch *>(c->k1scratch);
@@ -1151,6 +1305,13 @@ static int bigbwt_to_files(pfp_ctx *c, uint64_t n, int w, uint64_t p, int flags,
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t0 = now();
+  join_background(c);
+  // the two outputs whose sizes the text's length fixes get their files now: their pages are made ready beside the input and the chain
+  MappedOut m_bwt, m_sa;
+  // (measured: holding the registrations back until the text is in, or starting only then, moves the helper's 1.6-1.9 s for
+  //  12.6 GB behind the chain instead of beside the input - same total; profiles/r04_cli_probe_hold.txt)
+  const bool map_bwt = m_bwt.start(c, std::string(base) + ".bwt", n + 1);
+  const bool map_sa = (flags & PFP_FLAG_SA) && n && m_sa.start(c, std::string(base) + ".sa", n * 5);
   Chain ch;
   stage(ch.tx);
   if (trace_host) sync(c);
@@ -1160,13 +1321,29 @@ static int bigbwt_to_files(pfp_ctx *c, uint64_t n, int w, uint64_t p, int flags,
   run_chain_dev(c, ch, n, w, p, flags, d_bwt.p, nullptr, &used);
   const auto t2 = now();
   uint64_t sizes[4] = {0, 0, 0, 0};
+  int n_mapped = 0;
   emit_outputs(c, d_bwt.p, sa_view(ch.out), used + 1, flags, [&](const char *name, const uint8_t *d, uint64_t bytes) {
-    write_dev_file(c, std::string(base) + "." + name, 0, d, bytes, true);
     sizes[name[0] == 'b' ? 0 : (name[1] == 'a' ? 1 : (name[0] == 's' ? 2 : 3))] = bytes;
+    if (trace_host) fprintf(stderr, "[pfp]   %.1f ms after the chain: .%s (%.2f GB) is on the device\n", ms(t2, now()), name, bytes / 1e9);
+    MappedOut *mo = name[0] == 'b' ? (map_bwt ? &m_bwt : nullptr) : (name[0] == 's' && name[1] == 'a' && name[2] == 0 ? (map_sa ? &m_sa : nullptr) : nullptr);
+    MappedOut late;      // .ssa / .esa (and an .sa that could not start early): their sizes are only known now - the helper works while the copies follow it
+    if (!mo && late.start(c, std::string(base) + "." + name, bytes)) mo = &late;
+    if (mo && mo->active() && bytes <= mo->bytes) {
+      if (mo->write(c, d, bytes)) {
+        n_mapped++;
+        if (mo != &m_bwt) mo->finish(c, bytes);      // (its device buffer goes back to the pool when this returns; the BWT's lives to the end)
+        return;
+      }
+      mo->abandon(false);
+    } else if (mo && mo->active()) mo->abandon(false);
+    write_dev_file(c, std::string(base) + "." + name, 0, d, bytes, true);
   });
+  if (trace_host) fprintf(stderr, "[pfp]   %.1f ms after the chain: the other files are written\n", ms(t2, now()));
+  if (m_bwt.active()) m_bwt.finish(c, sizes[0]);
+  if (m_sa.active()) m_sa.abandon(true);
   if (trace_host)
-    fprintf(stderr, "[pfp] file to files: text in %.1f ms, chain %.1f ms (first call: the pool is cold), files out %.1f ms\n", ms(t0, t1), ms(t1, t2),
-            ms(t2, now()));
+    fprintf(stderr, "[pfp] file to files: text in %.1f ms, chain %.1f ms (first call: the pool is cold), files out %.1f ms%s\n", ms(t0, t1), ms(t1, t2),
+            ms(t2, now()), n_mapped ? (std::string(" (") + std::to_string(n_mapped) + " of them straight into the files' mapped pages)").c_str() : "");
   if (out_bytes) memcpy(out_bytes, sizes, sizeof sizes);
   return PFP_OK;
   PFP_CATCH(c)

@@ -3,6 +3,9 @@
 #include "devutil.hpp"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <mutex>
+#include <set>
+#include <string>
 #include <utility>
 
 namespace pfp {
@@ -16,6 +19,18 @@ namespace pfp {
     PFP_HIP(call_with_temp);                                    \
   } while (0)
 
+static thread_local const char *g_sort_tag = nullptr;
+SortTag::SortTag(const char *what) : prev(g_sort_tag) { g_sort_tag = what; }
+SortTag::~SortTag() { g_sort_tag = prev; }
+const char *tagged_sort_name(const char *base) {
+  if (!g_sort_tag) return base;
+  static std::mutex mu;
+  static std::set<std::string> names;      // (interned: the trace keeps the pointer)
+  std::lock_guard<std::mutex> lk(mu);
+  std::string nm = std::string(base) + " [" + g_sort_tag + "]";
+  if (nm.size() > 62) nm.resize(62);
+  return names.insert(nm).first->c_str();
+}
 template <class K, class V> static const char *sort_name() {
   if (sizeof(K) == 8 && sizeof(V) == 4) return "rocprim::radix_sort_pairs<u64,u32>";
   if (sizeof(K) == 4 && sizeof(V) == 4) return "rocprim::radix_sort_pairs<u32,u32>";
@@ -33,7 +48,7 @@ template <class K, class V>
 void sort_pairs(pfp_ctx *c, const K *kin, K *kout, const V *vin, V *vout, size_t n, int bb, int eb) {
   if (!n) return;
   PFP_SORT_GUARD(K, bb, eb);
-  KScope ks(c, sort_name<K, V>(), n * 2 * (sizeof(K) + sizeof(V)));
+  KScope ks(c, tagged_sort_name(sort_name<K, V>()), n * 2 * (sizeof(K) + sizeof(V)));
   PRIM2(rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, (unsigned)bb, (unsigned)eb, c->stream));
 }
 template <class K, class V>
@@ -41,7 +56,7 @@ void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &v
   if (!n) return;
   PFP_REQUIRE(k.n >= n && kalt.n >= n && v.n >= n && valt.n >= n, PFP_EINVAL, "sort_pairs_db: a buffer is shorter than n");
   PFP_SORT_GUARD(K, bb, eb);
-  KScope ks(c, sort_name<K, V>(), n * 2 * (sizeof(K) + sizeof(V)));
+  KScope ks(c, tagged_sort_name(sort_name<K, V>()), n * 2 * (sizeof(K) + sizeof(V)));
   rocprim::double_buffer<K> dk(k.p, kalt.p);
   rocprim::double_buffer<V> dv(v.p, valt.p);
   PRIM2(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream));
@@ -60,7 +75,7 @@ void sort_keys_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, size_t n, int bb, int e
   //  a millisecond, beyond it the onesweep path is taken whatever a release sets the limit to - the full-size digests
   //  of the reference pin that path)
   if (bb > 0 && eb == (int)(8 * sizeof(K)) && n <= (size_t(1) << 22)) bb = 0;
-  KScope ks(c, "rocprim::radix_sort_keys<u64>", n * 2 * sizeof(K));
+  KScope ks(c, tagged_sort_name("rocprim::radix_sort_keys<u64>"), n * 2 * sizeof(K));
   rocprim::double_buffer<K> dk(k.p, kalt.p);
   PRIM2(rocprim::radix_sort_keys(tmp, tb, dk, n, (unsigned)bb, (unsigned)eb, c->stream));
   if (dk.current() != k.p) std::swap(k, kalt);
@@ -68,7 +83,7 @@ void sort_keys_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, size_t n, int bb, int e
 void sort_keys_raw(pfp_ctx *c, const uint64_t *in, uint64_t *out, size_t n, int bb, int eb) {
   if (!n) return;
   if (bb > 0 && eb == 64 && n <= (size_t(1) << 22)) bb = 0;      // (the merge path's mask: see sort_keys_db)
-  KScope ks(c, "rocprim::radix_sort_keys<u64>", n * 16);
+  KScope ks(c, tagged_sort_name("rocprim::radix_sort_keys<u64>"), n * 16);
   PRIM2(rocprim::radix_sort_keys(tmp, tb, in, out, n, (unsigned)bb, (unsigned)eb, c->stream));
 }
 template void sort_keys_db<uint64_t>(pfp_ctx *, DBuf<uint64_t> &, DBuf<uint64_t> &, size_t, int, int);

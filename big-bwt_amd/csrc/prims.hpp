@@ -5,6 +5,14 @@
 
 namespace pfp {
 using u128 = unsigned __int128;
+// what a library sort is FOR, for the kernel trace: "rocprim::radix_sort_pairs<u64,u32> [phrase hashes]" instead of one row for
+// every sort of that type (round 4: the roofline's dominant kernel should be one kind of launch).  Scoped; nests innermost-wins.
+struct SortTag {
+  const char *prev;
+  explicit SortTag(const char *what);
+  ~SortTag();
+};
+const char *tagged_sort_name(const char *base);      // base, or an interned "base [tag]"
 // stable LSD radix sort of (key,value) pairs on key bits [begin_bit,end_bit); inputs are left intact
 // (the library then keeps a temporary copy of both arrays: use sort_pairs_db for the big sorts)
 template <class K, class V>

@@ -1002,6 +1002,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
   // of entropy each, so a partition by key BITS needs three passes where 16 uniform bits would do, and each pass reads its input
   // twice
   static const bool lib_sort = getenv("PFP_OWN_SORT") == nullptr;
+  SortTag first_tag(g.mode == MODE_DICT ? "dictionary, first round" : "parse, first round");
   if (idx_bits) {
     // keys-only first round: the words are (key << idx_bits | position), 16 bytes per element and pass instead of 24;
     // the sort is stable on the key bits alone, so ties stay in position order; one streaming pass splits the result
@@ -1014,6 +1015,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
     else msd_sort_pairs_db<I>(c, key, keyo, val, valo, N, 0, key0_bits);
     std::swap(key, keyo); std::swap(val, valo);
   }
+  SortTag later_tag(g.mode == MODE_DICT ? "dictionary, later rounds" : "parse, later rounds");
   if (lazy) { key.release(); val.release(); }      // dictionary mode: later rounds sort the (much smaller) unresolved set
   // (allocated only now: while the first sort holds its four buffers - 32 bytes per suffix in the wide build - nothing else
   //  of that size is live: a 4.8 GB dictionary peaked at 206 GB with the group array next to them, 168 GB without)

@@ -487,6 +487,44 @@ def test_c_driver_end_to_end(golden, O, tmp_path):
         assert sha(np.fromfile(str(f) + "." + ext, dtype=np.uint8)) == c["runs"]["6"][ext + "_sha256"], ext
 
 
+@pytest.mark.parametrize("where", ["memory_fs", "tmp_path"])
+def test_c_driver_outputs_through_mapped_files(golden, O, tmp_path, where):
+    """the .bwt and .sa whose sizes the text fixes are copied from HBM straight into the mapped pages of their files
+    (pipeline.hip MappedOut: files of 64 MB and more in a memory file system; PFP_MAP_MIN_BYTES brings the small ones of this
+    test in): same bytes as the pinned-buffer path, in /dev/shm and in a directory that may not be a memory file system (the
+    ordinary path there)"""
+    import shutil, tempfile
+    c = {x["name"]: x for x in golden}["gen_small"]
+    text = make_text(c["spec"], O)
+    d = tempfile.mkdtemp(dir="/dev/shm") if where == "memory_fs" else str(tmp_path)
+    try:
+        f = os.path.join(d, "t.fa")
+        with open(f, "wb") as fh:
+            fh.write(text.tobytes())
+        exe = os.path.join(ROOT, "big-bwt_amd", "bigbwt")
+        env = dict(os.environ, PFP_MAP_MIN_BYTES="1", PFP_TRACE_HOST="1")
+        for flag, run in (("-S", "1"), ("-s", "6"), ("-e", "6")):
+            out = subprocess.run([exe, "-w", "10", "-p", "100", flag, f], capture_output=True, text=True, env=env)
+            assert out.returncode == 0, out.stdout + out.stderr
+            if where == "memory_fs":
+                assert "2 of them straight" in out.stderr, out.stderr
+            assert sha(np.fromfile(f + ".bwt", dtype=np.uint8)) == c["runs"][run]["bwt_sha256"]
+            ext = {"-S": "sa", "-s": "ssa", "-e": "esa"}[flag]
+            assert sha(np.fromfile(f + "." + ext, dtype=np.uint8)) == c["runs"][run][ext + "_sha256"]
+        # a text too short for the parameters: the early file does not stay behind
+        with open(f, "wb") as fh:
+            fh.write(b"ACGT")
+        for ext in ("bwt", "sa"):
+            if os.path.exists(f + "." + ext):
+                os.remove(f + "." + ext)
+        out = subprocess.run([exe, "-w", "10", "-p", "100", "-S", f], capture_output=True, text=True, env=env)
+        if out.returncode != 0:
+            assert not os.path.exists(f + ".bwt") and not os.path.exists(f + ".sa")
+    finally:
+        if where == "memory_fs":
+            shutil.rmtree(d, ignore_errors=True)
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 2047, 2049, 4096, 4097, 50000, 300001, 2_500_000, 9_000_000])
 def test_first_round_sort_against_numpy(ctx, n):
     """csrc/radix.hip (the hand-written first-round sort: partition passes + bucket sorts in LDS) against numpy's stable sort:

@@ -14,7 +14,7 @@ with open("/dev/shm/probe.fa", "wb") as fh:
 P
 ls -la /dev/shm/probe.fa
 sleep 20
-for envs in "X=1" "X=2" "PFP_PWRITE_OUTPUT=1" "X=3"; do
+for envs in ${CLI_PROBE_ENVS:-X=1 PFP_MAP_OUTPUT=0 X=2}; do
   echo "=== $envs"
   s=$(date +%s%N)
   env $envs PFP_TRACE_HOST=1 big-bwt_amd/bigbwt -s /dev/shm/probe.fa 2>&1 | grep "pfp\]\|Total construction"

@@ -15,6 +15,15 @@ def bench_name(n):
         # (round 4: bench.py's trace labels are the launched kernels' own names - no mapping table)
         return 'pfp::' + k
     if 'onesweep' in n or 'radix_sort' in n or 'block_sort' in n:
+        # the library's kernels carry the sort's key and value types: "..._config<default_config, KEY, VALUE>"
+        T = {'unsigned long': 'u64', 'unsigned int': 'u32', 'unsigned short': 'u16', 'unsigned char': 'u8'}
+        m = re.search(r'_config<[^,<>]*default_config, ([a-z ]+), ([A-Za-z0-9_: ]+?)>', n)
+        if m and m.group(1) in T:
+            k, v = T[m.group(1)], m.group(2)
+            if v.endswith('empty_type'):
+                return f'rocprim::radix_sort_keys<{k}>'
+            if v in T:
+                return f'rocprim::radix_sort_pairs<{k},{T[v]}>'
         return 'rocprim::radix_sort_pairs<u64,u32>' if re.search(r'unsigned long, unsigned int|unsigned long,unsigned int', n) else 'rocprim::radix_sort_pairs<u32,u32>'
     return None
 
