@@ -217,10 +217,11 @@ def cli_leg(text, w, p, flags, gold, ctx=None):
                                  start_context_teardown_s=round(cli_s - ti - ch - fo, 3))
         return dict(MBps_process=round(n / cli_s / 1e6, 1), seconds_process=round(cli_s, 3),
                     seconds_construction=float(inner[0].split(":")[1]) if inner else None, outputs_ok=bool(ok), split=split,
-                    note="bigbwt (C driver), cold process, file in /dev/shm: parallel pread into pinned chunks -> H2D -> chain -> outputs streamed from HBM "
-                         "into the files (one buffered writer per file: ~6-7 GB/s into a memory file system); device memory another process has just freed "
-                         "costs ~30 ms per GB when it is handed out again (tools/microbench/alloc.hip): on an idle card the 12.6 GB run takes 3.5 s "
-                         "(profiles/r04_cli_probe_knobs.txt)")
+                    note="bigbwt (C driver), cold process, file in /dev/shm: parallel pread into pinned chunks -> H2D -> chain -> outputs copied from HBM "
+                         "straight into the mapped, registered pages of their files (a helper allocates and registers them beside the input and the chain: "
+                         "1.6-1.9 s for 12.6 GB, the critical path; DESIGN.md section 5); device memory another process has just freed costs ~30 ms per GB "
+                         "when it is handed out again (tools/microbench/alloc.hip): on an idle card the 12.6 GB run takes 2.1-2.7 s "
+                         "(profiles/r04_cli_probe_mapped.txt; 3.1-3.3 s through pinned buffers and pwrite)")
     finally:
         shutil.rmtree(tmpd, ignore_errors=True)
 

@@ -156,7 +156,13 @@ int pfp_bigbwt(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p,
 /* File to files: like pfp_bigbwt, but the outputs are streamed from HBM into <base>.bwt and, as the flags ask,
  * <base>.sa / .ssa / .esa (created or truncated) instead of being returned: what the `bigbwt` driver calls.  `text`
  * may be an mmap of the input file: it is read once, front to back, in chunks.  out_bytes (may be NULL) = the sizes
- * written {bwt, sa, ssa, esa}. */
+ * written {bwt, sa, ssa, esa}.
+ * An output of 64 MB or more whose file lies in a memory file system (tmpfs: /dev/shm) is not staged through pinned buffers and
+ * pwrite(): the file is created at its final size, mapped, its pages allocated and registered with the runtime by a helper
+ * thread beside the text input and the chain, and the result copied from HBM straight into them (.bwt and .sa, whose sizes n
+ * fixes, from the start of the call; .ssa / .esa once their run count is known).  Consequences a caller can see: those files
+ * exist (zero-filled) while the call runs, and are removed again if it fails; PFP_MAP_OUTPUT=0 in the environment keeps every
+ * output on the pwrite path (the reference writes with fwrite / pwrite: pfbwt.cpp:145-223, pfthreads.hpp:369-376). */
 int pfp_bigbwt_files(pfp_ctx *ctx, const uint8_t *text, uint64_t n, int w, uint64_t p, int flags,
                      const char *base, uint64_t out_bytes[4]);
 /* The same with the text taken from bytes [file_offset, file_offset + n) of an open file descriptor instead of a host buffer:

@@ -29,6 +29,9 @@ ctxs = [pkg.Context(0) for _ in range(R)]
 acc = {}
 
 
+per_phase, last_snap, tracing = {}, {}, [False]
+
+
 def wrap(obj, meth):
     f = getattr(obj, meth)
 
@@ -36,6 +39,14 @@ def wrap(obj, meth):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         r = f(*a, **k)
         torch.cuda.synchronize(); acc[meth] = acc.get(meth, 0.0) + (time.perf_counter() - t0) * 1e3
+        if tracing[0]:      # SIMSCALE_PHASES=1: the kernels of this call alone (difference of the cumulative trace)
+            snap = {x['name']: (x['total_ms'], x['launches']) for x in obj.kernel_trace()}
+            d = per_phase.setdefault(meth, {})
+            for nm, (ms, ln) in snap.items():
+                ms0, ln0 = last_snap.get(nm, (0.0, 0))
+                if ln > ln0:
+                    o = d.get(nm, (0.0, 0)); d[nm] = (o[0] + ms - ms0, o[1] + ln - ln0)
+            last_snap.clear(); last_snap.update(snap)
         return r
     setattr(obj, meth, g)
 
@@ -48,6 +59,7 @@ for it in range(2):
     acc.clear()
     if it == 1:
         ctxs[R - 1].set_kernel_trace(True)
+        tracing[0] = os.environ.get("SIMSCALE_PHASES") == "1"
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = D.simulate(ctxs, texts, wl['w'], wl['p'], wl['flags'], dedup=dedup, trim=set(range(R - 1)) if R > 2 else False)   # the timed rank keeps its pool warm, as a real rank does
     torch.cuda.synchronize(); el = (time.perf_counter() - t0) * 1e3
@@ -63,3 +75,11 @@ rows = sorted(kt, key=lambda r: -r['total_ms'])
 for r in rows[:int(os.environ.get("SIMSCALE_ROWS", "12"))]:
     print('   %-48s %8.2f ms %5d launches' % (r['name'], r['total_ms'], r['launches']))
 print('   traced total %.1f ms' % sum(r['total_ms'] for r in rows))
+if tracing[0]:
+    for meth, d in sorted(per_phase.items(), key=lambda kv: -sum(v[0] for v in kv[1].values())):
+        tot = sum(v[0] for v in d.values())
+        if tot < 1.0:
+            continue
+        print('  -- %s: %.1f ms of kernels (%.1f ms wall)' % (meth, tot, acc.get(meth, 0.0)))
+        for nm, (ms, ln) in sorted(d.items(), key=lambda kv: -kv[1][0])[:14]:
+            print('       %-48s %8.2f ms %5d launches' % (nm, ms, ln))
