@@ -419,6 +419,12 @@ def main():
                         frac=dom["frac"], traffic=None, us_per_launch=dom["us_per_launch"],
                         launches_per_step=dom["launches_per_step"], algo_bytes_per_launch=dom["algo_bytes_per_launch"],
                         share_of_step=round(dom["ms_per_step"] / ms_per_step, 3))
+        # (the dominant launch may be the library's LSD sort, whose fraction by algorithmic bytes is low by construction - five
+        #  to eight passes over the data; the largest HAND-WRITTEN kernel is reported next to it)
+        own = next((x for x in rows if x["kernel"].startswith("pfp::")), None)
+        if own is not None and own is not dom:
+            roofline["largest_own_kernel"] = dict(kernel=own["kernel"], achieved=own["achieved_GBps"], frac=own["frac"], us_per_launch=own["us_per_launch"],
+                                                  launches_per_step=own["launches_per_step"], share_of_step=round(own["ms_per_step"] / ms_per_step, 3))
         # HBM traffic of that kernel from the committed PMC passes of the same workload, per launch like `achieved`
         for rnd in ("r04",):          # (same round only: the kernels of earlier rounds are not this code)
             try:
