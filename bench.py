@@ -195,6 +195,17 @@ def cli_leg(text, w, p, flags, gold, ctx=None):
         torch.cuda.empty_cache()
         cmd = [os.path.join(ROOT, "big-bwt_amd", "bigbwt"), "-w", str(w), "-p", str(p)]
         cmd += [f for f, bit in (("-S", 1), ("-s", 2), ("-e", 4)) if flags & bit] + [fn]
+        # untimed, so that the child meets what a user's run meets - a file that has been lying in the page cache and a card whose
+        # free memory is clean: one read pass over the file just written (the first reader of fresh tmpfs pages gets 6 GB/s, later
+        # ones 40: profiles/r04_cli_probe_mapped.txt, first run of every series), and a pause in which the driver finishes scrubbing
+        # the device memory this process has just given back (without it the child's cold pool costs 3.6 s instead of 0.75 for 12.6 GB)
+        settle = float(os.environ.get("PFP_BENCH_CLI_SETTLE", "10" if n > (2 << 30) else "3"))
+        t_settle = time.perf_counter()
+        with open(fn, "rb", buffering=0) as fh:
+            buf = bytearray(1 << 26)
+            while fh.readinto(buf):
+                pass
+        time.sleep(max(0.0, settle - (time.perf_counter() - t_settle)))
         t1 = time.perf_counter()
         pr = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, PFP_TRACE_HOST="1"))
         cli_s = time.perf_counter() - t1
@@ -220,8 +231,9 @@ def cli_leg(text, w, p, flags, gold, ctx=None):
                     note="bigbwt (C driver), cold process, file in /dev/shm: parallel pread into pinned chunks -> H2D -> chain -> outputs copied from HBM "
                          "straight into the mapped, registered pages of their files (a helper allocates and registers them beside the input and the chain: "
                          "1.6-1.9 s for 12.6 GB, the critical path; DESIGN.md section 5); device memory another process has just freed costs ~30 ms per GB "
-                         "when it is handed out again (tools/microbench/alloc.hip): on an idle card the 12.6 GB run takes 2.1-2.7 s "
-                         "(profiles/r04_cli_probe_mapped.txt; 3.1-3.3 s through pinned buffers and pwrite)")
+                         "when it is handed out again (tools/microbench/alloc.hip), so the child is started PFP_BENCH_CLI_SETTLE seconds (default 10 / 3) after "
+                         "this process gave its memory back and after one untimed read pass over the input file; the C driver alone on an idle card: "
+                         "12.6 GB in 2.1-2.7 s (profiles/r04_cli_probe_mapped.txt; 3.1-3.3 s through pinned buffers and pwrite)")
     finally:
         shutil.rmtree(tmpd, ignore_errors=True)
 
