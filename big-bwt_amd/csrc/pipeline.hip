@@ -497,7 +497,8 @@ struct MappedOut {
       const auto a0 = std::chrono::steady_clock::now();
       (void)!fallocate(fd, 0, (off_t)off, (off_t)len);
       const auto a1 = std::chrono::steady_clock::now();
-      const hipError_t e = hipHostRegister(m + off, len, hipHostRegisterDefault);
+      static const long fail_at = []() { const char *t = getenv("PFP_TEST_MAP_FAIL"); return t ? atol(t) : -1L; }();      // (test hook: piece k is refused)
+      const hipError_t e = (long)i == fail_at ? hipErrorOutOfMemory : hipHostRegister(m + off, len, hipHostRegisterDefault);
       if (e != hipSuccess) (void)hipGetLastError();
       const auto a2 = std::chrono::steady_clock::now();
       {

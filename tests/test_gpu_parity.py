@@ -511,6 +511,22 @@ def test_c_driver_outputs_through_mapped_files(golden, O, tmp_path, where):
             assert sha(np.fromfile(f + ".bwt", dtype=np.uint8)) == c["runs"][run]["bwt_sha256"]
             ext = {"-S": "sa", "-s": "ssa", "-e": "esa"}[flag]
             assert sha(np.fromfile(f + "." + ext, dtype=np.uint8)) == c["runs"][run][ext + "_sha256"]
+        if where == "memory_fs":
+            # a piece the runtime refuses to register: the whole file takes the pwrite path, same bytes (PFP_MAP_PIECE_MB=2 and a
+            # 5 MB text: piece 1 exists for the .sa)
+            big = np.tile(text, 5_000_000 // len(text) + 1)[:5_000_000]
+            with open(f, "wb") as fh:
+                fh.write(big.tobytes())
+            want = O.bigbwt(big, 10, 100, 1)
+            for fail in ("0", "1"):
+                env2 = dict(env, PFP_TEST_MAP_FAIL=fail, PFP_MAP_PIECE_MB="2")
+                out = subprocess.run([exe, "-w", "10", "-p", "100", "-S", f], capture_output=True, text=True, env=env2)
+                assert out.returncode == 0, out.stdout + out.stderr
+                assert "2 of them straight" not in out.stderr
+                assert np.array_equal(np.fromfile(f + ".bwt", dtype=np.uint8), want["bwt"])
+                sa5 = np.fromfile(f + ".sa", dtype=np.uint8).reshape(-1, 5)
+                got_sa = sum(sa5[:, k].astype(np.uint64) << np.uint64(8 * k) for k in range(5))
+                assert np.array_equal(got_sa, want["sa"])
         # a text too short for the parameters: the early file does not stay behind
         with open(f, "wb") as fh:
             fh.write(b"ACGT")
