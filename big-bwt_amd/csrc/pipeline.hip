@@ -495,10 +495,12 @@ struct MappedOut {
     for (uint64_t i = 0; i < npieces && !cancel.load(); i++) {
       const uint64_t off = i * kPiece, len = std::min(kPiece, bytes - off);
       const auto a0 = std::chrono::steady_clock::now();
-      (void)!fallocate(fd, 0, (off_t)off, (off_t)len);
+      // (a file system without room: no page of the piece may be touched through the mapping - that would be a SIGBUS where
+      //  write() says ENOSPC; the piece counts as refused and the pwrite path reports the error)
+      const bool have_pages = fallocate(fd, 0, (off_t)off, (off_t)len) == 0;
       const auto a1 = std::chrono::steady_clock::now();
       static const long fail_at = []() { const char *t = getenv("PFP_TEST_MAP_FAIL"); return t ? atol(t) : -1L; }();      // (test hook: piece k is refused)
-      const hipError_t e = (long)i == fail_at ? hipErrorOutOfMemory : hipHostRegister(m + off, len, hipHostRegisterDefault);
+      const hipError_t e = (long)i == fail_at || !have_pages ? hipErrorOutOfMemory : hipHostRegister(m + off, len, hipHostRegisterDefault);
       if (e != hipSuccess) (void)hipGetLastError();
       const auto a2 = std::chrono::steady_clock::now();
       {
