@@ -31,6 +31,20 @@ const char *tagged_sort_name(const char *base) {
   if (nm.size() > 62) nm.resize(62);
   return names.insert(nm).first->c_str();
 }
+// rocPRIM's onesweep with this chip's numbers (round 4, tools/microbench/sortcfg.hip, profiles/r04_sortcfg*.txt; 80 M and 1.6 G
+// elements): u64 keys alone sort fastest with 9-bit digits in workgroups of 1024 x 8 keys (36 key bits: 4 passes instead of 5,
+// 2.55 -> 1.99 ms / 50.8 -> 41.1 ms); (u64, u32) and (u32, u32) pairs with the default 8-bit digit but 1024 x 7 (3.38 -> 2.87 ms
+// on 40 bits, 5.5 -> 4.85 on 64, 1.96 -> 1.72 for u32 keys; 1024 x 8 falls off a cliff: 4.1 ms); (u64, u64) pairs are best left alone.
+// Inputs of up to 2^20 elements keep the library's merge / single-block paths.
+template <unsigned BS, unsigned IPT, unsigned BITS>
+using OnesweepCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                               rocprim::radix_sort_onesweep_config<rocprim::kernel_config<BS, IPT>, rocprim::kernel_config<BS, IPT>, BITS,
+                                                                                   rocprim::block_radix_rank_algorithm::match>>;
+using KeysCfg = OnesweepCfg<1024, 8, kKeysDigitBits>;
+template <class K, class V> struct PairsCfgOf { using type = rocprim::default_config; };
+template <> struct PairsCfgOf<uint64_t, uint32_t> { using type = OnesweepCfg<1024, 7, 8>; };
+template <> struct PairsCfgOf<uint32_t, uint32_t> { using type = OnesweepCfg<1024, 7, 8>; };
+template <class K, class V> using PairsCfg = typename PairsCfgOf<K, V>::type;
 template <class K, class V> static const char *sort_name() {
   if (sizeof(K) == 8 && sizeof(V) == 4) return "rocprim::radix_sort_pairs<u64,u32>";
   if (sizeof(K) == 4 && sizeof(V) == 4) return "rocprim::radix_sort_pairs<u32,u32>";
@@ -49,7 +63,7 @@ void sort_pairs(pfp_ctx *c, const K *kin, K *kout, const V *vin, V *vout, size_t
   if (!n) return;
   PFP_SORT_GUARD(K, bb, eb);
   KScope ks(c, tagged_sort_name(sort_name<K, V>()), n * 2 * (sizeof(K) + sizeof(V)));
-  PRIM2(rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, (unsigned)bb, (unsigned)eb, c->stream));
+  PRIM2((rocprim::radix_sort_pairs<PairsCfg<K, V>>(tmp, tb, kin, kout, vin, vout, n, (unsigned)bb, (unsigned)eb, c->stream)));
 }
 template <class K, class V>
 void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &valt, size_t n, int bb, int eb) {
@@ -59,7 +73,7 @@ void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &v
   KScope ks(c, tagged_sort_name(sort_name<K, V>()), n * 2 * (sizeof(K) + sizeof(V)));
   rocprim::double_buffer<K> dk(k.p, kalt.p);
   rocprim::double_buffer<V> dv(v.p, valt.p);
-  PRIM2(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream));
+  PRIM2((rocprim::radix_sort_pairs<PairsCfg<K, V>>(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream)));
   if (dk.current() != k.p) std::swap(k, kalt);
   if (dv.current() != v.p) std::swap(v, valt);
 }
@@ -77,14 +91,14 @@ void sort_keys_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, size_t n, int bb, int e
   if (bb > 0 && eb == (int)(8 * sizeof(K)) && n <= (size_t(1) << 22)) bb = 0;
   KScope ks(c, tagged_sort_name("rocprim::radix_sort_keys<u64>"), n * 2 * sizeof(K));
   rocprim::double_buffer<K> dk(k.p, kalt.p);
-  PRIM2(rocprim::radix_sort_keys(tmp, tb, dk, n, (unsigned)bb, (unsigned)eb, c->stream));
+  PRIM2((rocprim::radix_sort_keys<KeysCfg>(tmp, tb, dk, n, (unsigned)bb, (unsigned)eb, c->stream)));
   if (dk.current() != k.p) std::swap(k, kalt);
 }
 void sort_keys_raw(pfp_ctx *c, const uint64_t *in, uint64_t *out, size_t n, int bb, int eb) {
   if (!n) return;
   if (bb > 0 && eb == 64 && n <= (size_t(1) << 22)) bb = 0;      // (the merge path's mask: see sort_keys_db)
   KScope ks(c, tagged_sort_name("rocprim::radix_sort_keys<u64>"), n * 16);
-  PRIM2(rocprim::radix_sort_keys(tmp, tb, in, out, n, (unsigned)bb, (unsigned)eb, c->stream));
+  PRIM2((rocprim::radix_sort_keys<KeysCfg>(tmp, tb, in, out, n, (unsigned)bb, (unsigned)eb, c->stream)));
 }
 template void sort_keys_db<uint64_t>(pfp_ctx *, DBuf<uint64_t> &, DBuf<uint64_t> &, size_t, int, int);
 template void sort_pairs<uint64_t, uint32_t>(pfp_ctx *, const uint64_t *, uint64_t *, const uint32_t *, uint32_t *, size_t, int, int);

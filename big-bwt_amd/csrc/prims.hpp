@@ -26,6 +26,9 @@ inline void sort_pairs_u32_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, 
 // Both pairs must hold at least n elements.
 template <class K, class V>
 void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &valt, size_t n, int begin_bit, int end_bit);
+// digit width of the keys-only library sort (prims.hip: 9-bit onesweep digits for u64 keys): callers that choose their key width
+// round it to whole passes
+constexpr int kKeysDigitBits = 9;
 // keys only, ping-ponging between k and kalt (swapped when the last pass ended in the alternate).  The bits below
 // begin_bit must be a unique index that ascends with the input order (small inputs are sorted on the whole word)
 template <class K>

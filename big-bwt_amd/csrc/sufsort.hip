@@ -1486,7 +1486,7 @@ static int keysonly_bits(uint64_t N, double rep_hint, KeyCode &kc) {
   if (!(sizeof(I) == 4 && N >= 2 && (keysonly_env == 1 || (keysonly_env != 0 && rep_hint >= 2.0 && N >= (1u << 20))))) return 0;
   const int ib = bits_for(N - 1);
   int width = 64 - ib;                      // key bits incl. the terminator flag
-  if (width > 24 && width % 8 <= 2) width -= width % 8;       // a radix pass for one or two bits is a whole pass
+  if (width > 3 * kKeysDigitBits && width % kKeysDigitBits <= 2) width -= width % kKeysDigitBits;       // a radix pass for one or two bits is a whole pass
   // (measured: 36 key bits on 129 M suffixes - first sort 7.8 -> 3.9 ms, same rounds after it; 31 key bits on 1.7 G
   //  suffixes leave three times as many unresolved after the first pivot round - the pair sort stays there)
   if (!(width - 1 >= 35 || keysonly_env == 1)) return 0;

@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 *_kernel_stats.csv with short kernel names (used to write profiles/*.md)."""
-import csv, re, sys
+import csv, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocnames import sort_types
 rows = list(csv.DictReader(open(sys.argv[1])))
 def short(n):
     m = re.search(r'pfp::(\w+)(<\d+>)?', n)
     if m and 'rocprim' not in n[:40]: return 'pfp::' + m.group(1) + (m.group(2) or '')
     for k in ['onesweep_iteration', 'onesweep_global_offsets', 'partition_impl', 'scan_impl', 'block_sort', 'radix_sort_single', 'lookback_scan_state', 'init_lookback']:
         if k in n:
-            key = 'u64key' if re.search(r'onesweep_config<[^>]*unsigned long, unsigned int', n) else ('u32key' if 'onesweep' in n else '')
+            kv = sort_types(n)
+            key = ('%s%s' % (kv[0], ',' + kv[1] if kv[1] else ' keys')) if kv else ('u64key' if re.search(r'onesweep_config<[^>]*unsigned long, unsigned int', n) else ('u32key' if 'onesweep' in n else ''))
             return 'rocprim::' + k + (' ' + key if key else '')
     return n[:70]
 tot = sum(float(r['TotalDurationNs']) for r in rows)

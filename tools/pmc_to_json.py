@@ -6,7 +6,9 @@ Per kernel (bench.py's names): raw FETCH/WRITE bytes per chain execution and the
 2*FETCH + WRITE (gfx950: FETCH_SIZE reports half of the bytes of wide coalesced streaming reads,
 MI355X_MICROARCH.md 'HBM'; exact for WRITE_SIZE).  A chain = one pfp_bigbwt_dev call; the number of
 chains in the profiled run is the number of pfp::line_terms_kernel dispatches (the dictionary index: one per chain in every mode)."""
-import collections, csv, json, re, sys
+import collections, csv, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocnames import sort_types
 
 def bench_name(n):
     m = re.search(r'pfp::(\w+)', n)
@@ -15,15 +17,11 @@ def bench_name(n):
         # (round 4: bench.py's trace labels are the launched kernels' own names - no mapping table)
         return 'pfp::' + k
     if 'onesweep' in n or 'radix_sort' in n or 'block_sort' in n:
-        # the library's kernels carry the sort's key and value types: "..._config<default_config, KEY, VALUE>"
-        T = {'unsigned long': 'u64', 'unsigned int': 'u32', 'unsigned short': 'u16', 'unsigned char': 'u8'}
-        m = re.search(r'_config<[^,<>]*default_config, ([a-z ]+), ([A-Za-z0-9_: ]+?)>', n)
-        if m and m.group(1) in T:
-            k, v = T[m.group(1)], m.group(2)
-            if v.endswith('empty_type'):
-                return f'rocprim::radix_sort_keys<{k}>'
-            if v in T:
-                return f'rocprim::radix_sort_pairs<{k},{T[v]}>'
+        kv = sort_types(n)
+        if kv and kv[1] is None:
+            return f'rocprim::radix_sort_keys<{kv[0]}>'
+        if kv and kv[1]:
+            return f'rocprim::radix_sort_pairs<{kv[0]},{kv[1]}>'
         return 'rocprim::radix_sort_pairs<u64,u32>' if re.search(r'unsigned long, unsigned int|unsigned long,unsigned int', n) else 'rocprim::radix_sort_pairs<u32,u32>'
     return None
 
