@@ -35,7 +35,8 @@ const char *tagged_sort_name(const char *base) {
 // elements): u64 keys alone sort fastest with 9-bit digits in workgroups of 1024 x 8 keys (36 key bits: 4 passes instead of 5,
 // 2.55 -> 1.99 ms / 50.8 -> 41.1 ms); (u64, u32) and (u32, u32) pairs with the default 8-bit digit but 1024 x 7 (3.38 -> 2.87 ms
 // on 40 bits, 5.5 -> 4.85 on 64, 1.96 -> 1.72 for u32 keys; 1024 x 8 falls off a cliff: 4.1 ms); (u64, u64) pairs are best left alone.
-// Inputs of up to 2^20 elements keep the library's merge / single-block paths.
+// Inputs of up to 2^20 elements keep the library's merge / single-block paths; pairs below 6 M elements the library's own tile
+// (7168-element tiles leave CUs idle there: 2 M pairs 0.285 -> 0.329 ms, 4 M even, 8 M 0.67 -> 0.59; profiles/r04_sortcfg_small.txt).
 template <unsigned BS, unsigned IPT, unsigned BITS>
 using OnesweepCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<BS, IPT>, rocprim::kernel_config<BS, IPT>, BITS,
@@ -45,6 +46,7 @@ template <class K, class V> struct PairsCfgOf { using type = rocprim::default_co
 template <> struct PairsCfgOf<uint64_t, uint32_t> { using type = OnesweepCfg<1024, 7, 8>; };
 template <> struct PairsCfgOf<uint32_t, uint32_t> { using type = OnesweepCfg<1024, 7, 8>; };
 template <class K, class V> using PairsCfg = typename PairsCfgOf<K, V>::type;
+constexpr size_t kTunedPairsMin = size_t(6) << 20;
 template <class K, class V> static const char *sort_name() {
   if (sizeof(K) == 8 && sizeof(V) == 4) return "rocprim::radix_sort_pairs<u64,u32>";
   if (sizeof(K) == 4 && sizeof(V) == 4) return "rocprim::radix_sort_pairs<u32,u32>";
@@ -63,7 +65,8 @@ void sort_pairs(pfp_ctx *c, const K *kin, K *kout, const V *vin, V *vout, size_t
   if (!n) return;
   PFP_SORT_GUARD(K, bb, eb);
   KScope ks(c, tagged_sort_name(sort_name<K, V>()), n * 2 * (sizeof(K) + sizeof(V)));
-  PRIM2((rocprim::radix_sort_pairs<PairsCfg<K, V>>(tmp, tb, kin, kout, vin, vout, n, (unsigned)bb, (unsigned)eb, c->stream)));
+  if (n >= kTunedPairsMin) PRIM2((rocprim::radix_sort_pairs<PairsCfg<K, V>>(tmp, tb, kin, kout, vin, vout, n, (unsigned)bb, (unsigned)eb, c->stream)));
+  else PRIM2(rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, (unsigned)bb, (unsigned)eb, c->stream));
 }
 template <class K, class V>
 void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &valt, size_t n, int bb, int eb) {
@@ -73,7 +76,8 @@ void sort_pairs_db(pfp_ctx *c, DBuf<K> &k, DBuf<K> &kalt, DBuf<V> &v, DBuf<V> &v
   KScope ks(c, tagged_sort_name(sort_name<K, V>()), n * 2 * (sizeof(K) + sizeof(V)));
   rocprim::double_buffer<K> dk(k.p, kalt.p);
   rocprim::double_buffer<V> dv(v.p, valt.p);
-  PRIM2((rocprim::radix_sort_pairs<PairsCfg<K, V>>(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream)));
+  if (n >= kTunedPairsMin) PRIM2((rocprim::radix_sort_pairs<PairsCfg<K, V>>(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream)));
+  else PRIM2(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, (unsigned)bb, (unsigned)eb, c->stream));
   if (dk.current() != k.p) std::swap(k, kalt);
   if (dv.current() != v.p) std::swap(v, valt);
 }
