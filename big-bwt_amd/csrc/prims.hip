@@ -112,14 +112,19 @@ template void sort_pairs_db<uint64_t, uint32_t>(pfp_ctx *, DBuf<uint64_t> &, DBu
 template void sort_pairs_db<uint64_t, uint64_t>(pfp_ctx *, DBuf<uint64_t> &, DBuf<uint64_t> &, DBuf<uint64_t> &, DBuf<uint64_t> &, size_t, int, int);
 template void sort_pairs_db<u128, uint64_t>(pfp_ctx *, DBuf<u128> &, DBuf<u128> &, DBuf<uint64_t> &, DBuf<uint64_t> &, size_t, int, int);
 
+// The segmented sort's tile (round 4; 12.6 GB -s, whose later rounds hand it groups of hundreds to a thousand members): the library's
+// gfx942 default gives every segment above 128 elements a workgroup tile of 256 x 16 = 4096, mostly empty here.  256 x 4: 15.4 -> 11.6 ms
+// (u32 keys) and 10.1 -> ~6 ms (u64 keys) per step; 256 x 8 / x 6 / x 3 / x 2 and 128 x 4 in between; wave-wide "medium" warp sorts
+// (64 lanes x 8) three times slower (49 ms).  Outputs identical (full-size digests), configs[2] / c2r unchanged.
+using SegCfg = rocprim::segmented_radix_sort_config<8, rocprim::kernel_config<256, 4>, rocprim::WarpSortConfig<8, 4, 256, 64, 16, 8, 256>, 1>;
 template <class V>
 void segsort_pairs_u32(pfp_ctx *c, const uint32_t *kin, uint32_t *kout, const V *vin, V *vout, size_t n,
                        size_t nseg, const uint32_t *seg_begin, const uint32_t *seg_end, int bb, int eb) {
   if (!n || !nseg) return;
   PFP_REQUIRE(n < 0xFFFFFFFFull, PFP_ELIMIT, "segmented sort of 2^32 or more elements");
   KScope ks(c, "rocprim::segmented_radix_sort_pairs<u32,u32>", n * (8 + 2 * sizeof(V)) + nseg * 8);
-  PRIM2(rocprim::segmented_radix_sort_pairs(tmp, tb, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, seg_begin, seg_end,
-                                            (unsigned)bb, (unsigned)eb, c->stream));
+  PRIM2((rocprim::segmented_radix_sort_pairs<SegCfg>(tmp, tb, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, seg_begin, seg_end,
+                                                     (unsigned)bb, (unsigned)eb, c->stream)));
 }
 template void segsort_pairs_u32<uint32_t>(pfp_ctx *, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, size_t, size_t,
                                           const uint32_t *, const uint32_t *, int, int);
@@ -131,8 +136,8 @@ void segsort_pairs_u64_u32(pfp_ctx *c, const uint64_t *kin, uint64_t *kout, cons
   if (!n || !nseg) return;
   PFP_REQUIRE(n < 0xFFFFFFFFull, PFP_ELIMIT, "segmented sort of 2^32 or more elements");
   KScope ks(c, "rocprim::segmented_radix_sort_pairs<u64,u32>", n * (16 + 8) + nseg * 8);
-  PRIM2(rocprim::segmented_radix_sort_pairs(tmp, tb, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, seg_begin, seg_end,
-                                            (unsigned)bb, (unsigned)eb, c->stream));
+  PRIM2((rocprim::segmented_radix_sort_pairs<SegCfg>(tmp, tb, kin, kout, vin, vout, (unsigned)n, (unsigned)nseg, seg_begin, seg_end,
+                                                     (unsigned)bb, (unsigned)eb, c->stream)));
 }
 
 void exclusive_sum_u32(pfp_ctx *c, const uint32_t *in, uint32_t *out, size_t n) {
