@@ -35,13 +35,17 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
   return k;
 }
 
-// sum over the 8 lanes of an aligned 8-lane group
-__device__ __forceinline__ uint64_t group8_sum(uint64_t v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+// sum / or over the 2^LG lanes of an aligned lane group (LG = 2 or 3)
+template <int LG>
+__device__ __forceinline__ uint64_t group_sum(uint64_t v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+  if (LG > 2) v += __shfl_xor(v, 4, 64);
   return v;
 }
-__device__ __forceinline__ uint32_t group8_or(uint32_t v) {
-  v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64); v |= __shfl_xor(v, 4, 64);
+template <int LG>
+__device__ __forceinline__ uint32_t group_or(uint32_t v) {
+  v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64);
+  if (LG > 2) v |= __shfl_xor(v, 4, 64);
   return v;
 }
 

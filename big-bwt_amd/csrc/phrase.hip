@@ -61,13 +61,16 @@ __device__ __forceinline__ uint64_t finish_hash(uint64_t sum, uint64_t len) {
   return fmix64(sum ^ (len * 0xA24BAED4963EE407ULL));
 }
 
+// 2^LG lanes per phrase, 16 bytes a lane and step: 8 lanes for phrases of ~100 bytes (the nominal -p 100), 4 where the chain chose
+// phrases of ~48 bytes (with 8 lanes five of them had nothing to hash).  The sum of the terms does not depend on who adds them.
+template <int LG>
 __global__ __launch_bounds__(256) void phrase_hash_kernel(const uint8_t *__restrict__ tp, PhraseGeom g, uint64_t P,
                                                           uint64_t seed, uint64_t *__restrict__ hash,
                                                           uint32_t *__restrict__ long_list,
                                                           uint32_t *__restrict__ long_count) {
   uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
-  uint64_t k = t >> 3;
-  int l8 = (int)(t & 7);
+  uint64_t k = t >> LG;
+  int l8 = (int)(t & ((1u << LG) - 1u));
   if (k >= P) return;
   uint64_t s = ph_start(g, k), len = ph_end(g, k) - s + 1;
   if (len > kLongPhrase) {
@@ -75,10 +78,12 @@ __global__ __launch_bounds__(256) void phrase_hash_kernel(const uint8_t *__restr
     return;
   }
   uint64_t sum = 0;
-  for (uint64_t off = (uint64_t)l8 * 16; off < len; off += 128) sum += piece_terms(tp + s, off, len, seed);
-  sum = group8_sum(sum);
+  for (uint64_t off = (uint64_t)l8 * 16; off < len; off += (16u << LG)) sum += piece_terms(tp + s, off, len, seed);
+  sum = group_sum<LG>(sum);
   if (l8 == 0) hash[k] = finish_hash(sum, len);
 }
+// lanes per phrase from the average phrase length
+static inline int lanes_log2_for(uint64_t bytes, uint64_t phrases) { return phrases && bytes / phrases <= 72 ? 2 : 3; }
 
 __global__ __launch_bounds__(256) void phrase_hash_long_kernel(const uint8_t *__restrict__ tp, PhraseGeom g,
                                                                uint64_t seed, const uint32_t *__restrict__ long_list,
@@ -118,13 +123,14 @@ __global__ void iota_u32_kernel(uint32_t *p, uint64_t n) {
 }
 
 // sorted by hash: head flags + byte verification against the predecessor
+template <int LG>
 __global__ __launch_bounds__(256) void dedup_verify_kernel(const uint8_t *__restrict__ tp, PhraseGeom g, uint64_t P,
                                                            const uint64_t *__restrict__ ks,
                                                            const uint32_t *__restrict__ vs,
                                                            uint32_t *__restrict__ head, uint32_t *__restrict__ collision) {
   uint64_t t = (uint64_t)BID * 256 + threadIdx.x;
-  uint64_t i = t >> 3;
-  int l8 = (int)(t & 7);
+  uint64_t i = t >> LG;
+  int l8 = (int)(t & ((1u << LG) - 1u));
   if (i >= P) return;
   bool hd = (i == 0) || ks[i] != ks[i - 1];
   if (l8 == 0) head[i] = hd ? 1u : 0u;
@@ -134,13 +140,13 @@ __global__ __launch_bounds__(256) void dedup_verify_kernel(const uint8_t *__rest
   uint64_t sb = ph_start(g, b), lb = ph_end(g, b) - sb + 1;
   uint32_t diff = (la != lb) ? 1u : 0u;
   if (!diff && sa != sb) {
-    for (uint64_t off = (uint64_t)l8 * 16; off < la; off += 128) {
+    for (uint64_t off = (uint64_t)l8 * 16; off < la; off += (16u << LG)) {
       int keep = (la - off) >= 16 ? 16 : (int)(la - off);
       uint4 va = keep_bytes16(ld16u(tp + sa + off), keep), vb = keep_bytes16(ld16u(tp + sb + off), keep);
       diff |= (va.x ^ vb.x) | (va.y ^ vb.y) | (va.z ^ vb.z) | (va.w ^ vb.w);
     }
   }
-  diff = group8_or(diff);
+  diff = group_or<LG>(diff);
   if (diff && l8 == 0) atomicOr(collision, 1u);
 }
 
@@ -262,7 +268,7 @@ void hash_word_list(pfp_ctx *c, const uint8_t *bytes, const uint64_t *wstart, co
   PhraseGeom g{nullptr, 0, 0, 0, 0, wstart, wlen};
   DBuf<uint32_t> long_list(c, U), counters(c, 1);
   counters.zero();
-  hipLaunchKernelGGL(phrase_hash_kernel, gdim(cdiv(U * 8, TB)), gdim(TB), 0, c->stream, bytes, g, U, seed, d_hash, long_list.p, counters.p);
+  hipLaunchKernelGGL(phrase_hash_kernel<3>, gdim(cdiv(U * 8, TB)), gdim(TB), 0, c->stream, bytes, g, U, seed, d_hash, long_list.p, counters.p);
   const uint32_t nlong = read_scalar(c, counters.p);
   if (nlong) {
     DBuf<unsigned long long> hsum(c, nlong);
@@ -294,11 +300,12 @@ static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, u
   hipLaunchKernelGGL(iota_u32_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, iota.p, P);
   uint64_t seed = 0x243F6A8885A308D3ULL;
   uint32_t d = 0;
+  const int lg = lanes_log2_for(n, P);
   for (int attempt = 0;; attempt++) {
     counters.zero();
     { KScope kscope(c, "pfp::phrase_hash_kernel", n + 16 * P);
-    hipLaunchKernelGGL(phrase_hash_kernel, gdim(cdiv(P * 8, TB)), gdim(TB), 0, c->stream, tp, g, P, seed, hash.p,
-                       long_list.p, counters.p); }
+    if (lg == 2) hipLaunchKernelGGL(phrase_hash_kernel<2>, gdim(cdiv(P * 4, TB)), gdim(TB), 0, c->stream, tp, g, P, seed, hash.p, long_list.p, counters.p);
+    else hipLaunchKernelGGL(phrase_hash_kernel<3>, gdim(cdiv(P * 8, TB)), gdim(TB), 0, c->stream, tp, g, P, seed, hash.p, long_list.p, counters.p); }
     uint32_t nlong = read_scalar(c, counters.p);
     if (nlong) {
       DBuf<unsigned long long> hsum(c, nlong);
@@ -318,8 +325,8 @@ static void build_dictionary_core(pfp_ctx *c, const uint8_t *tp, PhraseGeom g, u
     }
     { SortTag tag("phrase hashes"); sort_pairs_u64_u32(c, hash.p, ks.p, iota.p, vs.p, P, 0, 64); }
     { KScope kscope(c, "pfp::dedup_verify_kernel", 2 * n + 16 * P);
-    hipLaunchKernelGGL(dedup_verify_kernel, gdim(cdiv(P * 8, TB)), gdim(TB), 0, c->stream, tp, g, P, ks.p, vs.p, head.p,
-                       counters.p + 1); }
+    if (lg == 2) hipLaunchKernelGGL(dedup_verify_kernel<2>, gdim(cdiv(P * 4, TB)), gdim(TB), 0, c->stream, tp, g, P, ks.p, vs.p, head.p, counters.p + 1);
+    else hipLaunchKernelGGL(dedup_verify_kernel<3>, gdim(cdiv(P * 8, TB)), gdim(TB), 0, c->stream, tp, g, P, ks.p, vs.p, head.p, counters.p + 1); }
     inclusive_sum_u32(c, head.p, hscan.p, P);
     PFP_HIP(hipGetLastError());
     PFP_HIP(hipMemcpyAsync(c->h_scalars, counters.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
