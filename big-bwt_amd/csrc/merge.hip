@@ -178,20 +178,35 @@ template void compute_lexrank<uint64_t>(pfp_ctx *, const Dictionary &, SuffixOrd
 
 // bwtparse.c:242-267: BWT(P)[j] = P[SA[j]-1]; bwlast = last of the phrase before that one
 // (cyclically), bwsai = sai of that phrase; SA[j]==0 -> dummy zeros.
-__global__ void parse_gather_kernel(uint64_t P, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ sym,
-                                    const uint8_t *__restrict__ last, const uint64_t *__restrict__ sai,
-                                    uint32_t *__restrict__ bwtp, uint8_t *__restrict__ bwlast,
-                                    uint64_t *__restrict__ bwsai, uint32_t *__restrict__ jidx) {
-  uint64_t j = (uint64_t)BID * blockDim.x + threadIdx.x;
+// From ONE record per phrase (round 4; three gathers - sym, last, sai - before): {symbol, last char of the phrase before, sai} packed in parse order by a streaming
+// pass, so that the suffix-array order costs one random 16-byte (8-byte without sai) access per phrase instead of three.
+__global__ void parse_pack16_kernel(uint64_t P, const uint32_t *__restrict__ sym, const uint8_t *__restrict__ last,
+                                    const uint64_t *__restrict__ sai, uint4 *__restrict__ rec) {
+  const uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  const uint64_t v = sai[t];
+  rec[t] = make_uint4(sym[t], (uint32_t)(t == 0 ? last[P - 1] : last[t - 1]), (uint32_t)v, (uint32_t)(v >> 32));
+}
+__global__ void parse_pack8_kernel(uint64_t P, const uint32_t *__restrict__ sym, const uint8_t *__restrict__ last, uint2 *__restrict__ rec) {
+  const uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  rec[t] = make_uint2(sym[t], (uint32_t)(t == 0 ? last[P - 1] : last[t - 1]));
+}
+template <class R>
+__global__ void parse_gather_rec_kernel(uint64_t P, const uint32_t *__restrict__ sa, const R *__restrict__ rec,
+                                        uint32_t *__restrict__ bwtp, uint8_t *__restrict__ bwlast,
+                                        uint64_t *__restrict__ bwsai, uint32_t *__restrict__ jidx) {
+  const uint64_t j = (uint64_t)BID * blockDim.x + threadIdx.x;
   if (j > P) return;
-  uint64_t s = sa[j];
+  const uint64_t s = sa[j];
   jidx[j] = (uint32_t)j;
   if (s == 0) {
-    bwtp[j] = 0; bwlast[j] = 0; if (bwsai) bwsai[j] = 0;
+    bwtp[j] = 0; bwlast[j] = 0;
+    if constexpr (sizeof(R) == 16) bwsai[j] = 0;
   } else {
-    bwtp[j] = sym[s - 1];
-    bwlast[j] = (s == 1) ? last[P - 1] : last[s - 2];
-    if (bwsai) bwsai[j] = sai[s - 1];
+    const R r = rec[s - 1];
+    bwtp[j] = r.x; bwlast[j] = (uint8_t)r.y;
+    if constexpr (sizeof(R) == 16) bwsai[j] = (uint64_t)r.z | ((uint64_t)r.w << 32);
   }
 }
 
@@ -215,8 +230,21 @@ void parse_bwt(pfp_ctx *c, const uint32_t *parse_sym, uint64_t P, const uint8_t 
   out.bwlast.alloc(c, P + 1);
   if (sai) out.bwsai.alloc(c, P + 1);
   DBuf<uint32_t> bwtp(c, P + 1), bwtp_s(c, P + 1), jidx(c, P + 1);
-  hipLaunchKernelGGL(parse_gather_kernel, gdim(cdiv(P + 1, TB)), gdim(TB), 0, c->stream, P, so.sa.p, sym.p, last, sai,
-                     bwtp.p, out.bwlast.p, sai ? out.bwsai.p : (uint64_t *)nullptr, jidx.p);
+  if (sai) {
+    DBuf<uint4> rec(c, P);
+    { KScope ks(c, "pfp::parse_pack16_kernel", P * (13 + 16));
+      hipLaunchKernelGGL(parse_pack16_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, P, (const uint32_t *)sym.p, last, sai, rec.p); }
+    KScope ks(c, "pfp::parse_gather_rec_kernel", (P + 1) * (4 + 16 + 4 + 1 + 8 + 4));
+    hipLaunchKernelGGL(parse_gather_rec_kernel<uint4>, gdim(cdiv(P + 1, TB)), gdim(TB), 0, c->stream, P, (const uint32_t *)so.sa.p, (const uint4 *)rec.p,
+                       bwtp.p, out.bwlast.p, out.bwsai.p, jidx.p);
+  } else {
+    DBuf<uint2> rec(c, P);
+    { KScope ks(c, "pfp::parse_pack8_kernel", P * (5 + 8));
+      hipLaunchKernelGGL(parse_pack8_kernel, gdim(cdiv(P, TB)), gdim(TB), 0, c->stream, P, (const uint32_t *)sym.p, last, rec.p); }
+    KScope ks(c, "pfp::parse_gather_rec_kernel", (P + 1) * (4 + 8 + 4 + 1 + 4));
+    hipLaunchKernelGGL(parse_gather_rec_kernel<uint2>, gdim(cdiv(P + 1, TB)), gdim(TB), 0, c->stream, P, (const uint32_t *)so.sa.p, (const uint2 *)rec.p,
+                       bwtp.p, out.bwlast.p, (uint64_t *)nullptr, jidx.p);
+  }
   // bwtparse.c:281-303: positions grouped by symbol, ascending inside a group == stable sort
   { SortTag tag("inverted list"); sort_pairs_u32_u32(c, bwtp.p, bwtp_s.p, jidx.p, out.ilist.p, P + 1, 0, bits_for(d)); }
   PFP_HIP(hipGetLastError());
