@@ -929,25 +929,33 @@ template <class I>
 __global__ void finish_rank_kernel(SufGeom g, const uint8_t *__restrict__ s, uint64_t m, const I *__restrict__ act_i,
                                    const I *__restrict__ act_grp, uint32_t *__restrict__ lt, uint32_t *__restrict__ eq,
                                    uint32_t *__restrict__ gstart, uint32_t *__restrict__ overflow) {
-  const uint64_t a = (uint64_t)BID * blockDim.x + threadIdx.x;
+  // eight lanes per member, each comparing it with every eighth other member of its group (one lane per member was a chain of up
+  // to 63 dependent string comparisons: 0.27 ms a launch for a few ten thousand members - the kernel's time is that chain's latency)
+  const uint64_t t = (uint64_t)BID * blockDim.x + threadIdx.x;
+  const uint64_t a = t >> 3;
+  const int l8 = (int)(t & 7);
   if (a >= m) return;
   const I grp = act_grp[a];
   uint64_t gs = a, ge = a + 1;
   while (gs > 0 && a - gs < (uint64_t)kFinishGrp && act_grp[gs - 1] == grp) gs--;
   while (ge < m && ge - gs <= (uint64_t)kFinishGrp && act_grp[ge] == grp) ge++;
-  if (ge - gs > (uint64_t)kFinishGrp || (gs > 0 && act_grp[gs - 1] == grp)) { atomicOr(overflow, 1u); return; }
+  if (ge - gs > (uint64_t)kFinishGrp || (gs > 0 && act_grp[gs - 1] == grp)) { if (l8 == 0) atomicOr(overflow, 1u); return; }
   const uint64_t ia = act_i[a];
   uint32_t nlt = 0, neq = 0, ovf = 0;
-  for (uint64_t b = gs; b < ge; b++) {
+  for (uint64_t b = gs + (uint64_t)l8; b < ge; b += 8) {
     if (b == a) continue;
-    if (*(volatile uint32_t *)overflow) return;      // somebody met a case for the rounds: no point in finishing the comparisons
+    if (*(volatile uint32_t *)overflow) break;      // somebody met a case for the rounds: no point in finishing the comparisons
     const uint64_t ib = act_i[b];
     const int cmp = g.mode == MODE_DICT ? finish_cmp_dict(s, ib, ia, &ovf) : finish_cmp_int(g.sym, ib, ia, &ovf);
     if (cmp < 0) nlt++;
     else if (cmp == 0 && b < a) neq++;
   }
-  if (ovf) atomicOr(overflow, 1u);
-  lt[a] = nlt; eq[a] = neq; gstart[a] = (uint32_t)gs;
+  // (all eight lanes of a member arrive here together: everything above the loop is the same for them)
+  uint32_t packed = nlt | (neq << 8) | (ovf << 16);      // <= 63 each
+  packed += __shfl_xor(packed, 1, 64); packed += __shfl_xor(packed, 2, 64); packed += __shfl_xor(packed, 4, 64);
+  if (l8 != 0) return;
+  if (packed >> 16) atomicOr(overflow, 1u);
+  lt[a] = packed & 0xffu; eq[a] = (packed >> 8) & 0xffu; gstart[a] = (uint32_t)gs;
 }
 template <class I>
 __global__ void finish_write_kernel(SufGeom g, uint64_t m, const I *__restrict__ aslot, const I *__restrict__ act_i, const uint32_t *__restrict__ lt,
@@ -1287,7 +1295,7 @@ static void doubling(pfp_ctx *c, SufGeom g, DBuf<uint64_t> &key, DBuf<I> &val, u
       DBuf<uint32_t> flt(c, m), feq(c, m), fgs(c, m), fov(c, 1);
       fov.zero();
       KScope ks(c, "pfp::finish_rank_kernel", m * (sizeof(I) * 4 + 12));
-      hipLaunchKernelGGL(finish_rank_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, out.bytes, m, act_i.p, act_grp.p, flt.p, feq.p,
+      hipLaunchKernelGGL(finish_rank_kernel<I>, gdim(cdiv(m * 8, TB)), gdim(TB), 0, c->stream, g, out.bytes, m, act_i.p, act_grp.p, flt.p, feq.p,
                          fgs.p, fov.p);
       if (read_scalar(c, fov.p) == 0) {
         hipLaunchKernelGGL(finish_write_kernel<I>, gdim(cdiv(m, TB)), gdim(TB), 0, c->stream, g, m, aslot.p, act_i.p, flt.p, feq.p, fgs.p,
