@@ -1,7 +1,7 @@
 // does a wider onesweep digit pay?  rocPRIM's default is 8 bits per pass; radix_sort_onesweep_config takes up to log2(block size).
 // The chain's first-round sorts: 80 M u64 keys on bits [28, 64) (configs[2] dictionary, keys only: 5 passes of 8 bits, 4 of 9),
 // (u64, u32) pairs on 40 bits (12.6 GB dictionary: 5 passes, 4 of 10) and on 64 bits (phrase hashes: 8 passes, 7 of 10).
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -o sortcfg sortcfg.hip && ./sortcfg [millions of elements]
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o sortcfg sortcfg.hip && ./sortcfg [millions of elements] [other]   (built on demand: 40 MB, not kept in the tree)
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
